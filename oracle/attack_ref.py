@@ -1,0 +1,108 @@
+"""Oracle (TEST INFRASTRUCTURE, see oracle/__init__.py): the PGD / Adam-ascent perturbation loop on the
+source images, PyTorch-CPU fp32.
+
+ref: eval/ibrnet/eval_adv.py:28-29 (clamp), :248-254 (init_adv_perturb), :258-310,512-519
+(optimize_adv_perturb, rgb-loss path), :783-843 (view-specific loop), :634-740 (universal loop).
+"""
+import numpy as np
+import torch
+
+from . import feature_net_ref as fnet
+from . import ibrnet_ref as ib
+
+
+def clamp(X, lower_limit, upper_limit):
+    """ref: eval/ibrnet/eval_adv.py:28-29 -- max(min(X, hi), lo) with tensor or scalar bounds."""
+    lo = lower_limit if torch.is_tensor(lower_limit) else torch.tensor(lower_limit, dtype=X.dtype)
+    hi = upper_limit if torch.is_tensor(upper_limit) else torch.tensor(upper_limit, dtype=X.dtype)
+    return torch.max(torch.min(X, hi), lo)
+
+
+def init_adv_perturb(src_rgbs, epsilon, upper_limit=1.0, lower_limit=0.0, generator=None):
+    """ref: eval/ibrnet/eval_adv.py:248-254: delta ~ U(-eps, eps), then projected so that src+delta in [0,1]."""
+    delta = torch.zeros_like(src_rgbs)
+    delta.uniform_(-float(epsilon), float(epsilon), generator=generator)
+    delta = clamp(delta, lower_limit - src_rgbs, upper_limit - src_rgbs)
+    return delta.requires_grad_(True)
+
+
+def attack_loss(delta, cnn_state, params_coarse, params_fine, src_ray_batch, train_ray_batch, cfg):
+    """ref: eval/ibrnet/eval_adv.py:292-310 -- features from PERTURBED images, colours from CLEAN images."""
+    imgs = (src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2)
+    featmaps = fnet.resunet_forward(cnn_state, imgs)
+    ret = ib.render_rays(train_ray_batch, params_coarse, params_fine, featmaps, cfg['N_samples'],
+                         inv_uniform=cfg['inv_uniform'], N_importance=cfg['N_importance'], det=True,
+                         white_bkgd=cfg.get('white_bkgd', False), src_ray_batch=src_ray_batch,
+                         anti_alias_pooling=cfg.get('anti_alias_pooling', True))
+    loss = ib.criterion(ret['outputs_coarse'], train_ray_batch)
+    if ret['outputs_fine'] is not None:
+        loss = loss + ib.criterion(ret['outputs_fine'], train_ray_batch)
+    return loss, ret
+
+
+class AdamAscent:
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) applied to g = -dL/d(delta), with StepLR(step, gamma),
+    written out explicitly (ref: eval/ibrnet/eval_adv.py:789-790, 805-819)."""
+
+    def __init__(self, shape, lr, step_size=100, gamma=0.5):
+        self.m = torch.zeros(shape)
+        self.v = torch.zeros(shape)
+        self.t = 0
+        self.lr0, self.step_size, self.gamma = lr, step_size, gamma
+
+    def lr(self):
+        return self.lr0 * self.gamma ** (self.t // self.step_size)
+
+    def step(self, delta, grad):
+        """Same operation order as torch.optim.Adam's single-tensor path (lerp_, mul_/addcmul_, addcdiv_)."""
+        g = -grad
+        lr = self.lr()
+        self.t += 1
+        self.m = self.m + (g - self.m) * (1 - 0.9)
+        self.v = self.v * 0.999 + (1 - 0.999) * (g * g)
+        bc1 = 1.0 - 0.9 ** self.t
+        bc2 = 1.0 - 0.999 ** self.t
+        denom = self.v.sqrt() / (bc2 ** 0.5) + 1e-8
+        return delta + (-(lr / bc1)) * (self.m / denom)
+
+
+def project(delta, src_rgbs, epsilon, upper_limit=1.0, lower_limit=0.0):
+    """ref: eval/ibrnet/eval_adv.py:838-839 -- eps-ball, then the [0,1] image box."""
+    delta = clamp(delta, -epsilon, epsilon)
+    return clamp(delta, lower_limit - src_rgbs, upper_limit - src_rgbs)
+
+
+def pgd_attack(delta0, cnn_state, params_coarse, params_fine, src_ray_batch, ray_batches, cfg, n_iters,
+               use_adam=True, adam_lr=1e-3, lr_step_size=100, lr_gamma=0.5, adv_lr=2.0, epsilon=8.0,
+               record=()):
+    """View-specific loop (ref :796-843): `ray_batches` is a callable it -> train_ray_batch (already-sampled rays).
+    Returns final delta, list of losses, and snapshots {it: delta} for iterations in `record`."""
+    eps = epsilon / 255.0
+    alpha = adv_lr / 255.0
+    delta = delta0.detach().clone()
+    opt = AdamAscent(delta.shape, adam_lr, lr_step_size, lr_gamma) if use_adam else None
+    losses, snaps = [], {}
+    src = src_ray_batch['src_rgbs']
+    for it in range(n_iters):
+        d = delta.clone().requires_grad_(True)
+        loss, _ = attack_loss(d, cnn_state, params_coarse, params_fine, src_ray_batch, ray_batches(it), cfg)
+        grad, = torch.autograd.grad(loss, d)
+        losses.append(float(loss))
+        if use_adam:
+            delta = opt.step(delta, grad)
+        else:
+            delta = delta + alpha * torch.sign(grad)
+        delta = project(delta, src, eps)
+        if (it + 1) in record:
+            snaps[it + 1] = delta.clone()
+    return delta, losses, snaps, opt
+
+
+def pick_pixels(rng, n_pixels, n_rand):
+    """ref: ibrnet/sample_ray.py:146-148 -- rng.choice(H*W, N_rand, replace=False) on RandomState(234)."""
+    return rng.choice(n_pixels, size=(n_rand,), replace=False)
+
+
+def new_pixel_rng():
+    """ref: ibrnet/sample_ray.py:20."""
+    return np.random.RandomState(234)

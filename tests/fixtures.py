@@ -1,0 +1,55 @@
+"""Loader for the committed golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+STAGE_CASES = ['ibrnet_tiny_invu', 'ibrnet_tiny_lin_white', 'ibrnet_tiny_noaa_v5', 'ibrnet_medium']
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, name + '.npz'))
+
+    def __contains__(self, k):
+        return k in self.z.files
+
+    def np(self, k):
+        return self.z[k]
+
+    def t(self, k, device='cpu'):
+        a = self.z[k]
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+    def params(self, prefix, device='cpu'):
+        out = OrderedDict()
+        for k in self.z.files:
+            if k.startswith(prefix + '/'):
+                out[k[len(prefix) + 1:]] = self.t(k, device)
+        return out or None
+
+    def stage_cfg(self):
+        H, W, V, R, S, N_imp, inv_u, white, aa, Hf, Wf = [int(x) for x in self.z['cfg']]
+        return dict(H=H, W=W, V=V, R=R, S=S, N_importance=N_imp, inv_uniform=bool(inv_u), white_bkgd=bool(white),
+                    anti_alias_pooling=bool(aa), Hf=Hf, Wf=Wf)
+
+    def ray_batch(self, device='cpu'):
+        return {'ray_o': self.t('in/ray_o', device), 'ray_d': self.t('in/ray_d', device),
+                'rgb': self.t('in/gt_rgb', device), 'camera': self.t('in/camera', device),
+                'depth_range': self.t('in/depth_range', device), 'src_rgbs': self.t('in/src_rgbs', device),
+                'src_cameras': self.t('in/src_cameras', device)}
+
+
+def assert_close(a, b, rtol=1e-4, atol=1e-5, name='', frac_ok=0.0):
+    """|a-b| <= atol + rtol*|b| elementwise; `frac_ok` tolerates that fraction of outliers (discrete flips)."""
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (name, a.shape, b.shape)
+    bad = np.abs(a - b) > atol + rtol * np.abs(b)
+    if bad.mean() > frac_ok:
+        i = np.unravel_index(np.argmax(np.abs(a - b) - rtol * np.abs(b)), a.shape) if a.ndim else ()
+        raise AssertionError('%s: %d/%d elements off (max abs err %.3e at %s: %r vs %r)'
+                             % (name, bad.sum(), bad.size, np.abs(a - b).max(), i, a[i], b[i]))
