@@ -1,0 +1,145 @@
+/*
+ * nerfool_hip.h -- C ABI of libnerfool_hip.so: the MI355X (gfx950) implementation of NeRFool's adversarial inner
+ * loop (IBRNet flavour).  Plain pointers and sizes only; every pointer is a DEVICE pointer unless marked HOST.
+ * Every call enqueues work on `stream` (a hipStream_t passed as void*) and returns immediately; 0 = ok, any other
+ * value = error (text via nf_last_error()).  The library never allocates or frees device memory: outputs and
+ * workspaces are provided by the caller (the Python host layer borrows torch storage).
+ *
+ * Each entry point names the reference function it replaces (paths relative to the GATECH-EIC/NeRFool tree).
+ * The reference is pure Python/PyTorch and has no FFI of its own; INTEGRATION.md shows the ctypes stub a
+ * maintainer would add.
+ */
+#ifndef NERFOOL_HIP_H
+#define NERFOOL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NF_ABI_VERSION 1
+
+typedef void* nf_stream_t; /* hipStream_t */
+
+int nf_abi_version(void);
+const char* nf_last_error(void);
+/* number of compute units of the current device (HOST query, used by the host layer to size grids/chunks) */
+int nf_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a2  sample_along_camera_ray            ref: ibrnet/render_ray.py:73-116
+ * depth_range: device [2] = (near, far).  t_rand: nullable [R,S] uniform numbers (det=False stratified jitter).
+ * Writes z_vals [R,S] and pts [R,S,3].
+ * ---------------------------------------------------------------------------------------------------------------- */
+int nf_sample_along_ray(const float* ray_o, const float* ray_d, const float* depth_range, int64_t n_rays,
+                        int n_samples, int inv_uniform, const float* t_rand, float* pts, float* z_vals,
+                        nf_stream_t stream);
+
+/* pts[r,s,:] = z[r,s] * ray_d[r] + ray_o[r]        ref: ibrnet/render_ray.py:241-243 */
+int nf_points_from_depths(const float* ray_o, const float* ray_d, const float* z_vals, int64_t n_rays,
+                          int n_samples, float* pts, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a3  Projector.compute                  ref: ibrnet/projection.py:89-132 (+ :42-62, :64-87, :24-35)
+ *
+ * nf_camera_setup turns the reference camera vectors ([34] = H, W, K 4x4, c2w 4x4 row-major) into the per-view
+ * table the gather kernels read: cam_ws [(V+1) * 16] floats; view v: [0..11] rows 0..2 of K*inv(c2w), [12..14]
+ * camera centre; entry V (query camera): [0]=h, [1]=w of the SOURCE images, [12..14] query camera centre.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int nf_camera_setup(const float* query_camera, const float* src_cameras, int n_views, float* cam_ws,
+                    nf_stream_t stream);
+
+/* xyz [N,3] (N = R*S points), src_rgbs [V,H,W,3], featmap: V x C x Hf x Wf addressed through element strides
+ * (fs_v, fs_c, fs_h, fs_w) so NCHW and channels-last maps are both accepted without a copy.
+ * Outputs: rgb_feat [N,V,3+C], ray_diff [N,V,4], mask [N,V] (0/1 floats); pix (nullable) [V,N,2] pixel locations. */
+int nf_project_gather_fwd(const float* xyz, int64_t n_pts, const float* cam_ws, int n_views, const float* src_rgbs,
+                          int H, int W, const float* featmap, int C, int Hf, int Wf, int64_t fs_v, int64_t fs_c,
+                          int64_t fs_h, int64_t fs_w, float* rgb_feat, float* ray_diff, float* mask, float* pix,
+                          nf_stream_t stream);
+
+/* pixel_mask[n] = (sum_v mask[n,v]) > 1   (bytes 0/1)        ref: ibrnet/render_ray.py:210,249 */
+int nf_pixel_mask(const float* mask, int64_t n_pts, int n_views, uint8_t* pixel_mask, nf_stream_t stream);
+
+/* Backward of the bilinear FEATURE gather (the rgb taps and ray_diff carry no gradient in the attack):
+ * d_featmap[v, c, y, x] += tap weights * d_rgb_feat[n, v, 3 + c]   (float atomics; d_featmap must be pre-zeroed or
+ * hold the gradient being accumulated; same stride convention as the forward). */
+int nf_project_gather_bwd(const float* xyz, int64_t n_pts, const float* cam_ws, int n_views, int H, int W,
+                          const float* d_rgb_feat, int C, int Hf, int Wf, int64_t fs_v, int64_t fs_c, int64_t fs_h,
+                          int64_t fs_w, float* d_featmap, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a4/a5  IBRNet.forward (+ MultiHeadAttention)      ref: ibrnet/mlp_network.py:222-274, :69-119, :23-43
+ *
+ * The 20 136 parameters travel as ONE packed blob; nf_ibrnet_blob_entry enumerates its layout so that the host
+ * packs a reference state-dict by key (HOST function, no GPU needed):
+ *   idx -> name (state-dict key), offset (floats), rows, cols, transposed (1: stored [in][out]), returns 0 while
+ *   idx is valid, 1 past the end.  nf_ibrnet_blob_floats() = total length.
+ * pos_enc [S,16] is the `pos_encoding` buffer (depends on S, not part of checkpoints).
+ * rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V] -> raw [R,S,4] (rgb, sigma).
+ * workspace: nf_ibrnet_workspace_floats(R,S,V,backward) floats.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int64_t nf_ibrnet_blob_floats(void);
+int nf_ibrnet_blob_entry(int idx, char* name, int name_cap, int64_t* offset, int* rows, int* cols, int* transposed);
+int64_t nf_ibrnet_workspace_floats(int64_t n_rays, int n_samples, int n_views, int backward);
+int nf_ibrnet_fwd(const float* blob, const float* pos_enc, const float* rgb_feat, const float* ray_diff,
+                  const float* mask, int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling,
+                  float* raw, float* workspace, nf_stream_t stream);
+/* d_raw [R,S,4] -> d_rgb_feat [R,S,V,35] (all 35 channels; the weights are constants of the attack) */
+int nf_ibrnet_bwd(const float* blob, const float* pos_enc, const float* rgb_feat, const float* ray_diff,
+                  const float* mask, const float* d_raw, int64_t n_rays, int n_samples, int n_views,
+                  int anti_alias_pooling, float* d_rgb_feat, float* workspace, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a6  raw2outputs                          ref: ibrnet/render_ray.py:123-170
+ * raw [R,S,4], z_vals [R,S], pixel_mask [R,S] bytes (0/1) -> rgb [R,3], depth [R], weights [R,S], alpha [R,S],
+ * ray_mask [R] bytes (sum_s pixel_mask > 8).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int nf_composite_fwd(const float* raw, const float* z_vals, const uint8_t* pixel_mask, int64_t n_rays, int n_samples,
+                     int white_bkgd, float* rgb, float* depth, float* weights, float* alpha, uint8_t* ray_mask,
+                     nf_stream_t stream);
+/* upstream gradients (each nullable): d_rgb [R,3], d_depth [R], d_weights [R,S], d_alpha [R,S] -> d_raw [R,S,4] */
+int nf_composite_bwd(const float* raw, const float* z_vals, int64_t n_rays, int n_samples, int white_bkgd,
+                     const float* d_rgb, const float* d_depth, const float* d_weights, const float* d_alpha,
+                     float* d_raw, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a7  sample_pdf + fine-sample assembly    ref: ibrnet/render_ray.py:24-70, :216-237
+ * z_vals [R,S] (ascending), weights [R,S] (detached), u_rand nullable [R,N_imp] (det=False)
+ * -> z_out [R,S+N_imp] ascending (the sorted union).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int nf_sample_fine(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance,
+                   int inv_uniform, const float* u_rand, float* z_out, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a8  Criterion / img2mse (masked)         ref: ibrnet/criterion.py:23-33, utils.py:48-58
+ * out [3] = (loss, sum_r mask_r * |rgb_r - gt_r|^2, sum_r mask_r).  mask nullable (plain mean).
+ * cnt_override (nullable, device [1]): global mask count of a ray-sharded batch; then
+ * loss = local_sum / (cnt_override*3 + 1e-6).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int nf_masked_mse_fwd(const float* rgb, const float* gt, const uint8_t* mask, int64_t n_rays,
+                      const float* cnt_override, float* out, nf_stream_t stream);
+/* d_rgb[r,c] = d_loss * 2 (rgb-gt) mask_r / (cnt*3 + 1e-6); cnt = device [1] (out+2 of the forward or the override) */
+int nf_masked_mse_bwd(const float* rgb, const float* gt, const uint8_t* mask, int64_t n_rays, const float* cnt,
+                      const float* d_loss, float* d_rgb, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a11/a13  perturbation update             ref: eval/ibrnet/eval_adv.py:28-29, :248-254, :805-839
+ * All tensors flat [n] (delta, grad, exp_avg, exp_avg_sq, src all shaped [1,V,H,W,3]).
+ *   nf_project_perturb : delta = max(min(delta, eps), -eps) (skipped if eps < 0); delta = max(min(delta, hi-src), lo-src)
+ *   nf_pgd_adam_step   : g = -grad; torch.optim.Adam single-tensor update with neg_step_size = -(lr/bias_corr1),
+ *                        bc2_sqrt = sqrt(bias_corr2) (HOST doubles rounded to float, as torch does); then both clamps
+ *   nf_pgd_sign_step   : delta += alpha * sign(grad); then both clamps
+ * ---------------------------------------------------------------------------------------------------------------- */
+int nf_project_perturb(float* delta, const float* src, int64_t n, float epsilon, float lower, float upper,
+                       nf_stream_t stream);
+int nf_pgd_adam_step(float* delta, const float* grad, float* exp_avg, float* exp_avg_sq, const float* src, int64_t n,
+                     float neg_step_size, float beta1, float beta2, float bc2_sqrt, float adam_eps, float epsilon,
+                     float lower, float upper, nf_stream_t stream);
+int nf_pgd_sign_step(float* delta, const float* grad, const float* src, int64_t n, float alpha, float epsilon,
+                     float lower, float upper, nf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFOOL_HIP_H */

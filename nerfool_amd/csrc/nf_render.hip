@@ -1,0 +1,318 @@
+// Per-ray kernels of the renderer: alpha compositing fwd/bwd (a6), hierarchical re-sampling (a7), masked MSE (a8).
+// ref: ibrnet/render_ray.py:24-70,123-170,216-237; utils.py:48-58; ibrnet/criterion.py:23-33.
+//
+// One wave64 per ray: lane l owns the contiguous samples [l*K, (l+1)*K), K = ceil(S/64); transmittance is a wave-level
+// exclusive product scan of the per-lane products, sums are wave butterflies.  No LDS, no atomics, deterministic.
+#include "nf_common.h"
+
+#define NF_RAYS_PER_BLOCK 4
+
+__device__ __forceinline__ float nf_wave_excl_prod(float v, int lane) {
+    // inclusive scan by doubling, then shift by one lane
+#pragma unroll
+    for (int d = 1; d < NF_WAVE; d <<= 1) {
+        float o = __shfl_up(v, d, NF_WAVE);
+        if (lane >= d) v = v * o;
+    }
+    float e = __shfl_up(v, 1, NF_WAVE);
+    return lane == 0 ? 1.f : e;
+}
+
+__device__ __forceinline__ float nf_wave_excl_suffix_sum(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < NF_WAVE; d <<= 1) {
+        float o = __shfl_down(v, d, NF_WAVE);
+        if (lane + d < NF_WAVE) v = v + o;
+    }
+    float e = __shfl_down(v, 1, NF_WAVE);
+    return lane == NF_WAVE - 1 ? 0.f : e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a6 forward.  alpha = 1-exp(-sigma); T = exclusive cumprod(1-alpha+1e-10); w = alpha*T   (render_ray.py:139-153)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_composite_fwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                       const uint8_t* __restrict__ pixel_mask, int64_t n_rays, int S,
+                                                       int white_bkgd, float* __restrict__ rgb, float* __restrict__ depth,
+                                                       float* __restrict__ weights, float* __restrict__ alpha_out,
+                                                       uint8_t* __restrict__ ray_mask) {
+    int lane = threadIdx.x & (NF_WAVE - 1);
+    int64_t r = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    bool live = r < n_rays;
+    int64_t rr = live ? r : 0;
+    int K = (S + NF_WAVE - 1) / NF_WAVE;
+    int s0 = lane * K, s1 = min(s0 + K, S);
+    const float* rw = raw + rr * S * 4;
+    float prod = 1.f;
+    for (int s = s0; s < s1; ++s) {
+        float a = 1.f - expf(-rw[s * 4 + 3]);
+        prod = prod * (1.f - a + 1e-10f);
+    }
+    float T = nf_wave_excl_prod(prod, lane);
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sw = 0.f, cnt = 0.f;
+    for (int s = s0; s < s1; ++s) {
+        float a = 1.f - expf(-rw[s * 4 + 3]);
+        float w = a * T;
+        T = T * (1.f - a + 1e-10f);
+        sr += w * rw[s * 4 + 0];
+        sg += w * rw[s * 4 + 1];
+        sb += w * rw[s * 4 + 2];
+        sd += w * z_vals[rr * S + s];
+        sw += w;
+        cnt += pixel_mask[rr * S + s] ? 1.f : 0.f;
+        if (live) {
+            weights[r * S + s] = w;
+            alpha_out[r * S + s] = a;
+        }
+    }
+    sr = nf_wave_sum(sr); sg = nf_wave_sum(sg); sb = nf_wave_sum(sb);
+    sd = nf_wave_sum(sd); sw = nf_wave_sum(sw); cnt = nf_wave_sum(cnt);
+    if (live && lane == 0) {
+        float bg = white_bkgd ? (1.f - sw) : 0.f;
+        rgb[r * 3 + 0] = sr + bg;
+        rgb[r * 3 + 1] = sg + bg;
+        rgb[r * 3 + 2] = sb + bg;
+        depth[r] = sd;
+        ray_mask[r] = cnt > 8.f ? 1 : 0;
+    }
+}
+
+extern "C" int nf_composite_fwd(const float* raw, const float* z_vals, const uint8_t* pixel_mask, int64_t n_rays,
+                                int n_samples, int white_bkgd, float* rgb, float* depth, float* weights, float* alpha,
+                                uint8_t* ray_mask, nf_stream_t stream) {
+    NF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 4096, "nf_composite_fwd: bad sizes (R %lld, S %d)",
+               (long long)n_rays, n_samples);
+    if (n_rays == 0) return 0;
+    hipLaunchKernelGGL(k_composite_fwd, dim3(nf_blocks(n_rays, NF_RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, raw,
+                       z_vals, pixel_mask, n_rays, n_samples, white_bkgd, rgb, depth, weights, alpha, ray_mask);
+    NF_LAUNCH_CHECK("nf_composite_fwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a6 backward.  With G_s = dL/dw_s = d_rgb.c_s + d_depth z_s + d_weights_s - [white] sum_c d_rgb_c :
+//   dL/dalpha_s = G_s T_s - (sum_{k>s} G_k w_k) / t_s + d_alpha_s,   dL/dsigma_s = dL/dalpha_s (1 - alpha_s),
+//   dL/dc_s = w_s d_rgb.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_composite_bwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                       int64_t n_rays, int S, int white_bkgd,
+                                                       const float* __restrict__ d_rgb, const float* __restrict__ d_depth,
+                                                       const float* __restrict__ d_weights,
+                                                       const float* __restrict__ d_alpha, float* __restrict__ d_raw) {
+    int lane = threadIdx.x & (NF_WAVE - 1);
+    int64_t r = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    bool live = r < n_rays;
+    int64_t rr = live ? r : 0;
+    int K = (S + NF_WAVE - 1) / NF_WAVE;
+    int s0 = lane * K, s1 = min(s0 + K, S);
+    const float* rw = raw + rr * S * 4;
+    float gr = d_rgb ? d_rgb[rr * 3 + 0] : 0.f, gg = d_rgb ? d_rgb[rr * 3 + 1] : 0.f, gb = d_rgb ? d_rgb[rr * 3 + 2] : 0.f;
+    float gd = d_depth ? d_depth[rr] : 0.f;
+    float gbg = white_bkgd ? (gr + gg + gb) : 0.f;
+    float prod = 1.f;
+    for (int s = s0; s < s1; ++s) {
+        float a = 1.f - expf(-rw[s * 4 + 3]);
+        prod = prod * (1.f - a + 1e-10f);
+    }
+    float T0 = nf_wave_excl_prod(prod, lane);
+    // per-lane sum of G_k w_k, then exclusive suffix over lanes
+    float T = T0, loc = 0.f;
+    for (int s = s0; s < s1; ++s) {
+        float a = 1.f - expf(-rw[s * 4 + 3]);
+        float w = a * T;
+        T = T * (1.f - a + 1e-10f);
+        float G = gr * rw[s * 4 + 0] + gg * rw[s * 4 + 1] + gb * rw[s * 4 + 2] + gd * z_vals[rr * S + s] - gbg +
+                  (d_weights ? d_weights[rr * S + s] : 0.f);
+        loc += G * w;
+    }
+    float suffix = nf_wave_excl_suffix_sum(loc, lane);   // sum over samples of later lanes
+    // walk this lane's samples backwards; the transmittance in front of sample s is rebuilt from T0 by forward
+    // products (K is tiny) instead of dividing, so that t = 1e-10 factors cannot poison it
+    for (int s = s1 - 1; s >= s0; --s) {
+        float Ts = T0;
+        for (int j = s0; j < s; ++j) Ts = Ts * (1.f - (1.f - expf(-rw[j * 4 + 3])) + 1e-10f);
+        float a = 1.f - expf(-rw[s * 4 + 3]);
+        float t = 1.f - a + 1e-10f;
+        float w = a * Ts;
+        float G = gr * rw[s * 4 + 0] + gg * rw[s * 4 + 1] + gb * rw[s * 4 + 2] + gd * z_vals[rr * S + s] - gbg +
+                  (d_weights ? d_weights[rr * S + s] : 0.f);
+        float da = G * Ts - suffix / t + (d_alpha ? d_alpha[rr * S + s] : 0.f);
+        suffix += G * w;
+        if (live) {
+            float* o = d_raw + (r * S + s) * 4;
+            o[0] = w * gr;
+            o[1] = w * gg;
+            o[2] = w * gb;
+            o[3] = da * (1.f - a);
+        }
+    }
+}
+
+extern "C" int nf_composite_bwd(const float* raw, const float* z_vals, int64_t n_rays, int n_samples, int white_bkgd,
+                                const float* d_rgb, const float* d_depth, const float* d_weights, const float* d_alpha,
+                                float* d_raw, nf_stream_t stream) {
+    NF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 4096, "nf_composite_bwd: bad sizes");
+    if (n_rays == 0) return 0;
+    hipLaunchKernelGGL(k_composite_bwd, dim3(nf_blocks(n_rays, NF_RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, raw,
+                       z_vals, n_rays, n_samples, white_bkgd, d_rgb, d_depth, d_weights, d_alpha, d_raw);
+    NF_LAUNCH_CHECK("nf_composite_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a7.  One wave per ray, staging in LDS: q = weights[1:S-1] + 1e-5 (flipped under inv_uniform), cdf over the M = S-2
+// bins, edges b = mid-points (of 1/z, flipped, under inv_uniform), inverse-CDF sampling at u_k = k/(N-1) (or u_rand),
+// then the sorted union of the S old and N new depths by ranking (no sequential merge, robust to ties).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sample_fine(const float* __restrict__ z_vals, const float* __restrict__ weights,
+                                                     int64_t n_rays, int S, int N, int inv_uniform,
+                                                     const float* __restrict__ u_rand, float* __restrict__ z_out) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    int lane = threadIdx.x & (NF_WAVE - 1);
+    int wave = threadIdx.x >> 6;
+    int64_t r = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wave;
+    bool live = r < n_rays;
+    int64_t rr = live ? r : 0;
+    int M = S - 2;
+    float* cdf = smem + (size_t)wave * (2 * S + N);   // [M+1]
+    float* bins = cdf + S;                            // [M+1]
+    float* znew = bins + S;                           // [N]
+    const float* z = z_vals + rr * S;
+    const float* wgt = weights + rr * S;
+
+    // total of q, then cdf by a per-lane sequential scan of contiguous chunks + wave scan of chunk sums
+    int K = (M + NF_WAVE - 1) / NF_WAVE;
+    int i0 = min(lane * K, M), i1 = min(i0 + K, M);
+    float loc = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        int src = inv_uniform ? (M - 1 - i) : i;          // flip(weights[1:-1])
+        loc += wgt[1 + src] + 1e-5f;
+    }
+    float total = nf_wave_sum(loc);
+    float incl = loc;
+#pragma unroll
+    for (int d = 1; d < NF_WAVE; d <<= 1) {
+        float o = __shfl_up(incl, d, NF_WAVE);
+        if (lane >= d) incl += o;
+    }
+    float run = incl - loc;                               // sum of q over earlier lanes
+    if (lane == 0) cdf[0] = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        int src = inv_uniform ? (M - 1 - i) : i;
+        run += wgt[1 + src] + 1e-5f;
+        cdf[i + 1] = run / total;
+    }
+    for (int i = lane; i <= M; i += NF_WAVE) {
+        if (inv_uniform) {
+            int j = M - i;                                // flip of the S-1 mid-points of 1/z
+            bins[i] = 0.5f * (1.f / z[j + 1] + 1.f / z[j]);
+        } else {
+            bins[i] = 0.5f * (z[i + 1] + z[i]);
+        }
+    }
+    __syncthreads();
+    for (int k = lane; k < N; k += NF_WAVE) {
+        float u = u_rand ? u_rand[rr * N + k] : (N > 1 ? (float)k / (float)(N - 1) : 0.f);
+        if (!u_rand && k == N - 1 && N > 1) u = 1.f;      // torch.linspace end point is exact
+        int above = 0;
+        for (int i = 0; i < M; ++i) above += (u >= cdf[i]) ? 1 : 0;
+        int below = max(above - 1, 0);
+        float c0 = cdf[below], c1 = cdf[above];
+        float b0 = bins[below], b1 = bins[above];
+        float den = c1 - c0;
+        den = den < 1e-5f ? 1.f : den;
+        float t = (u - c0) / den;
+        float smp = b0 + t * (b1 - b0);
+        znew[k] = inv_uniform ? 1.f / smp : smp;
+    }
+    __syncthreads();
+    // sorted union by ranking: position = (#elements strictly smaller) + (#equal elements that come first)
+    float* out = z_out + rr * (S + N);
+    for (int i = lane; i < S + N; i += NF_WAVE) {
+        float val = i < S ? z[i] : znew[i - S];
+        int pos = 0;
+        for (int j = 0; j < S; ++j) {
+            float o = z[j];
+            pos += (o < val || (o == val && j < i)) ? 1 : 0;
+        }
+        for (int j = 0; j < N; ++j) {
+            float o = znew[j];
+            pos += (o < val || (o == val && (j + S) < i)) ? 1 : 0;
+        }
+        if (live) out[pos] = val;
+    }
+}
+
+extern "C" int nf_sample_fine(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance,
+                              int inv_uniform, const float* u_rand, float* z_out, nf_stream_t stream) {
+    NF_REQUIRE(n_rays >= 0 && n_samples >= 3 && n_importance >= 1, "nf_sample_fine: need S >= 3 and N_importance >= 1");
+    size_t smem = (size_t)NF_RAYS_PER_BLOCK * (2 * n_samples + n_importance) * sizeof(float);
+    NF_REQUIRE(smem <= 64 * 1024, "nf_sample_fine: S=%d, N_importance=%d exceed the LDS staging budget", n_samples,
+               n_importance);
+    if (n_rays == 0) return 0;
+    hipLaunchKernelGGL(k_sample_fine, dim3(nf_blocks(n_rays, NF_RAYS_PER_BLOCK)), dim3(256), smem, (hipStream_t)stream,
+                       z_vals, weights, n_rays, n_samples, n_importance, inv_uniform, u_rand, z_out);
+    NF_LAUNCH_CHECK("nf_sample_fine");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// a8.  Single block, fixed reduction order (deterministic).  out = (loss, sum mask*|d|^2, sum mask)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_masked_mse_fwd(const float* __restrict__ rgb, const float* __restrict__ gt,
+                                                         const uint8_t* __restrict__ mask, int64_t n_rays,
+                                                         const float* __restrict__ cnt_override, float* __restrict__ out) {
+    __shared__ float s_num[16], s_cnt[16];
+    float num = 0.f, cnt = 0.f;
+    for (int64_t r = threadIdx.x; r < n_rays; r += blockDim.x) {
+        float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
+        float d0 = rgb[r * 3 + 0] - gt[r * 3 + 0], d1 = rgb[r * 3 + 1] - gt[r * 3 + 1], d2 = rgb[r * 3 + 2] - gt[r * 3 + 2];
+        num += (d0 * d0 + d1 * d1 + d2 * d2) * m;
+        cnt += m;
+    }
+    num = nf_wave_sum(num);
+    cnt = nf_wave_sum(cnt);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { s_num[wave] = num; s_cnt[wave] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tn = 0.f, tc = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tn += s_num[w]; tc += s_cnt[w]; }
+        float denom_cnt = cnt_override ? cnt_override[0] : tc;
+        // masked: sum / (sum(mask)*3 + 1e-6) (utils.py:58); unmasked: plain mean over 3R elements (utils.py:56)
+        out[0] = mask ? tn / (denom_cnt * 3.f + 1e-6f) : tn / (denom_cnt * 3.f);
+        out[1] = tn;
+        out[2] = tc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_masked_mse_bwd(const float* __restrict__ rgb, const float* __restrict__ gt,
+                                                        const uint8_t* __restrict__ mask, int64_t n_rays,
+                                                        const float* __restrict__ cnt, const float* __restrict__ d_loss,
+                                                        float* __restrict__ d_rgb) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * 3) return;
+    int64_t r = i / 3;
+    float m = mask ? (mask[r] ? 1.f : 0.f) : 1.f;
+    float denom = mask ? (cnt[0] * 3.f + 1e-6f) : (cnt[0] * 3.f);
+    d_rgb[i] = d_loss[0] * 2.f * (rgb[i] - gt[i]) * m / denom;
+}
+
+extern "C" int nf_masked_mse_fwd(const float* rgb, const float* gt, const uint8_t* mask, int64_t n_rays,
+                                 const float* cnt_override, float* out, nf_stream_t stream) {
+    NF_REQUIRE(n_rays >= 0, "nf_masked_mse_fwd: bad sizes");
+    hipLaunchKernelGGL(k_masked_mse_fwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, rgb, gt, mask, n_rays, cnt_override,
+                       out);
+    NF_LAUNCH_CHECK("nf_masked_mse_fwd");
+    return 0;
+}
+
+extern "C" int nf_masked_mse_bwd(const float* rgb, const float* gt, const uint8_t* mask, int64_t n_rays, const float* cnt,
+                                 const float* d_loss, float* d_rgb, nf_stream_t stream) {
+    NF_REQUIRE(n_rays >= 0, "nf_masked_mse_bwd: bad sizes");
+    if (n_rays == 0) return 0;
+    hipLaunchKernelGGL(k_masked_mse_bwd, dim3(nf_blocks(n_rays * 3, 256)), dim3(256), 0, (hipStream_t)stream, rgb, gt, mask,
+                       n_rays, cnt, d_loss, d_rgb);
+    NF_LAUNCH_CHECK("nf_masked_mse_bwd");
+    return 0;
+}

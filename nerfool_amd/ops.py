@@ -1,0 +1,256 @@
+"""Tensor-level wrappers of the C ABI: validate, borrow torch storage (raw data_ptr), allocate outputs through torch,
+launch on torch's current stream.  No arithmetic happens here; torch is used for memory and streams only."""
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    return 0
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32 (got %s)' % (name, t.dtype))
+    if not t.is_cuda and not _lib.emulated():
+        raise RuntimeError('%s is on %s: the nerfool_amd kernels run on the GPU only (no CPU fallback)' % (name, t.device))
+    return t
+
+
+def _c(t, name):
+    return _f32(t, name).contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def sample_along_ray(ray_o, ray_d, depth_range, n_samples, inv_uniform, t_rand=None):
+    ray_o, ray_d = _c(ray_o, 'ray_o'), _c(ray_d, 'ray_d')
+    dr = _c(depth_range.reshape(-1), 'depth_range')
+    R = ray_o.shape[0]
+    pts = torch.empty(R, n_samples, 3, dtype=torch.float32, device=ray_o.device)
+    z = torch.empty(R, n_samples, dtype=torch.float32, device=ray_o.device)
+    if t_rand is not None:
+        t_rand = _c(t_rand, 't_rand')
+    _lib.check(_lib.lib().nf_sample_along_ray(_ptr(ray_o), _ptr(ray_d), _ptr(dr), R, n_samples, int(bool(inv_uniform)),
+                                              _ptr(t_rand), _ptr(pts), _ptr(z), _stream(ray_o)), 'nf_sample_along_ray')
+    return pts, z
+
+
+def points_from_depths(ray_o, ray_d, z_vals):
+    ray_o, ray_d, z_vals = _c(ray_o, 'ray_o'), _c(ray_d, 'ray_d'), _c(z_vals, 'z_vals')
+    R, S = z_vals.shape
+    pts = torch.empty(R, S, 3, dtype=torch.float32, device=z_vals.device)
+    _lib.check(_lib.lib().nf_points_from_depths(_ptr(ray_o), _ptr(ray_d), _ptr(z_vals), R, S, _ptr(pts), _stream(pts)),
+               'nf_points_from_depths')
+    return pts
+
+
+def camera_setup(query_camera, src_cameras):
+    q = _c(query_camera.reshape(-1), 'query_camera')
+    s = _c(src_cameras.reshape(-1, 34), 'src_cameras')
+    V = s.shape[0]
+    ws = torch.empty((V + 1) * 16, dtype=torch.float32, device=s.device)
+    _lib.check(_lib.lib().nf_camera_setup(_ptr(q), _ptr(s), V, _ptr(ws), _stream(s)), 'nf_camera_setup')
+    return ws
+
+
+def project_gather_fwd(xyz, cam_ws, src_rgbs, featmaps, want_pix=False):
+    """xyz [N,3]; src_rgbs [V,H,W,3]; featmaps [V,C,Hf,Wf] (any strides)."""
+    xyz = _c(xyz, 'xyz')
+    src_rgbs = _c(src_rgbs, 'src_rgbs')
+    _f32(featmaps, 'featmaps')
+    N = xyz.shape[0]
+    V, H, W, _ = src_rgbs.shape
+    _, C, Hf, Wf = featmaps.shape
+    dev = xyz.device
+    rgb_feat = torch.empty(N, V, 3 + C, dtype=torch.float32, device=dev)
+    ray_diff = torch.empty(N, V, 4, dtype=torch.float32, device=dev)
+    mask = torch.empty(N, V, dtype=torch.float32, device=dev)
+    pix = torch.empty(V, N, 2, dtype=torch.float32, device=dev) if want_pix else None
+    sv, sc, sh, sw = featmaps.stride()
+    _lib.check(_lib.lib().nf_project_gather_fwd(_ptr(xyz), N, _ptr(cam_ws), V, _ptr(src_rgbs), H, W, _ptr(featmaps), C, Hf,
+                                                Wf, sv, sc, sh, sw, _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pix),
+                                                _stream(xyz)), 'nf_project_gather_fwd')
+    return rgb_feat, ray_diff, mask, pix
+
+
+def project_gather_bwd(xyz, cam_ws, V, H, W, d_rgb_feat, feat_shape):
+    """Returns d_featmaps [V,C,Hf,Wf] stored channels-last (one 128-byte record per pixel for C=32)."""
+    xyz = _c(xyz, 'xyz')
+    d_rgb_feat = _c(d_rgb_feat, 'd_rgb_feat')
+    _, C, Hf, Wf = feat_shape
+    N = xyz.shape[0]
+    d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
+    sv, sc, sh, sw = d_feat.stride()
+    _lib.check(_lib.lib().nf_project_gather_bwd(_ptr(xyz), N, _ptr(cam_ws), V, H, W, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc, sh,
+                                                sw, _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd')
+    return d_feat
+
+
+def pixel_mask(mask):
+    """mask [..., V] float -> bool [...] : (sum_v mask) > 1."""
+    m = _c(mask, 'mask')
+    V = m.shape[-1]
+    n = m.numel() // V
+    out = torch.empty(m.shape[:-1], dtype=torch.bool, device=m.device)
+    _lib.check(_lib.lib().nf_pixel_mask(_ptr(m), n, V, _ptr(out), _stream(m)), 'nf_pixel_mask')
+    return out
+
+
+def ibrnet_blob_layout():
+    """[(state-dict key, offset, rows, cols, transposed)] from the library's own table."""
+    import ctypes
+    L = _lib.lib()
+    out, idx = [], 0
+    name = ctypes.create_string_buffer(96)
+    off, rows, cols, tr = ctypes.c_int64(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    while L.nf_ibrnet_blob_entry(idx, name, 96, ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols),
+                                 ctypes.byref(tr)) == 0:
+        out.append((name.value.decode(), off.value, rows.value, cols.value, bool(tr.value)))
+        idx += 1
+    return out
+
+
+def pack_ibrnet_blob(state, device):
+    """state: mapping key -> tensor (reference IBRNet state-dict layout) -> flat float32 blob on `device`."""
+    blob = torch.zeros(_lib.lib().nf_ibrnet_blob_floats(), dtype=torch.float32)
+    for key, off, rows, cols, transposed in ibrnet_blob_layout():
+        if key == 's' and key not in state:
+            continue                                    # anti_alias_pooling = 0 nets have no `s`
+        t = state[key].detach().to('cpu', torch.float32).reshape(rows, cols)
+        if transposed:
+            t = t.t()
+        blob[off:off + rows * cols] = t.contiguous().reshape(-1)
+    return blob.to(device)
+
+
+def ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias):
+    rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
+    R, S, V, F = rgb_feat.shape
+    if F != 35:
+        raise ValueError('IBRNet expects 3+32 channels per view (got %d)' % F)
+    pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
+    if pe.shape[0] != S:
+        raise ValueError('pos_encoding is built for %d samples, input has %d' % (pe.shape[0], S))
+    L = _lib.lib()
+    ws = torch.empty(L.nf_ibrnet_workspace_floats(R, S, V, 0), dtype=torch.float32, device=rgb_feat.device)
+    raw = torch.empty(R, S, 4, dtype=torch.float32, device=rgb_feat.device)
+    _lib.check(L.nf_ibrnet_fwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S, V, int(bool(anti_alias)),
+                               _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd')
+    return raw
+
+
+def ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, anti_alias):
+    rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
+    d_raw = _c(d_raw, 'd_raw')
+    R, S, V, _ = rgb_feat.shape
+    pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
+    L = _lib.lib()
+    ws = torch.empty(L.nf_ibrnet_workspace_floats(R, S, V, 1), dtype=torch.float32, device=rgb_feat.device)
+    d_rgb_feat = torch.empty_like(rgb_feat)
+    _lib.check(L.nf_ibrnet_bwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(d_raw), R, S, V,
+                               int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(ws), _stream(d_raw)), 'nf_ibrnet_bwd')
+    return d_rgb_feat
+
+
+def composite_fwd(raw, z_vals, pixel_mask_b, white_bkgd):
+    raw, z_vals = _c(raw, 'raw'), _c(z_vals, 'z_vals')
+    pm = pixel_mask_b.contiguous()
+    if pm.dtype != torch.bool:
+        pm = pm != 0
+    R, S, _ = raw.shape
+    dev = raw.device
+    rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(R, dtype=torch.float32, device=dev)
+    weights = torch.empty(R, S, dtype=torch.float32, device=dev)
+    alpha = torch.empty(R, S, dtype=torch.float32, device=dev)
+    ray_mask = torch.empty(R, dtype=torch.bool, device=dev)
+    _lib.check(_lib.lib().nf_composite_fwd(_ptr(raw), _ptr(z_vals), _ptr(pm), R, S, int(bool(white_bkgd)), _ptr(rgb),
+                                           _ptr(depth), _ptr(weights), _ptr(alpha), _ptr(ray_mask), _stream(raw)),
+               'nf_composite_fwd')
+    return rgb, depth, weights, alpha, ray_mask
+
+
+def composite_bwd(raw, z_vals, white_bkgd, d_rgb=None, d_depth=None, d_weights=None, d_alpha=None):
+    raw, z_vals = _c(raw, 'raw'), _c(z_vals, 'z_vals')
+    R, S, _ = raw.shape
+    grads = [None if g is None else _c(g, 'upstream gradient') for g in (d_rgb, d_depth, d_weights, d_alpha)]
+    d_raw = torch.empty_like(raw)
+    _lib.check(_lib.lib().nf_composite_bwd(_ptr(raw), _ptr(z_vals), R, S, int(bool(white_bkgd)), _ptr(grads[0]), _ptr(grads[1]),
+                                           _ptr(grads[2]), _ptr(grads[3]), _ptr(d_raw), _stream(raw)), 'nf_composite_bwd')
+    return d_raw
+
+
+def sample_fine(z_vals, weights, n_importance, inv_uniform, u_rand=None):
+    z_vals, weights = _c(z_vals, 'z_vals'), _c(weights, 'weights')
+    R, S = z_vals.shape
+    out = torch.empty(R, S + n_importance, dtype=torch.float32, device=z_vals.device)
+    if u_rand is not None:
+        u_rand = _c(u_rand, 'u_rand')
+    _lib.check(_lib.lib().nf_sample_fine(_ptr(z_vals), _ptr(weights), R, S, n_importance, int(bool(inv_uniform)), _ptr(u_rand),
+                                         _ptr(out), _stream(out)), 'nf_sample_fine')
+    return out
+
+
+def masked_mse_fwd(rgb, gt, mask_b=None, cnt_override=None):
+    rgb, gt = _c(rgb, 'rgb'), _c(gt, 'gt')
+    R = rgb.shape[0]
+    pm = None
+    if mask_b is not None:
+        pm = mask_b.contiguous()
+        if pm.dtype != torch.bool:
+            pm = pm != 0
+    out = torch.empty(3, dtype=torch.float32, device=rgb.device)
+    _lib.check(_lib.lib().nf_masked_mse_fwd(_ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt_override), _ptr(out), _stream(rgb)),
+               'nf_masked_mse_fwd')
+    return out, pm
+
+
+def masked_mse_bwd(rgb, gt, pm, cnt, d_loss):
+    R = rgb.shape[0]
+    d_rgb = torch.empty_like(rgb)
+    d_loss = _c(d_loss.reshape(1), 'd_loss')
+    _lib.check(_lib.lib().nf_masked_mse_bwd(_ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt), _ptr(d_loss), _ptr(d_rgb),
+                                            _stream(rgb)), 'nf_masked_mse_bwd')
+    return d_rgb
+
+
+def _flat_inplace(t, name):
+    _f32(t, name)
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous (updated in place)' % name)
+    return t
+
+
+def project_perturb_(delta, src, epsilon, lower=0.0, upper=1.0):
+    _flat_inplace(delta, 'delta')
+    src = _c(src, 'src')
+    _lib.check(_lib.lib().nf_project_perturb(_ptr(delta), _ptr(src), delta.numel(), float(epsilon), float(lower), float(upper),
+                                             _stream(delta)), 'nf_project_perturb')
+    return delta
+
+
+def pgd_adam_step_(delta, grad, exp_avg, exp_avg_sq, src, lr, step, epsilon, beta1=0.9, beta2=0.999, adam_eps=1e-8,
+                   lower=0.0, upper=1.0):
+    """`step` is 1-based.  Bias corrections are HOST doubles rounded to float exactly as torch.optim.Adam does."""
+    for t, n in ((delta, 'delta'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+        _flat_inplace(t, n)
+    grad, src = _c(grad, 'grad'), _c(src, 'src')
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    _lib.check(_lib.lib().nf_pgd_adam_step(_ptr(delta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(src), delta.numel(),
+                                           -(lr / bc1), beta1, beta2, bc2 ** 0.5, adam_eps, float(epsilon), float(lower),
+                                           float(upper), _stream(delta)), 'nf_pgd_adam_step')
+    return delta
+
+
+def pgd_sign_step_(delta, grad, src, alpha, epsilon, lower=0.0, upper=1.0):
+    _flat_inplace(delta, 'delta')
+    grad, src = _c(grad, 'grad'), _c(src, 'src')
+    _lib.check(_lib.lib().nf_pgd_sign_step(_ptr(delta), _ptr(grad), _ptr(src), delta.numel(), float(alpha), float(epsilon),
+                                           float(lower), float(upper), _stream(delta)), 'nf_pgd_sign_step')
+    return delta

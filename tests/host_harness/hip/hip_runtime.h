@@ -1,0 +1,162 @@
+// TEST INFRASTRUCTURE ONLY -- a minimal CPU stand-in for <hip/hip_runtime.h>.
+//
+// tests/host_harness/build.sh compiles the UNMODIFIED kernel sources of nerfool_amd/csrc/*.hip with g++ against this
+// header into tests/host_harness/libnerfool_emu.so, so that the kernels' index arithmetic, wave-level scans, LDS
+// staging and (emulated) MFMA fragment layouts can be parity-checked against the oracle on a machine without a GPU,
+// through the same C ABI.  It is never loaded by the product (nerfool_amd/_lib.py refuses to run without the real
+// gfx950 library) and implements only what those sources use.
+//
+// Execution model: blocks run one after another; the threads of a block are real OS threads; __syncthreads() and the
+// wave-collective operations (__shfl*, MFMA) are barriers over the block / over the 64 consecutive threads of a wave.
+// Every lane of a wave must therefore reach every collective (true on the GPU for the kernels in this repo as well).
+#pragma once
+
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_DYNAMIC_SHARED(type, name) type* name = (type*)hip_emu::dynamic_smem();
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+enum { hipDeviceAttributeMultiprocessorCount = 1 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
+
+namespace hip_emu {
+struct Block {
+    pthread_barrier_t all;
+    std::vector<pthread_barrier_t> wave;
+    std::vector<std::vector<uint64_t>> slot;   // per wave, 64 exchange slots
+    std::vector<char> smem;
+};
+extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local Block* t_block;
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+inline void* dynamic_smem() { return t_block->smem.data(); }
+inline int lane() { return (int)(t_threadIdx.x & 63); }
+inline int wave() { return (int)(t_threadIdx.x >> 6); }
+inline void wave_barrier() { pthread_barrier_wait(&t_block->wave[wave()]); }
+
+// every lane publishes `v`, then reads the value of lane `src` (own value when src is out of range)
+template <typename T>
+inline T exchange(T v, int src) {
+    static_assert(sizeof(T) <= 8, "exchange");
+    uint64_t raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    auto& sl = t_block->slot[wave()];
+    sl[lane()] = raw;
+    wave_barrier();
+    uint64_t got = (src >= 0 && src < 64) ? sl[src] : raw;
+    wave_barrier();
+    T out;
+    memcpy(&out, &got, sizeof(T));
+    return out;
+}
+}  // namespace hip_emu
+
+#define threadIdx hip_emu::t_threadIdx
+#define blockIdx hip_emu::t_blockIdx
+#define blockDim hip_emu::t_blockDim
+#define gridDim hip_emu::t_gridDim
+
+static inline void __syncthreads() { pthread_barrier_wait(&hip_emu::t_block->all); }
+
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hip_emu::exchange(v, hip_emu::lane() ^ mask); }
+template <typename T>
+static inline T __shfl_up(T v, unsigned d, int width = 64) { (void)width; int s = hip_emu::lane() - (int)d; return hip_emu::exchange(v, s < 0 ? hip_emu::lane() : s); }
+template <typename T>
+static inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; int s = hip_emu::lane() + (int)d; return hip_emu::exchange(v, s > 63 ? hip_emu::lane() : s); }
+template <typename T>
+static inline T __shfl(T v, int src, int width = 64) { (void)width; return hip_emu::exchange(v, src & 63); }
+
+static inline float atomicAdd(float* addr, float val) {
+    uint32_t* p = (uint32_t*)addr;
+    uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    for (;;) {
+        float f;
+        memcpy(&f, &old, 4);
+        f += val;
+        uint32_t nw;
+        memcpy(&nw, &f, 4);
+        if (__atomic_compare_exchange_n(p, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+            memcpy(&f, &old, 4);
+            return f;
+        }
+    }
+}
+
+using std::max;
+using std::min;
+
+// ---- MFMA emulation (gfx950 semantics as documented in /opt/skills/guides/cdna_hip_programming.md section 3) ----
+typedef float nf_emu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float nf_emu_f32x4 __attribute__((ext_vector_type(4)));
+
+// D = A(32x2) * B(2x32) + C.  lane l: a = A[l&31][l>>5], b = B[l>>5][l&31];
+// c[r] of lane l = C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].  k-ordered fmaf chain.
+static inline nf_emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, nf_emu_f32x16 c, int, int, int) {
+    float A[2], B[2];
+    nf_emu_f32x16 d = c;
+    int l = hip_emu::lane(), col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        for (int k = 0; k < 2; ++k) {
+            A[k] = hip_emu::exchange(a, row + 32 * k);
+            B[k] = hip_emu::exchange(b, col + 32 * k);
+        }
+        float acc = c[r];
+        acc = fmaf(A[0], B[0], acc);
+        acc = fmaf(A[1], B[1], acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
+// D = A(16x4) * B(4x16) + C.  lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; c[r] = C[row = 4*(l>>4) + r][col = l&15]
+static inline nf_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, nf_emu_f32x4 c, int, int, int) {
+    nf_emu_f32x4 d = c;
+    int l = hip_emu::lane(), col = l & 15, q = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * q + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float A = hip_emu::exchange(a, row + 16 * k);
+            float B = hip_emu::exchange(b, col + 16 * k);
+            acc = fmaf(A, B, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
+template <typename K, typename... Args>
+static inline void hip_emu_launch(K kernel, dim3 grid, dim3 block, size_t smem, Args... args) {
+    hip_emu::launch(grid, block, smem, [=]() { kernel(args...); });
+}
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+    do { (void)(stream); hip_emu_launch(kernel, grid, block, smem, __VA_ARGS__); } while (0)
