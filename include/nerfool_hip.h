@@ -128,14 +128,15 @@ int nf_masked_mse_bwd(const float* rgb, const float* gt, const uint8_t* mask, in
  * All tensors flat [n] (delta, grad, exp_avg, exp_avg_sq, src all shaped [1,V,H,W,3]).
  *   nf_project_perturb : delta = max(min(delta, eps), -eps) (skipped if eps < 0); delta = max(min(delta, hi-src), lo-src)
  *   nf_pgd_adam_step   : g = -grad; torch.optim.Adam single-tensor update with neg_step_size = -(lr/bias_corr1),
- *                        bc2_sqrt = sqrt(bias_corr2) (HOST doubles rounded to float, as torch does); then both clamps
+ *                        bc2_sqrt = sqrt(bias_corr2), one_minus_beta{1,2} = 1 - beta (all computed in HOST double and
+ *                        rounded to float once, exactly as torch does); then both clamps
  *   nf_pgd_sign_step   : delta += alpha * sign(grad); then both clamps
  * ---------------------------------------------------------------------------------------------------------------- */
 int nf_project_perturb(float* delta, const float* src, int64_t n, float epsilon, float lower, float upper,
                        nf_stream_t stream);
 int nf_pgd_adam_step(float* delta, const float* grad, float* exp_avg, float* exp_avg_sq, const float* src, int64_t n,
-                     float neg_step_size, float beta1, float beta2, float bc2_sqrt, float adam_eps, float epsilon,
-                     float lower, float upper, nf_stream_t stream);
+                     float neg_step_size, float one_minus_beta1, float beta2, float one_minus_beta2, float bc2_sqrt,
+                     float adam_eps, float epsilon, float lower, float upper, nf_stream_t stream);
 int nf_pgd_sign_step(float* delta, const float* grad, const float* src, int64_t n, float alpha, float epsilon,
                      float lower, float upper, nf_stream_t stream);
 

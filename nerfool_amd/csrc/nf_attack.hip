@@ -20,10 +20,9 @@ __global__ void __launch_bounds__(256) k_project_perturb(float* __restrict__ del
 __global__ void __launch_bounds__(256) k_pgd_adam_step(float* __restrict__ delta, const float* __restrict__ grad,
                                                        float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                        const float* __restrict__ src, int64_t n, float neg_step_size,
-                                                       float beta1, float beta2, float bc2_sqrt, float adam_eps, float eps,
-                                                       float lo, float hi) {
+                                                       float w1, float beta2, float w2, float bc2_sqrt, float adam_eps,
+                                                       float eps, float lo, float hi) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    float w1 = 1.f - beta1, w2 = 1.f - beta2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float g = -grad[i];
         float m = exp_avg[i];
@@ -64,12 +63,14 @@ extern "C" int nf_project_perturb(float* delta, const float* src, int64_t n, flo
 }
 
 extern "C" int nf_pgd_adam_step(float* delta, const float* grad, float* exp_avg, float* exp_avg_sq, const float* src,
-                                int64_t n, float neg_step_size, float beta1, float beta2, float bc2_sqrt, float adam_eps,
-                                float epsilon, float lower, float upper, nf_stream_t stream) {
+                                int64_t n, float neg_step_size, float one_minus_beta1, float beta2, float one_minus_beta2,
+                                float bc2_sqrt, float adam_eps, float epsilon, float lower, float upper,
+                                nf_stream_t stream) {
     NF_REQUIRE(n >= 0 && bc2_sqrt > 0.f, "nf_pgd_adam_step: bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_pgd_adam_step, dim3(nf_stream_grid(n)), dim3(256), 0, (hipStream_t)stream, delta, grad, exp_avg,
-                       exp_avg_sq, src, n, neg_step_size, beta1, beta2, bc2_sqrt, adam_eps, epsilon, lower, upper);
+                       exp_avg_sq, src, n, neg_step_size, one_minus_beta1, beta2, one_minus_beta2, bc2_sqrt, adam_eps, epsilon, lower,
+                       upper);
     NF_LAUNCH_CHECK("nf_pgd_adam_step");
     return 0;
 }

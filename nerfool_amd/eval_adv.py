@@ -1,0 +1,176 @@
+"""Attack half of the reference's eval/ibrnet/eval_adv.py with the same call surface -- `clamp`, `init_adv_perturb`,
+`optimize_adv_perturb` (rgb-loss path) -- plus `PGDAttack`, the view-specific / universal loop of eval_adv.py:609-740,
+762-843 with the Adam-ascent / sign-PGD update and both projections fused into one HIP kernel, and an optional
+ray-sharded multi-GPU mode (one RCCL all-reduce of d(delta) per step).
+
+Everything outside the rgb-loss attack (pseudo ground truth, depth / density / camera losses, PCGrad, camera
+perturbation, purification) is out of scope and raises NotImplementedError when requested."""
+import torch
+
+from . import ops
+from .ibrnet.criterion import Criterion
+from .ibrnet.render_ray import render_rays
+from .ibrnet.sample_ray import RaySamplerSingleImage
+
+criterion = Criterion()
+
+_UNSUPPORTED_FLAGS = ('gt_depth_path', 'use_patch_sampling', 'use_pseudo_gt', 'density_loss', 'depth_var_loss',
+                      'depth_diff_loss', 'depth_consistency_loss', 'depth_smooth_loss', 'camera_consistency_loss',
+                      'perturb_camera', 'use_pcgrad', 'use_unseen_views')
+
+
+def _reject_out_of_scope(args):
+    for flag in _UNSUPPORTED_FLAGS:
+        if getattr(args, flag, None):
+            raise NotImplementedError('--%s belongs to an auxiliary experiment outside the rgb-loss attack path' % flag)
+
+
+def clamp(X, lower_limit, upper_limit):
+    """max(min(X, upper), lower) with tensor or scalar bounds (eval_adv.py:28-29).  Convenience only: the attack loop
+    itself uses the fused projection inside the update kernels."""
+    hi = upper_limit if torch.is_tensor(upper_limit) else torch.tensor(upper_limit, dtype=X.dtype, device=X.device)
+    lo = lower_limit if torch.is_tensor(lower_limit) else torch.tensor(lower_limit, dtype=X.dtype, device=X.device)
+    return torch.max(torch.min(X, hi), lo)
+
+
+def init_adv_perturb(args, src_ray_batch, epsilon, upper_limit, lower_limit):
+    """delta ~ U(-eps, eps) from torch's generator on the source device, projected so that src+delta stays in
+    [lower, upper] (eval_adv.py:248-254)."""
+    src = src_ray_batch['src_rgbs']
+    delta = torch.zeros_like(src)
+    delta.uniform_(-float(epsilon), float(epsilon))
+    ops.project_perturb_(delta, src, -1.0, float(lower_limit), float(upper_limit))
+    delta.requires_grad = True
+    return delta
+
+
+def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, return_loss=True, select_inds=None,
+                         shard=None):
+    """One loss evaluation of the attack (eval_adv.py:258-310,512-519): draw N_rand rays of the target view `data`,
+    features from the PERTURBED source images, colours from the CLEAN ones, masked MSE on coarse + fine.
+
+    select_inds: optional explicit pixel indices (otherwise drawn from the reference's RandomState(234) stream).
+    shard: optional `RayShard` -- this rank renders its slice of the drawn rays and the loss denominators are the
+    all-reduced mask counts."""
+    _reject_out_of_scope(args)
+    device = delta.device
+    sampler = RaySamplerSingleImage.cached(data, device)
+    if select_inds is None:
+        n_draw = args.N_rand * (shard.world if shard is not None else 1)
+        select_inds = sampler.sample_random_pixel(n_draw, getattr(args, 'sample_mode', 'uniform'),
+                                                  getattr(args, 'center_ratio', 0.8))
+        if shard is not None:
+            select_inds = select_inds[shard.rank::shard.world]
+    train_ray_batch = sampler.select(select_inds)
+    featmaps = model.feature_net((src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
+    ret = render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
+                      N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
+                      det=getattr(args, 'det', True), white_bkgd=args.white_bkgd, args=args, src_ray_batch=src_ray_batch)
+    counts = None
+    if shard is not None:
+        counts = shard.global_mask_counts(ret)
+    loss_rgb, _ = criterion(ret['outputs_coarse'], train_ray_batch, None,
+                            None if counts is None else counts[0:1])
+    if ret['outputs_fine'] is not None:
+        fine_loss, _ = criterion(ret['outputs_fine'], train_ray_batch, None, None if counts is None else counts[1:2])
+        loss_rgb = loss_rgb + fine_loss
+    total_loss = {'rgb': loss_rgb}
+    loss = loss_rgb
+    if return_loss:
+        return loss, total_loss
+    return torch.autograd.grad(loss, delta)[0].detach()
+
+
+class RayShard:
+    """Data-parallel ray sharding over the ranks of a torch.distributed group (backend 'nccl' = RCCL over xGMI on the
+    GPU box, 'gloo' in the CPU tests).  Two collectives per PGD step: a 2-float all-reduce of the mask counts (they set
+    the loss denominators, utils.py:58) and ONE all-reduce of d(delta) (valid because the CNN backward is linear in the
+    upstream gradient).  Every rank then applies the identical deterministic update, so delta stays replicated."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def global_mask_counts(self, ret):
+        c = ret['outputs_coarse']['mask'].sum(dtype=torch.float32).reshape(1)
+        f = ret['outputs_fine']['mask'].sum(dtype=torch.float32).reshape(1) if ret['outputs_fine'] is not None else c
+        counts = torch.cat([c, f])
+        self.dist.all_reduce(counts, op=self.dist.ReduceOp.SUM, group=self.group)
+        return counts
+
+    def all_reduce_grad(self, grad):
+        self.dist.all_reduce(grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        return grad
+
+
+class PGDAttack:
+    """The perturbation loop of eval_adv.py (view-specific :783-843, universal :634-740).
+
+    state: delta [1,V,H,W,3] (requires_grad), Adam moments, iteration counter.  `step(data)` = loss forward, backward to
+    delta, optional gradient all-reduce, fused update + eps-ball + [0,1]-box projection."""
+
+    def __init__(self, args, model, projector, src_ray_batch, shard=None, delta=None):
+        _reject_out_of_scope(args)
+        self.args, self.model, self.projector, self.src = args, model, projector, src_ray_batch
+        self.shard = shard
+        self.epsilon = args.epsilon / 255.0
+        self.alpha = args.adv_lr / 255.0
+        self.delta = delta if delta is not None else init_adv_perturb(args, src_ray_batch, self.epsilon, 1, 0)
+        self.use_adam = bool(getattr(args, 'use_adam', False))
+        if self.use_adam:
+            self.exp_avg = torch.zeros_like(self.delta.data)
+            self.exp_avg_sq = torch.zeros_like(self.delta.data)
+        self.iters = 0
+        self.last_loss = None
+
+    def lr(self):
+        step_size = getattr(self.args, 'lr_step_size', 100)
+        gamma = getattr(self.args, 'lr_gamma', 0.5)
+        return self.args.adam_lr * gamma ** (self.iters // step_size)     # StepLR stepped after every opt.step()
+
+    def gradient(self, data, select_inds=None):
+        self.delta.grad = None
+        loss, _ = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data,
+                                       return_loss=True, select_inds=select_inds, shard=self.shard)
+        loss.backward()
+        grad = self.delta.grad
+        if self.shard is not None:
+            self.shard.all_reduce_grad(grad)
+        self.last_loss = loss.detach()
+        return grad
+
+    def apply(self, grad):
+        src = self.src['src_rgbs']
+        if self.use_adam:
+            lr = self.lr()
+            self.iters += 1
+            ops.pgd_adam_step_(self.delta.data, grad, self.exp_avg, self.exp_avg_sq, src, lr, self.iters, self.epsilon)
+        else:
+            self.iters += 1
+            ops.pgd_sign_step_(self.delta.data, grad, src, self.alpha, self.epsilon)
+
+    def step(self, data, select_inds=None):
+        self.apply(self.gradient(data, select_inds))
+        return self.last_loss
+
+    def run_view_specific(self, data, n_iters=None):
+        """eval_adv.py:796-843: adv_iters steps on one target view."""
+        for _ in range(self.args.adv_iters if n_iters is None else n_iters):
+            self.step(data)
+        return self.delta
+
+    def run_universal(self, train_loader, n_iters=None):
+        """eval_adv.py:646-740: cycles over the training views; the reference's `iters > adv_iters` test makes it run
+        adv_iters + 1 steps."""
+        total = (self.args.adv_iters if n_iters is None else n_iters) + 1
+        done = 0
+        while done < total:
+            for data in train_loader:
+                self.step(data)
+                done += 1
+                if done >= total:
+                    break
+        return self.delta

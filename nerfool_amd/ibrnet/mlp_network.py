@@ -1,0 +1,100 @@
+"""IBRNet per-sample network as an nn.Module whose forward AND backward are the HIP kernels.
+
+The module tree reproduces the parameter names of ibrnet/mlp_network.py:152-208 so that the public IBRNet
+checkpoints (`net_coarse` / `net_fine` state-dicts) load by key; `pos_encoding` is rebuilt from n_samples because
+checkpoints may lack it (ibrnet/model.py:148-150).  The parameters are treated as constants of the attack: the
+backward produces d/d(rgb_feat) only (the reference accumulates weight gradients and never reads them)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+def _mlp(dims, final_act=True):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2 or final_act:
+            layers.append(nn.ELU())        # placeholders keep the Sequential indices of the reference (0, 2, 4)
+    return nn.Sequential(*layers)
+
+
+class _RayAttentionParams(nn.Module):
+    """Parameter holder named like MultiHeadAttention (ibrnet/mlp_network.py:69-88)."""
+
+    def __init__(self, n_head=4, d_model=16, d_k=4, d_v=4):
+        super().__init__()
+        self.w_qs = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_ks = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_vs = nn.Linear(d_model, n_head * d_v, bias=False)
+        self.fc = nn.Linear(n_head * d_v, d_model, bias=False)
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
+
+
+def sinusoid_table(n_samples, d_hid=16):
+    pos = np.arange(n_samples, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    ang = pos / np.power(10000.0, 2 * (j // 2) / d_hid)
+    return torch.from_numpy(np.where(j % 2 == 0, np.sin(ang), np.cos(ang))).float().unsqueeze(0)
+
+
+class _IBRNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_feat, ray_diff, mask, blob, pos_enc, anti_alias):
+        raw = ops.ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
+        ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc)
+        ctx.anti_alias = anti_alias
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        rgb_feat, ray_diff, mask, blob, pos_enc = ctx.saved_tensors
+        d_rgb_feat = ops.ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, ctx.anti_alias)
+        return d_rgb_feat, None, None, None, None, None
+
+
+class IBRNet(nn.Module):
+    def __init__(self, args, in_feat_ch=32, n_samples=64, **kwargs):
+        super().__init__()
+        if in_feat_ch != 32:
+            raise ValueError('the HIP IBRNet kernels are built for 32 feature channels (got %d)' % in_feat_ch)
+        self.args = args
+        self.anti_alias_pooling = args.anti_alias_pooling
+        if self.anti_alias_pooling:
+            self.s = nn.Parameter(torch.tensor(0.2), requires_grad=True)
+        self.n_samples = n_samples
+        self.ray_dir_fc = _mlp([4, 16, in_feat_ch + 3])
+        self.base_fc = _mlp([(in_feat_ch + 3) * 3, 64, 32])
+        self.vis_fc = _mlp([32, 32, 33])
+        self.vis_fc2 = nn.Sequential(nn.Linear(32, 32), nn.ELU(), nn.Linear(32, 1), nn.Sigmoid())
+        self.geometry_fc = _mlp([32 * 2 + 1, 64, 16])
+        self.ray_attention = _RayAttentionParams(4, 16, 4, 4)
+        self.out_geometry_fc = nn.Sequential(nn.Linear(16, 16), nn.ELU(), nn.Linear(16, 1), nn.ReLU())
+        self.rgb_fc = _mlp([32 + 1 + 4, 16, 8, 1], final_act=False)
+        self.register_buffer('pos_encoding', sinusoid_table(n_samples))
+        for seq in (self.base_fc, self.vis_fc2, self.vis_fc, self.geometry_fc, self.rgb_fc):
+            for m in seq:
+                if isinstance(m, nn.Linear):
+                    nn.init.kaiming_normal_(m.weight.data)
+                    nn.init.zeros_(m.bias.data)
+        self._blob = None
+        self._blob_key = None
+
+    def _packed(self, device):
+        """Flat parameter blob in the kernels' layout, re-packed only when a parameter changed."""
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._blob is None or key != self._blob_key:
+            self._blob = ops.pack_ibrnet_blob(self.state_dict(), device)
+            self._blob_key = key
+        return self._blob
+
+    def forward(self, rgb_feat, ray_diff, mask):
+        """
+        :param rgb_feat: [n_rays, n_samples, n_views, 35]
+        :param ray_diff: [n_rays, n_samples, n_views, 4]
+        :param mask: [n_rays, n_samples, n_views, 1]
+        :return: [n_rays, n_samples, 4]  (rgb, sigma)
+        """
+        blob = self._packed(rgb_feat.device)
+        return _IBRNetFunction.apply(rgb_feat, ray_diff, mask[..., 0], blob, self.pos_encoding, bool(self.anti_alias_pooling))

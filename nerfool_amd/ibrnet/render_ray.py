@@ -1,0 +1,82 @@
+"""Ray renderer: depth sampling, projection, IBRNet, compositing, hierarchical re-sampling -- the reference's
+ibrnet/render_ray.py call surface (`sample_along_camera_ray`, `raw2outputs`, `render_rays`, same argument names and
+return dicts) with every stage executed by a HIP kernel."""
+from collections import OrderedDict
+
+import torch
+
+from .. import ops
+
+
+def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=False, det=False):
+    """ref: ibrnet/render_ray.py:73-116.  -> pts [N_rays, N_samples, 3], z_vals [N_rays, N_samples]"""
+    t_rand = None
+    if not det:
+        t_rand = torch.rand(ray_d.shape[0], N_samples, dtype=torch.float32, device=ray_d.device)
+    return ops.sample_along_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform, t_rand)
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, z_vals, pixel_mask, white_bkgd):
+        rgb, depth, weights, alpha, ray_mask = ops.composite_fwd(raw, z_vals, pixel_mask, white_bkgd)
+        ctx.save_for_backward(raw, z_vals)
+        ctx.white_bkgd = white_bkgd
+        ctx.mark_non_differentiable(ray_mask)
+        return rgb, depth, weights, alpha, ray_mask
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d_weights, d_alpha, _d_mask):
+        raw, z_vals = ctx.saved_tensors
+        d_raw = ops.composite_bwd(raw, z_vals, ctx.white_bkgd, d_rgb, d_depth, d_weights, d_alpha)
+        return d_raw, None, None, None
+
+
+def raw2outputs(raw, z_vals, mask, white_bkgd=False, geo_noise=None):
+    """ref: ibrnet/render_ray.py:123-170.  raw [N_rays, N_samples, 4], z_vals [N_rays, N_samples], mask (bool per sample:
+    at least two valid observations).  geo_noise is a training-only option of the reference and is rejected here."""
+    if geo_noise is not None and geo_noise > 0:
+        raise NotImplementedError('geo_noise is a training-time option outside the attack path')
+    rgb, depth, weights, alpha, ray_mask = _Composite.apply(raw, z_vals, mask, bool(white_bkgd))
+    return OrderedDict([('rgb', rgb), ('depth', depth), ('weights', weights), ('mask', ray_mask), ('alpha', alpha),
+                        ('z_vals', z_vals)])
+
+
+def sample_fine_depths(z_vals, weights, N_importance, inv_uniform=False, det=False):
+    """ref: ibrnet/render_ray.py:216-237 (sample_pdf on the detached inner weights, union with the coarse depths,
+    sort) as one kernel.  -> [N_rays, N_samples + N_importance] ascending."""
+    u = None
+    if not det:
+        u = torch.rand(z_vals.shape[0], N_importance, dtype=torch.float32, device=z_vals.device)
+    return ops.sample_fine(z_vals.detach(), weights.detach(), N_importance, inv_uniform, u)
+
+
+def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo_noise):
+    rgb_feat, ray_diff, mask = projector.compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'],
+                                                 featmaps=featmap)
+    pixel_mask = ops.pixel_mask(mask[..., 0])            # at least 2 observations (:210)
+    raw = net(rgb_feat, ray_diff, mask)
+    return raw2outputs(raw, z_vals, pixel_mask, white_bkgd=white_bkgd, geo_noise=geo_noise)
+
+
+def render_rays(ray_batch, model, featmaps, projector, N_samples, inv_uniform=False, N_importance=0, det=False,
+                white_bkgd=False, args=None, src_ray_batch=None, geo_noise=None):
+    """
+    :param ray_batch: {'ray_o': [N_rays, 3], 'ray_d': [N_rays, 3], 'camera', 'depth_range', 'src_rgbs', 'src_cameras'}
+    :param model: object with .net_coarse / .net_fine
+    :param featmaps: (coarse [V,32,Hf,Wf], fine [V,32,Hf,Wf])
+    :return: {'outputs_coarse': OrderedDict, 'outputs_fine': OrderedDict or None}   (ibrnet/render_ray.py:173-256)
+    """
+    src = ray_batch if src_ray_batch is None else src_ray_batch
+    ret = {'outputs_coarse': None, 'outputs_fine': None}
+    pts, z_vals = sample_along_camera_ray(ray_batch['ray_o'], ray_batch['ray_d'], ray_batch['depth_range'], N_samples,
+                                          inv_uniform=inv_uniform, det=det)
+    ret['outputs_coarse'] = _level(pts, z_vals, ray_batch, src, model.net_coarse, featmaps[0], projector, white_bkgd,
+                                   geo_noise)
+    if N_importance > 0:
+        assert model.net_fine is not None
+        z_vals = sample_fine_depths(z_vals, ret['outputs_coarse']['weights'], N_importance, inv_uniform, det)
+        pts = ops.points_from_depths(ray_batch['ray_o'], ray_batch['ray_d'], z_vals)
+        ret['outputs_fine'] = _level(pts, z_vals, ray_batch, src, model.net_fine, featmaps[1], projector, white_bkgd,
+                                     geo_noise)
+    return ret

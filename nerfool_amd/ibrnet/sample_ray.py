@@ -1,0 +1,103 @@
+"""Per-image ray generator and random pixel picker with the reference's interface (ibrnet/sample_ray.py:43-187):
+`RaySamplerSingleImage(data, device)`, `.get_all()`, `.random_sample(N_rand, sample_mode, center_ratio)`, `.H/.W/.rgb`.
+
+Host-side component.  Differences from the reference, none observable in the returned tensors:
+  * tensors go to `device` (the reference hard-codes `.cuda()`),
+  * the pixel grid / ray directions are built on `device` once and can be re-used across PGD iterations through
+    `RaySamplerSingleImage.cached(data, device)`, instead of re-running meshgrid + H*W bmm on the CPU and re-uploading
+    the source images every iteration (eval/ibrnet/eval_adv.py:264),
+  * pixel picks come from the same module-global `RandomState(234)` stream (`rng`)."""
+import numpy as np
+import torch
+
+rng = np.random.RandomState(234)
+
+
+def parse_camera(params):
+    H = params[:, 0]
+    W = params[:, 1]
+    intrinsics = params[:, 2:18].reshape((-1, 4, 4))
+    c2w = params[:, 18:34].reshape((-1, 4, 4))
+    return W, H, intrinsics, c2w
+
+
+class RaySamplerSingleImage(object):
+    _cache_key = None
+    _cache_val = None
+
+    def __init__(self, data, device, resize_factor=1, render_stride=1, load_gt_depth=False):
+        if resize_factor != 1:
+            raise NotImplementedError('resize_factor != 1 is not used on the attack path')
+        if load_gt_depth:
+            raise NotImplementedError('ground-truth depth (auxiliary depth losses) is outside the attack path')
+        self.render_stride = render_stride
+        self.device = torch.device(device)
+        self.camera = data['camera']
+        self.rgb_path = data.get('rgb_path')
+        self.depth_range = data['depth_range']
+        W, H, self.intrinsics, self.c2w_mat = parse_camera(self.camera)
+        self.batch_size = len(self.camera)
+        self.H, self.W = int(H[0]), int(W[0])
+        self.src_depths = self.depth_full = self.depth = None
+        self.rays_o, self.rays_d = self.get_rays_single_image(self.H, self.W, self.intrinsics, self.c2w_mat)
+        rgb = data.get('rgb')
+        self.rgb = None if rgb is None else rgb.reshape(-1, 3).to(self.device)
+        self.src_rgbs = data['src_rgbs'].to(self.device) if 'src_rgbs' in data else None
+        self.src_cameras = data['src_cameras'].to(self.device) if 'src_cameras' in data else None
+        self._camera_dev = self.camera.to(self.device)
+        self._depth_range_dev = self.depth_range.to(self.device)
+
+    @classmethod
+    def cached(cls, data, device, **kw):
+        """Same object for the same batch dict (identity of its tensors): the attack loop calls this every iteration."""
+        key = (id(data), str(device), tuple(sorted(kw.items())),
+               tuple(v.data_ptr() for v in data.values() if torch.is_tensor(v)))
+        if cls._cache_key != key:
+            cls._cache_val = cls(data, device, **kw)
+            cls._cache_key = key
+        return cls._cache_val
+
+    def get_rays_single_image(self, H, W, intrinsics, c2w):
+        """rays_d = R * K^-1 * (u, v, 1) without half-pixel offset; rays_o = camera centre (sample_ray.py:98-116)."""
+        dev = self.device
+        us = torch.arange(0, W, self.render_stride, dtype=torch.float32, device=dev)
+        vs = torch.arange(0, H, self.render_stride, dtype=torch.float32, device=dev)
+        v, u = torch.meshgrid(vs, us, indexing='ij')
+        pixels = torch.stack((u.reshape(-1), v.reshape(-1), torch.ones(u.numel(), device=dev)), dim=0)[None]
+        # 3x3 inverse on the host in fp32 like the reference, the H*W-column product on the device
+        m = c2w[:, :3, :3].bmm(torch.inverse(intrinsics[:, :3, :3])).to(dev)
+        rays_d = m.bmm(pixels.expand(self.batch_size, -1, -1)).transpose(1, 2).reshape(-1, 3)
+        rays_o = c2w[:, :3, 3].to(dev).unsqueeze(1).expand(-1, rays_d.shape[0], -1).reshape(-1, 3)
+        return rays_o.contiguous(), rays_d.contiguous()
+
+    def _common(self):
+        return {'camera': self._camera_dev, 'depth_range': self._depth_range_dev, 'src_rgbs': self.src_rgbs,
+                'src_cameras': self.src_cameras, 'src_depths': None, 'depth_full': None}
+
+    def get_all(self):
+        ret = {'ray_o': self.rays_o, 'ray_d': self.rays_d, 'rgb': self.rgb, 'depth': None}
+        ret.update(self._common())
+        return ret
+
+    def sample_random_pixel(self, N_rand, sample_mode, center_ratio=0.8):
+        if sample_mode == 'center':
+            border_H = int(self.H * (1 - center_ratio) / 2.)
+            border_W = int(self.W * (1 - center_ratio) / 2.)
+            u, v = np.meshgrid(np.arange(border_H, self.H - border_H), np.arange(border_W, self.W - border_W))
+            u, v = u.reshape(-1), v.reshape(-1)
+            pick = rng.choice(u.shape[0], size=(N_rand,), replace=False)
+            return v[pick] + self.W * u[pick]
+        if sample_mode == 'uniform':
+            return rng.choice(self.H * self.W, size=(N_rand,), replace=False)
+        raise Exception('unknown sample mode!')
+
+    def random_sample(self, N_rand, sample_mode, center_ratio=0.8):
+        select_inds = self.sample_random_pixel(N_rand, sample_mode, center_ratio)
+        return self.select(select_inds)
+
+    def select(self, select_inds):
+        idx = torch.as_tensor(np.asarray(select_inds), dtype=torch.long, device=self.device)
+        ret = {'ray_o': self.rays_o[idx], 'ray_d': self.rays_d[idx], 'rgb': None if self.rgb is None else self.rgb[idx],
+               'selected_inds': select_inds, 'depth': None}
+        ret.update(self._common())
+        return ret

@@ -3,6 +3,7 @@ launch on torch's current stream.  No arithmetic happens here; torch is used for
 import torch
 
 from . import _lib
+from . import prof
 
 
 def _stream(t):
@@ -72,9 +73,10 @@ def project_gather_fwd(xyz, cam_ws, src_rgbs, featmaps, want_pix=False):
     mask = torch.empty(N, V, dtype=torch.float32, device=dev)
     pix = torch.empty(V, N, 2, dtype=torch.float32, device=dev) if want_pix else None
     sv, sc, sh, sw = featmaps.stride()
-    _lib.check(_lib.lib().nf_project_gather_fwd(_ptr(xyz), N, _ptr(cam_ws), V, _ptr(src_rgbs), H, W, _ptr(featmaps), C, Hf,
-                                                Wf, sv, sc, sh, sw, _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pix),
-                                                _stream(xyz)), 'nf_project_gather_fwd')
+    with prof.launch('nf_project_gather_fwd', xyz, n_pts=N, V=V, C=C):
+        _lib.check(_lib.lib().nf_project_gather_fwd(_ptr(xyz), N, _ptr(cam_ws), V, _ptr(src_rgbs), H, W, _ptr(featmaps), C,
+                                                    Hf, Wf, sv, sc, sh, sw, _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
+                                                    _ptr(pix), _stream(xyz)), 'nf_project_gather_fwd')
     return rgb_feat, ray_diff, mask, pix
 
 
@@ -86,8 +88,9 @@ def project_gather_bwd(xyz, cam_ws, V, H, W, d_rgb_feat, feat_shape):
     N = xyz.shape[0]
     d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
     sv, sc, sh, sw = d_feat.stride()
-    _lib.check(_lib.lib().nf_project_gather_bwd(_ptr(xyz), N, _ptr(cam_ws), V, H, W, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc, sh,
-                                                sw, _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd')
+    with prof.launch('nf_project_gather_bwd', xyz, n_pts=N, V=V, C=C):
+        _lib.check(_lib.lib().nf_project_gather_bwd(_ptr(xyz), N, _ptr(cam_ws), V, H, W, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc,
+                                                    sh, sw, _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd')
     return d_feat
 
 
@@ -139,8 +142,9 @@ def ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias):
     L = _lib.lib()
     ws = torch.empty(L.nf_ibrnet_workspace_floats(R, S, V, 0), dtype=torch.float32, device=rgb_feat.device)
     raw = torch.empty(R, S, 4, dtype=torch.float32, device=rgb_feat.device)
-    _lib.check(L.nf_ibrnet_fwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S, V, int(bool(anti_alias)),
-                               _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd')
+    with prof.launch('nf_ibrnet_fwd', raw, R=R, S=S, V=V):
+        _lib.check(L.nf_ibrnet_fwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S, V,
+                                   int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd')
     return raw
 
 
@@ -152,8 +156,9 @@ def ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, anti_alias):
     L = _lib.lib()
     ws = torch.empty(L.nf_ibrnet_workspace_floats(R, S, V, 1), dtype=torch.float32, device=rgb_feat.device)
     d_rgb_feat = torch.empty_like(rgb_feat)
-    _lib.check(L.nf_ibrnet_bwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(d_raw), R, S, V,
-                               int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(ws), _stream(d_raw)), 'nf_ibrnet_bwd')
+    with prof.launch('nf_ibrnet_bwd', d_raw, R=R, S=S, V=V):
+        _lib.check(L.nf_ibrnet_bwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(d_raw), R, S, V,
+                                   int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(ws), _stream(d_raw)), 'nf_ibrnet_bwd')
     return d_rgb_feat
 
 
@@ -242,9 +247,11 @@ def pgd_adam_step_(delta, grad, exp_avg, exp_avg_sq, src, lr, step, epsilon, bet
     grad, src = _c(grad, 'grad'), _c(src, 'src')
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
-    _lib.check(_lib.lib().nf_pgd_adam_step(_ptr(delta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(src), delta.numel(),
-                                           -(lr / bc1), beta1, beta2, bc2 ** 0.5, adam_eps, float(epsilon), float(lower),
-                                           float(upper), _stream(delta)), 'nf_pgd_adam_step')
+    with prof.launch('nf_pgd_adam_step', delta, n=delta.numel()):
+        _lib.check(_lib.lib().nf_pgd_adam_step(_ptr(delta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(src),
+                                               delta.numel(), -(lr / bc1), 1.0 - beta1, beta2, 1.0 - beta2, bc2 ** 0.5,
+                                               adam_eps, float(epsilon), float(lower), float(upper), _stream(delta)),
+                   'nf_pgd_adam_step')
     return delta
 
 

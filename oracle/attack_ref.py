@@ -87,7 +87,7 @@ def pgd_attack(delta0, cnn_state, params_coarse, params_fine, src_ray_batch, ray
         d = delta.clone().requires_grad_(True)
         loss, _ = attack_loss(d, cnn_state, params_coarse, params_fine, src_ray_batch, ray_batches(it), cfg)
         grad, = torch.autograd.grad(loss, d)
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         if use_adam:
             delta = opt.step(delta, grad)
         else:

@@ -22,13 +22,14 @@ class Golden:
 
     def t(self, k, device='cpu'):
         a = self.z[k]
-        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        return torch.from_numpy(np.array(a, order='C')).to(device)      # np.array keeps 0-d shapes
 
     def params(self, prefix, device='cpu'):
         out = OrderedDict()
         for k in self.z.files:
-            if k.startswith(prefix + '/'):
-                out[k[len(prefix) + 1:]] = self.t(k, device)
+            name = k[len(prefix) + 1:]
+            if k.startswith(prefix + '/') and ('.' in name or name in ('s', 'pos_encoding')):
+                out[name] = self.t(k, device)
         return out or None
 
     def stage_cfg(self):

@@ -1,0 +1,285 @@
+"""Parity checks of the HIP path against the oracle / the reference's golden vectors, written once and run twice:
+on a real MI355X (tests/test_gpu_parity.py, -m gpu, device 'cuda') and through the CPU stand-in build of the same
+kernel sources (tests/test_emu_parity.py, device 'cpu').  Everything goes through the C ABI (nerfool_amd.ops)."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from fixtures import Golden, assert_close
+from nerfool_amd import eval_adv as EA
+from nerfool_amd import ops
+from nerfool_amd.ibrnet.feature_network import ResUNet
+from nerfool_amd.ibrnet.mlp_network import IBRNet
+from nerfool_amd.ibrnet.projection import Projector
+from nerfool_amd.ibrnet.render_image import render_single_image
+from nerfool_amd.ibrnet.render_ray import raw2outputs, render_rays, sample_along_camera_ray, sample_fine_depths
+from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
+from nerfool_amd.ibrnet import sample_ray as product_sample_ray
+from oracle import attack_ref as atk
+from oracle import feature_net_ref as fnet
+from oracle import ibrnet_ref as ib
+
+
+def make_net(params, n_samples, aa, dev):
+    net = IBRNet(SimpleNamespace(anti_alias_pooling=int(aa)), in_feat_ch=32, n_samples=n_samples)
+    sd = {k: v for k, v in params.items() if aa or k != 's'}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k == 'pos_encoding' for k in missing)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    return net.to(dev).eval()
+
+
+def make_model(g, cfg, dev):
+    pc, pf = g.params('coarse'), g.params('fine')
+    return SimpleNamespace(net_coarse=make_net(pc, cfg['S'], cfg['anti_alias_pooling'], dev),
+                           net_fine=make_net(pf, cfg['S'] + cfg['N_importance'], cfg['anti_alias_pooling'], dev) if pf else None)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def check_stage_kernels(case, dev):
+    """a2, a3, a4/a5, a6, a7 one by one against the reference's stage captures."""
+    g = Golden(case)
+    cfg = g.stage_cfg()
+    rb = g.ray_batch(dev)
+    R, S, V = cfg['R'], cfg['S'], cfg['V']
+    pts, z = sample_along_camera_ray(rb['ray_o'], rb['ray_d'], rb['depth_range'], S, inv_uniform=cfg['inv_uniform'], det=True)
+    assert_close(pts, g.np('coarse/pts'), 1e-6, 1e-6, 'pts')
+    assert_close(z, g.np('coarse/z'), 1e-6, 1e-6, 'z_vals')
+    cam = ops.camera_setup(rb['camera'], rb['src_cameras'])
+    fm = g.t('in/featmap_coarse', dev)
+    for layout, f in (('nchw', fm), ('channels_last', fm.contiguous(memory_format=torch.channels_last)),
+                      ('slice_of_64', torch.cat([fm, fm], 1).contiguous(memory_format=torch.channels_last)[:, 32:])):
+        rgb_feat, ray_diff, mask, pix = ops.project_gather_fwd(g.t('coarse/pts', dev).reshape(-1, 3), cam, rb['src_rgbs'][0], f,
+                                                                want_pix=True)
+        assert_close(pix.view(V, R, S, 2), g.np('coarse/pix'), 1e-5, 2e-3, layout + ' pixel locations')
+        assert np.array_equal(mask.view(R, S, V, 1).cpu().numpy(), g.np('coarse/mask')), layout + ' mask'
+        assert_close(rgb_feat.view(R, S, V, 35), g.np('coarse/rgb_feat'), 1e-4, 2e-5, layout + ' rgb_feat')
+        assert_close(ray_diff.view(R, S, V, 4), g.np('coarse/ray_diff'), 1e-4, 2e-5, layout + ' ray_diff')
+    net = make_net(g.params('coarse'), S, cfg['anti_alias_pooling'], dev)
+    raw = net(g.t('coarse/rgb_feat', dev), g.t('coarse/ray_diff', dev), g.t('coarse/mask', dev))
+    ref_raw = g.np('coarse/raw')
+    assert_close(raw, ref_raw, 1e-3, 1e-3 * float(np.abs(ref_raw).max()), 'IBRNet raw')
+    pm = ops.pixel_mask(g.t('coarse/mask', dev)[..., 0])
+    out = raw2outputs(g.t('coarse/raw', dev), g.t('coarse/z', dev), pm, white_bkgd=cfg['white_bkgd'])
+    for k in ('rgb', 'depth', 'weights', 'alpha'):
+        assert_close(out[k], g.np('outputs_coarse/' + k), 1e-4, 1e-5, 'raw2outputs ' + k)
+    assert np.array_equal(out['mask'].cpu().numpy(), g.np('outputs_coarse/mask'))
+    if cfg['N_importance']:
+        zf = sample_fine_depths(g.t('outputs_coarse/z_vals', dev), g.t('outputs_coarse/weights', dev), cfg['N_importance'],
+                                cfg['inv_uniform'], det=True)
+        assert bool((zf[:, 1:] >= zf[:, :-1]).all()), 'fine depths sorted'
+        assert_close(zf, g.np('outputs_fine/z_vals'), 1e-4, 1e-5, 'fine depths')
+
+
+def check_ibrnet_backward(case, dev):
+    """HIP IBRNet backward vs autograd of the oracle forward (CPU)."""
+    g = Golden(case)
+    cfg = g.stage_cfg()
+    p = g.params('coarse')
+    rgb_feat = g.t('coarse/rgb_feat').requires_grad_(True)
+    ray_diff, mask = g.t('coarse/ray_diff'), g.t('coarse/mask')
+    raw = ib.ibrnet_forward(p, rgb_feat, ray_diff, mask, cfg['anti_alias_pooling'])
+    d_raw = torch.randn(raw.shape, generator=torch.Generator().manual_seed(5))
+    ref, = torch.autograd.grad(raw, rgb_feat, d_raw)
+    net = make_net(p, cfg['S'], cfg['anti_alias_pooling'], dev)
+    x = g.t('coarse/rgb_feat', dev).requires_grad_(True)
+    out = net(x, ray_diff.to(dev), mask.to(dev))
+    mine, = torch.autograd.grad(out, x, d_raw.to(dev))
+    assert_close(mine, ref, 2e-3, 1e-3 * float(ref.abs().max()), 'd raw / d rgb_feat', frac_ok=1e-3)
+
+
+def check_gather_and_composite_backward(case, dev):
+    g = Golden(case)
+    cfg = g.stage_cfg()
+    rb = g.ray_batch()
+    R, S, V = cfg['R'], cfg['S'], cfg['V']
+    pts = g.t('coarse/pts')
+    fm = g.t('in/featmap_coarse').requires_grad_(True)
+    rf, _, _ = ib.projector_compute(pts, rb['camera'], rb['src_rgbs'], rb['src_cameras'], fm)
+    dg = torch.randn(rf.shape, generator=torch.Generator().manual_seed(6))
+    ref, = torch.autograd.grad(rf, fm, dg)
+    proj = Projector(dev)
+    for layout in ('nchw', 'channels_last'):
+        f = g.t('in/featmap_coarse', dev)
+        if layout == 'channels_last':
+            f = f.contiguous(memory_format=torch.channels_last)
+        f.requires_grad_(True)
+        rgb_feat, _, _ = proj.compute(pts.to(dev), rb['camera'].to(dev), rb['src_rgbs'].to(dev), rb['src_cameras'].to(dev), f)
+        mine, = torch.autograd.grad(rgb_feat, f, dg.to(dev))
+        assert_close(mine, ref, 1e-4, 1e-5 * float(ref.abs().max()), 'd rgb_feat / d featmap (%s)' % layout)
+    raw = g.t('coarse/raw').requires_grad_(True)
+    z = g.t('coarse/z')
+    pm = g.t('coarse/mask')[..., 0].sum(2) > 1
+    o = ib.raw2outputs(raw, z, pm, cfg['white_bkgd'])
+    gen = torch.Generator().manual_seed(7)
+    ups = [torch.randn(R, 3, generator=gen), torch.randn(R, generator=gen), torch.randn(R, S, generator=gen),
+           torch.randn(R, S, generator=gen)]
+    ref, = torch.autograd.grad([o['rgb'], o['depth'], o['weights'], o['alpha']], raw, ups)
+    raw_d = g.t('coarse/raw', dev).requires_grad_(True)
+    od = raw2outputs(raw_d, z.to(dev), pm.to(dev), white_bkgd=cfg['white_bkgd'])
+    mine, = torch.autograd.grad([od['rgb'], od['depth'], od['weights'], od['alpha']], raw_d, [u.to(dev) for u in ups])
+    assert_close(mine, ref, 1e-4, 1e-5 * float(ref.abs().max()), 'd outputs / d raw')
+
+
+def check_render_rays(case, dev):
+    """The product render_rays (all kernels chained, autograd Functions) vs the reference's end-to-end capture."""
+    g = Golden(case)
+    cfg = g.stage_cfg()
+    rb = g.ray_batch(dev)
+    model = make_model(g, cfg, dev)
+    fm_c = g.t('in/featmap_coarse', dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    fm_f = g.t('in/featmap_fine', dev).requires_grad_(True)
+    ret = render_rays(rb, model, (fm_c, fm_f), Projector(dev), cfg['S'], inv_uniform=cfg['inv_uniform'],
+                      N_importance=cfg['N_importance'], det=True, white_bkgd=cfg['white_bkgd'])
+    crit = EA.criterion
+    loss, _ = crit(ret['outputs_coarse'], rb)
+    if ret['outputs_fine'] is not None:
+        loss = loss + crit(ret['outputs_fine'], rb)[0]
+    for level in ('outputs_coarse', 'outputs_fine'):
+        if ret[level] is None:
+            continue
+        assert np.array_equal(ret[level]['mask'].cpu().numpy(), g.np(level + '/mask')), level + ' ray mask'
+        # rendered colour is the north-star quantity: 1e-3 of full scale; per-sample quantities tolerate the rare
+        # ill-conditioned sample of the reference's pooling weight (see tests/test_oracle_golden.py)
+        assert_close(ret[level]['rgb'], g.np(level + '/rgb'), 1e-3, 1e-3, level + ' rgb')
+        assert_close(ret[level]['depth'], g.np(level + '/depth'), 1e-3, 2e-3, level + ' depth')
+        assert_close(ret[level]['z_vals'], g.np(level + '/z_vals'), 1e-4, 1e-4, level + ' z_vals')
+        for k in ('weights', 'alpha'):
+            assert_close(ret[level][k], g.np('%s/%s' % (level, k)), 2e-3, 5e-4, '%s %s' % (level, k), frac_ok=2e-3)
+    assert_close(loss, g.np('loss'), 1e-3, 1e-6, 'loss')
+    grads = torch.autograd.grad(loss, [fm_c, fm_f] if cfg['N_importance'] else [fm_c])
+    gc = g.np('grad/featmap_coarse')
+    assert_close(grads[0], gc, 5e-3, 2e-3 * float(np.abs(gc).max()), 'd loss / d featmap_coarse', frac_ok=1e-3)
+    if cfg['N_importance']:
+        gf = g.np('grad/featmap_fine')
+        assert_close(grads[1], gf, 5e-3, 5e-3 * float(np.abs(gf).max()), 'd loss / d featmap_fine', frac_ok=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _attack_setup(dev):
+    g = Golden('attack_tiny')
+    H, W, V, R, S, N_imp, cnn_seed, n_adam, n_sign = [int(x) for x in g.np('cfg')]
+    feature_net = ResUNet(coarse_out_ch=32, fine_out_ch=32)
+    feature_net.load_state_dict(fnet.random_resunet_state(cnn_seed), strict=True)
+    for p in feature_net.parameters():
+        p.requires_grad_(False)
+    cfg = dict(S=S, N_importance=N_imp, anti_alias_pooling=True)
+    model = make_model(g, cfg, dev)
+    model.feature_net = feature_net.to(dev).eval()
+    data = {k: g.t('in/' + k) for k in ('rgb', 'camera', 'src_rgbs', 'src_cameras', 'depth_range')}
+    data['rgb_path'] = ['golden']
+    args = SimpleNamespace(N_rand=R, sample_mode='uniform', center_ratio=0.8, N_samples=S, N_importance=N_imp,
+                           inv_uniform=True, det=True, white_bkgd=False, epsilon=8, adv_lr=2, use_adam=True, adam_lr=1e-3,
+                           lr_step_size=4, lr_gamma=0.5, adv_iters=n_adam, chunk_size=1000)
+    sampler = RaySamplerSingleImage(data, dev)
+    return g, args, model, data, sampler, (H, W, V, R, S, N_imp, n_adam, n_sign)
+
+
+def check_ray_sampler(dev):
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    all_rays = sampler.get_all()
+    assert_close(all_rays['ray_o'][::97], g.np('image/ray_o'), 1e-6, 1e-6, 'ray_o')
+    assert_close(all_rays['ray_d'][::97], g.np('image/ray_d'), 1e-5, 1e-5, 'ray_d')
+    product_sample_ray.rng.seed(234)
+    picks = np.stack([sampler.sample_random_pixel(dims[3], 'uniform') for _ in range(3)])
+    assert np.array_equal(picks, g.np('adam/selected_inds')[:3])
+
+
+def check_feature_net(dev):
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    with torch.no_grad():
+        x = (data['src_rgbs'] + g.t('in/delta0')).to(dev).squeeze(0).permute(0, 3, 1, 2)
+        fc, ff = model.feature_net(x)
+    assert list(fc.shape) == list(g.np('cnn/shape'))
+    assert fc.stride(1) == 1, 'feature maps must come out channels-last'
+    assert_close(fc.reshape(-1)[::37][:1000], g.np('cnn/coarse_sample'), 1e-3, 2e-4, 'cnn coarse sample')
+    assert_close(ff.reshape(-1)[::41][:1000], g.np('cnn/fine_sample'), 1e-3, 2e-4, 'cnn fine sample')
+
+
+def check_attack_steps(dev, free_steps=None):
+    """Teacher-forced PGD steps (the loop is chaotic in fp32, see tests/test_oracle_golden.py): from the reference's
+    delta_t the HIP path must reproduce grad_t; from the reference's grad_t the fused update must reproduce delta_t+1."""
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    src_ray_batch = sampler.get_all()
+    eps = 8.0 / 255.0
+    picks = g.np('adam/selected_inds')
+    deltas = [g.t('in/delta0', dev), g.t('adam/delta_1', dev), g.t('adam/delta_2', dev), g.t('adam/delta_3', dev)]
+    atk_state = EA.PGDAttack(args, model, Projector(dev), src_ray_batch, delta=deltas[0].clone().requires_grad_(True))
+    for t in range(3):
+        atk_state.delta.data.copy_(deltas[t])
+        grad = atk_state.gradient(data, select_inds=picks[t])
+        ref_grad = g.np('adam/grad_iter%d' % t)
+        assert_close(atk_state.last_loss, g.np('adam/losses')[t], 1e-3, 1e-6, 'attack loss, iter %d' % t)
+        assert_close(grad, ref_grad, 1e-2, 2e-3 * float(np.abs(ref_grad).max()), 'd loss / d delta, iter %d' % t,
+                     frac_ok=2e-3)
+        atk_state.apply(g.t('adam/grad_iter%d' % t, dev))                 # the reference's gradient
+        assert_close(atk_state.delta.data, deltas[t + 1], 0, 2e-7, 'delta after fused Adam step %d' % (t + 1))
+    m_ref, v_ref = g.np('adam/exp_avg_3'), g.np('adam/exp_avg_sq_3')
+    assert_close(atk_state.exp_avg, m_ref, 1e-5, 1e-6 * float(np.abs(m_ref).max()), 'exp_avg')
+    assert_close(atk_state.exp_avg_sq, v_ref, 1e-5, 1e-6 * float(np.abs(v_ref).max()), 'exp_avg_sq')
+    # sign-PGD: one teacher-forced step
+    args_sign = SimpleNamespace(**{**vars(args), 'use_adam': False})
+    a2 = EA.PGDAttack(args_sign, model, Projector(dev), src_ray_batch, delta=deltas[0].clone().requires_grad_(True))
+    a2.apply(g.t('sign/grad_iter0', dev))
+    assert_close(a2.delta.data, g.np('sign/delta_1'), 0, 1e-7, 'delta after fused sign step')
+    # invariants of the projection, any number of free-running steps
+    product_sample_ray.rng.seed(234)
+    a3 = EA.PGDAttack(args, model, Projector(dev), src_ray_batch, delta=deltas[0].clone().requires_grad_(True))
+    n_free = dims[6] if free_steps is None else free_steps
+    losses = [float(a3.step(data)) for _ in range(n_free)]
+    d = a3.delta.data
+    src = src_ray_batch['src_rgbs']
+    assert float(d.abs().max()) <= eps + 1e-7
+    assert float((src + d).min()) >= -1e-6 and float((src + d).max()) <= 1 + 1e-6
+    ref_losses = g.np('adam/losses')
+    assert_close(np.array(losses[:2]), ref_losses[:2], 2e-3, 1e-6, 'first free-running losses')
+    if n_free == dims[6]:
+        assert abs(np.mean(losses[-3:]) - np.mean(ref_losses[-3:])) < 0.2 * np.mean(ref_losses[-3:])
+        assert float((d - g.t('adam/delta_%d' % dims[6], dev)).abs().mean()) < 0.1 * eps
+
+
+def check_init_perturb(dev):
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    src_ray_batch = sampler.get_all()
+    eps = 8.0 / 255.0
+    torch.manual_seed(0)
+    delta = EA.init_adv_perturb(args, src_ray_batch, eps, 1, 0)
+    src = src_ray_batch['src_rgbs']
+    assert delta.requires_grad and delta.shape == src.shape
+    assert float(delta.abs().max()) <= eps
+    assert float((src + delta).min()) >= 0 and float((src + delta).max()) <= 1
+    raw = torch.empty_like(src).uniform_(-eps, eps)
+    want = atk.clamp(raw.cpu(), 0 - src.cpu(), 1 - src.cpu())
+    got = ops.project_perturb_(raw.clone(), src, -1.0)
+    assert_close(got, want, 0, 0, 'init projection')
+    assert_close(EA.clamp(raw, 0 - src, 1 - src), want, 0, 0, 'clamp')
+
+
+def check_render_single_image(dev, rows=None):
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    H, W, V, R, S, N_imp, n_adam, _ = dims
+    src_ray_batch = sampler.get_all()
+    with torch.no_grad():
+        x = (src_ray_batch['src_rgbs'] + g.t('adam/delta_%d' % n_adam, dev)).squeeze(0).permute(0, 3, 1, 2)
+        featmaps = model.feature_net(x)
+    ray_batch = sampler.get_all()
+    shape_src = sampler
+    if rows is not None:      # the CPU stand-in renders only the first `rows` image rows
+        ray_batch = {k: (v[:rows * W] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in ray_batch.items()}
+        shape_src = SimpleNamespace(H=rows, W=W)
+        H = rows
+    ret = render_single_image(ray_sampler=shape_src, ray_batch=ray_batch, model=model, projector=Projector(dev),
+                              chunk_size=1000, det=True, N_samples=S, inv_uniform=True, N_importance=N_imp,
+                              white_bkgd=False, featmaps=featmaps, args=None, src_ray_batch=src_ray_batch)
+    for level in ('outputs_coarse', 'outputs_fine'):
+        assert ret[level]['rgb'].shape == (H, W, 3) and ret[level]['rgb'].device.type == 'cpu'
+        mism = (ret[level]['mask'].numpy() != g.np('image/%s/mask' % level)[:H]).mean()
+        assert mism <= 1e-3, '%s ray mask mismatch fraction %g' % (level, mism)
+        assert_close(ret[level]['rgb'], g.np('image/%s/rgb' % level)[:H], 1e-3, 1e-3, level + ' image rgb', frac_ok=2e-3)
+        assert_close(ret[level]['depth'], g.np('image/%s/depth' % level)[:H], 2e-3, 2e-3, level + ' image depth',
+                     frac_ok=5e-3)
+    if rows is None:
+        mse = float(torch.mean((ret['outputs_fine']['rgb'] - g.t('in/rgb')[0]) ** 2))
+        assert abs(ib.mse2psnr(mse) - float(g.np('image/psnr_fine'))) < 1e-2, 'PSNR'

@@ -1,0 +1,124 @@
+"""GPU (MI355X): the parity tests proper.  Everything goes through libnerfool_hip.so (C ABI); the checker is the CPU
+oracle / the reference's golden vectors.  Tolerances are written next to each comparison in parity_cases.py."""
+import numpy as np
+import pytest
+import torch
+
+import parity_cases as pc
+from fixtures import STAGE_CASES
+
+pytestmark = pytest.mark.gpu
+TINY = [c for c in STAGE_CASES if c != 'ibrnet_medium']
+
+
+@pytest.fixture(scope='module', autouse=True)
+def real_library():
+    from nerfool_amd import _lib
+    _lib._lib, _lib._emulated = None, False
+    lib = _lib.lib()          # raises if nerfool_amd/libnerfool_hip.so is missing: no fallback
+    assert not _lib.emulated()
+    assert lib.nf_device_cu_count() > 0
+    yield
+
+
+@pytest.mark.parametrize('case', TINY)
+def test_stage_kernels(case):
+    pc.check_stage_kernels(case, 'cuda')
+
+
+@pytest.mark.parametrize('case', TINY)
+def test_ibrnet_backward(case):
+    pc.check_ibrnet_backward(case, 'cuda')
+
+
+@pytest.mark.parametrize('case', TINY)
+def test_gather_and_composite_backward(case):
+    pc.check_gather_and_composite_backward(case, 'cuda')
+
+
+@pytest.mark.parametrize('case', STAGE_CASES)
+def test_render_rays(case):
+    pc.check_render_rays(case, 'cuda')
+
+
+def test_ray_sampler():
+    pc.check_ray_sampler('cuda')
+
+
+def test_feature_net():
+    pc.check_feature_net('cuda')
+
+
+def test_init_perturb():
+    pc.check_init_perturb('cuda')
+
+
+def test_attack_steps():
+    pc.check_attack_steps('cuda')
+
+
+def test_render_single_image():
+    pc.check_render_single_image('cuda')
+
+
+def test_cpu_tensors_are_rejected():
+    from nerfool_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.sample_along_ray(torch.zeros(4, 3), torch.ones(4, 3), torch.tensor([[2., 6.]]), 8, True)
+
+
+def test_full_size_properties():
+    """BASELINE config 2 sizes (756x1008 sources, V=4, 64+64 samples, 512 rays): size-independent invariants."""
+    from types import SimpleNamespace
+    from nerfool_amd import ops
+    from nerfool_amd.ibrnet.mlp_network import IBRNet
+    from nerfool_amd.ibrnet.projection import Projector
+    from nerfool_amd.ibrnet.render_ray import render_rays
+    from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
+    from nerfool_amd.synthetic import feature_map_size, make_scene, smooth_featmaps
+    dev = 'cuda'
+    H, W, V, R, S, N = 756, 1008, 4, 512, 64, 64
+    data = make_scene(H, W, V, seed=5)
+    sampler = RaySamplerSingleImage(data, dev)
+    rb = sampler.select(np.random.RandomState(0).choice(H * W, size=(R,), replace=False))
+    Hf, Wf = feature_map_size(H, W)
+    assert (Hf, Wf) == (192, 252)
+    fm = smooth_featmaps(V, 64, Hf, Wf, seed=1).to(dev).contiguous(memory_format=torch.channels_last)
+    fm_c, fm_f = fm[:, :32].requires_grad_(True), fm[:, 32:].requires_grad_(True)
+    torch.manual_seed(1)
+    args = SimpleNamespace(anti_alias_pooling=1)
+    model = SimpleNamespace(net_coarse=IBRNet(args, 32, S).to(dev), net_fine=IBRNet(args, 32, S + N).to(dev))
+    with torch.no_grad():
+        model.net_coarse.out_geometry_fc[2].bias += 1.0
+        model.net_fine.out_geometry_fc[2].bias += 1.0
+    ret = render_rays(rb, model, (fm_c, fm_f), Projector(dev), S, inv_uniform=True, N_importance=N, det=True)
+    for level, n in (('outputs_coarse', S), ('outputs_fine', S + N)):
+        o = ret[level]
+        assert o['weights'].shape == (R, n) and torch.isfinite(o['rgb']).all()
+        assert float(o['weights'].min()) >= 0 and float(o['weights'].sum(-1).max()) <= 1 + 1e-4      # sum of weights in [0,1]
+        assert float(o['alpha'].min()) >= 0 and float(o['alpha'].max()) <= 1
+        z = o['z_vals']
+        assert bool((z[:, 1:] >= z[:, :-1]).all()) and float(z.min()) >= 2 - 1e-4 and float(z.max()) <= 6 + 1e-4
+        d = o['depth'] / o['weights'].sum(-1).clamp_min(1e-6)
+        assert float(d.min()) >= 2 - 1e-3 and float(d.max()) <= 6 + 1e-3                              # convex combination of depths
+    # the coarse depths are a subset of the fine depths (sorted union)
+    zc, zf = ret['outputs_coarse']['z_vals'], ret['outputs_fine']['z_vals']
+    assert bool((torch.searchsorted(zf, zc) < zf.shape[1]).all())
+    assert bool((zf.gather(1, torch.searchsorted(zf, zc).clamp_max(zf.shape[1] - 1)) == zc).all())
+    # linearity of the backward in the upstream gradient, and determinism of everything but the float-atomic scatter
+    loss = ret['outputs_fine']['rgb'].square().sum() + ret['outputs_coarse']['rgb'].square().sum()
+    g1 = torch.autograd.grad(loss, [fm_c, fm_f], retain_graph=True)
+    g2 = torch.autograd.grad(2.0 * loss, [fm_c, fm_f])
+    for a, b in zip(g1, g2):
+        assert torch.isfinite(a).all()
+        assert float((2 * a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+    # the eps-ball / box projection of the fused update at the full delta size
+    src = sampler.get_all()['src_rgbs']
+    delta = torch.empty_like(src).uniform_(-0.05, 0.05)
+    grad = torch.randn_like(src)
+    m, v = torch.zeros_like(src), torch.zeros_like(src)
+    eps = 8 / 255.
+    for t in range(1, 4):
+        ops.pgd_adam_step_(delta, grad, m, v, src, 1e-3, t, eps)
+        assert float(delta.abs().max()) <= eps + 1e-7
+        assert float((src + delta).min()) >= -1e-6 and float((src + delta).max()) <= 1 + 1e-6
