@@ -145,7 +145,9 @@ def check_render_rays(case, dev):
         # ill-conditioned sample of the reference's pooling weight (see tests/test_oracle_golden.py)
         assert_close(ret[level]['rgb'], g.np(level + '/rgb'), 1e-3, 1e-3, level + ' rgb')
         assert_close(ret[level]['depth'], g.np(level + '/depth'), 1e-3, 2e-3, level + ' depth')
-        assert_close(ret[level]['z_vals'], g.np(level + '/z_vals'), 1e-4, 1e-4, level + ' z_vals')
+        # a re-sampled depth can flip bins where u_k ties a cdf edge or where the reference's `denom < 1e-5 -> 1`
+        # rule makes the inverse CDF discontinuous (render_ray.py:62-64): tolerate isolated flips
+        assert_close(ret[level]['z_vals'], g.np(level + '/z_vals'), 1e-4, 1e-4, level + ' z_vals', frac_ok=2e-4)
         for k in ('weights', 'alpha'):
             assert_close(ret[level][k], g.np('%s/%s' % (level, k)), 2e-3, 5e-4, '%s %s' % (level, k), frac_ok=2e-3)
     assert_close(loss, g.np('loss'), 1e-3, 1e-6, 'loss')
