@@ -90,6 +90,21 @@ int nf_ibrnet_bwd(const float* blob, const float* pos_enc, const float* rgb_feat
                   const float* mask, const float* d_raw, int64_t n_rays, int n_samples, int n_views,
                   int anti_alias_pooling, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 
+/* Matrix-core (MFMA, exact fp32) path of the same function for V in {1,2,4,8,16,32}: two kernels per level
+ * (per-(sample,view) rows on v_mfma_f32_32x32x2_f32, then per-ray attention).  mfma_blob = the natural blob re-ordered
+ * into MFMA operand order by nf_ibrnet_pack_mfma (HOST pointers in, HOST pointers out; no GPU needed).
+ * workspace: nf_ibrnet_mfma_workspace_floats(R, S) floats. */
+int64_t nf_ibrnet_mfma_blob_floats(void);
+int nf_ibrnet_pack_mfma(const float* natural_blob_host, float* mfma_blob_host);
+int nf_ibrnet_mfma_supported(int n_samples, int n_views);
+int64_t nf_ibrnet_mfma_workspace_floats(int64_t n_rays, int n_samples);
+int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
+                       const float* ray_diff, const float* mask, int64_t n_rays, int n_samples, int n_views,
+                       int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream);
+/* diagnostics: d[lane][16] = mfma_f32_32x32x2_f32(a[lane], b[lane], c[lane][16]) for one wave -- pins the fragment
+ * layout the kernels (and the CPU stand-in of the test-suite) assume */
+int nf_debug_mfma32(const float* a, const float* b, const float* c, float* d, nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * a6  raw2outputs                          ref: ibrnet/render_ray.py:123-170
  * raw [R,S,4], z_vals [R,S], pixel_mask [R,S] bytes (0/1) -> rgb [R,3], depth [R], weights [R,S], alpha [R,S],

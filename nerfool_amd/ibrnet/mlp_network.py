@@ -4,6 +4,8 @@ The module tree reproduces the parameter names of ibrnet/mlp_network.py:152-208 
 checkpoints (`net_coarse` / `net_fine` state-dicts) load by key; `pos_encoding` is rebuilt from n_samples because
 checkpoints may lack it (ibrnet/model.py:148-150).  The parameters are treated as constants of the attack: the
 backward produces d/d(rgb_feat) only (the reference accumulates weight gradients and never reads them)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -39,10 +41,18 @@ def sinusoid_table(n_samples, d_hid=16):
     return torch.from_numpy(np.where(j % 2 == 0, np.sin(ang), np.cos(ang))).float().unsqueeze(0)
 
 
+# 'auto' = matrix-core kernels whenever the shape allows (V a power of two), 'generic' = shape-generic kernels only
+KERNEL_PATH = os.environ.get('NERFOOL_IBRNET_KERNELS', 'auto')
+
+
 class _IBRNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb_feat, ray_diff, mask, blob, pos_enc, anti_alias):
-        raw = ops.ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
+    def forward(ctx, rgb_feat, ray_diff, mask, blob, mfma_blob, pos_enc, anti_alias):
+        S, V = rgb_feat.shape[1], rgb_feat.shape[2]
+        if KERNEL_PATH != 'generic' and mfma_blob is not None and ops.ibrnet_mfma_supported(S, V):
+            raw = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
+        else:
+            raw = ops.ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
         ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc)
         ctx.anti_alias = anti_alias
         return raw
@@ -51,7 +61,7 @@ class _IBRNetFunction(torch.autograd.Function):
     def backward(ctx, d_raw):
         rgb_feat, ray_diff, mask, blob, pos_enc = ctx.saved_tensors
         d_rgb_feat = ops.ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, ctx.anti_alias)
-        return d_rgb_feat, None, None, None, None, None
+        return d_rgb_feat, None, None, None, None, None, None
 
 
 class IBRNet(nn.Module):
@@ -79,6 +89,7 @@ class IBRNet(nn.Module):
                     nn.init.kaiming_normal_(m.weight.data)
                     nn.init.zeros_(m.bias.data)
         self._blob = None
+        self._mfma_blob = None
         self._blob_key = None
 
     def _packed(self, device):
@@ -86,8 +97,9 @@ class IBRNet(nn.Module):
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._blob is None or key != self._blob_key:
             self._blob = ops.pack_ibrnet_blob(self.state_dict(), device)
+            self._mfma_blob = ops.pack_ibrnet_mfma_blob(self._blob)
             self._blob_key = key
-        return self._blob
+        return self._blob, self._mfma_blob
 
     def forward(self, rgb_feat, ray_diff, mask):
         """
@@ -96,5 +108,6 @@ class IBRNet(nn.Module):
         :param mask: [n_rays, n_samples, n_views, 1]
         :return: [n_rays, n_samples, 4]  (rgb, sigma)
         """
-        blob = self._packed(rgb_feat.device)
-        return _IBRNetFunction.apply(rgb_feat, ray_diff, mask[..., 0], blob, self.pos_encoding, bool(self.anti_alias_pooling))
+        blob, mfma_blob = self._packed(rgb_feat.device)
+        return _IBRNetFunction.apply(rgb_feat, ray_diff, mask[..., 0], blob, mfma_blob, self.pos_encoding,
+                                     bool(self.anti_alias_pooling))

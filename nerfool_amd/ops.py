@@ -131,6 +131,44 @@ def pack_ibrnet_blob(state, device):
     return blob.to(device)
 
 
+def pack_ibrnet_mfma_blob(natural_blob):
+    """natural blob (any device) -> MFMA-operand-order blob on the same device (re-ordering done by the library on
+    host memory)."""
+    L = _lib.lib()
+    nat = natural_blob.detach().to('cpu', torch.float32).contiguous()
+    out = torch.empty(L.nf_ibrnet_mfma_blob_floats(), dtype=torch.float32)
+    _lib.check(L.nf_ibrnet_pack_mfma(nat.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma')
+    return out.to(natural_blob.device)
+
+
+def ibrnet_mfma_supported(S, V):
+    return bool(_lib.lib().nf_ibrnet_mfma_supported(int(S), int(V)))
+
+
+def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias):
+    rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
+    R, S, V, F = rgb_feat.shape
+    if F != 35:
+        raise ValueError('IBRNet expects 3+32 channels per view (got %d)' % F)
+    pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
+    if pe.shape[0] != S:
+        raise ValueError('pos_encoding is built for %d samples, input has %d' % (pe.shape[0], S))
+    L = _lib.lib()
+    ws = torch.empty(L.nf_ibrnet_mfma_workspace_floats(R, S), dtype=torch.float32, device=rgb_feat.device)
+    raw = torch.empty(R, S, 4, dtype=torch.float32, device=rgb_feat.device)
+    with prof.launch('nf_ibrnet_fwd_mfma', raw, R=R, S=S, V=V):
+        _lib.check(L.nf_ibrnet_fwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S,
+                                        V, int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd_mfma')
+    return raw
+
+
+def debug_mfma32(a, b, c):
+    d = torch.empty_like(c)
+    _lib.check(_lib.lib().nf_debug_mfma32(_ptr(_c(a, 'a')), _ptr(_c(b, 'b')), _ptr(_c(c, 'c')), _ptr(d), _stream(d)),
+               'nf_debug_mfma32')
+    return d
+
+
 def ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias):
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     R, S, V, F = rgb_feat.shape

@@ -119,19 +119,33 @@ typedef float nf_emu_f32x4 __attribute__((ext_vector_type(4)));
 
 // D = A(32x2) * B(2x32) + C.  lane l: a = A[l&31][l>>5], b = B[l>>5][l&31];
 // c[r] of lane l = C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].  k-ordered fmaf chain.
+// all lanes publish (a, b) once; two wave barriers per MFMA
+static inline void nf_emu_publish_ab(float a, float b, float* A, float* B) {
+    auto& sl = hip_emu::t_block->slot[hip_emu::wave()];
+    uint64_t raw = 0;
+    float ab[2] = {a, b};
+    memcpy(&raw, ab, 8);
+    sl[hip_emu::lane()] = raw;
+    hip_emu::wave_barrier();
+    for (int l = 0; l < 64; ++l) {
+        float t[2];
+        memcpy(t, &sl[l], 8);
+        A[l] = t[0];
+        B[l] = t[1];
+    }
+    hip_emu::wave_barrier();
+}
+
 static inline nf_emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, nf_emu_f32x16 c, int, int, int) {
-    float A[2], B[2];
+    float A[64], B[64];
+    nf_emu_publish_ab(a, b, A, B);
     nf_emu_f32x16 d = c;
     int l = hip_emu::lane(), col = l & 31, hi = l >> 5;
     for (int r = 0; r < 16; ++r) {
         int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        for (int k = 0; k < 2; ++k) {
-            A[k] = hip_emu::exchange(a, row + 32 * k);
-            B[k] = hip_emu::exchange(b, col + 32 * k);
-        }
         float acc = c[r];
-        acc = fmaf(A[0], B[0], acc);
-        acc = fmaf(A[1], B[1], acc);
+        acc = fmaf(A[row], B[col], acc);             // k = 0: A[row][0] lives in lane row, B[0][col] in lane col
+        acc = fmaf(A[row + 32], B[col + 32], acc);   // k = 1
         d[r] = acc;
     }
     return d;
@@ -139,16 +153,14 @@ static inline nf_emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
 
 // D = A(16x4) * B(4x16) + C.  lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; c[r] = C[row = 4*(l>>4) + r][col = l&15]
 static inline nf_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, nf_emu_f32x4 c, int, int, int) {
+    float A[64], B[64];
+    nf_emu_publish_ab(a, b, A, B);
     nf_emu_f32x4 d = c;
     int l = hip_emu::lane(), col = l & 15, q = l >> 4;
     for (int r = 0; r < 4; ++r) {
         int row = 4 * q + r;
         float acc = c[r];
-        for (int k = 0; k < 4; ++k) {
-            float A = hip_emu::exchange(a, row + 16 * k);
-            float B = hip_emu::exchange(b, col + 16 * k);
-            acc = fmaf(A, B, acc);
-        }
+        for (int k = 0; k < 4; ++k) acc = fmaf(A[row + 16 * k], B[col + 16 * k], acc);
         d[r] = acc;
     }
     return d;

@@ -64,3 +64,24 @@ def test_attack_steps():
 
 def test_render_single_image():
     pc.check_render_single_image('cpu', rows=4)
+
+
+def test_mfma_forward_matches_generic_kernels():
+    """matrix-core forward (emulated v_mfma_f32_32x32x2_f32) vs the generic kernel, ragged tile count, V = 4 and 2."""
+    import torch
+    from nerfool_amd import ops
+    from oracle.ibrnet_ref import random_ibrnet_params
+    for R, S, V in ((3, 10, 4), (2, 9, 2)):
+        gen = torch.Generator().manual_seed(S)
+        p = random_ibrnet_params(S, seed=3)
+        blob = ops.pack_ibrnet_blob(p, 'cpu')
+        mblob = ops.pack_ibrnet_mfma_blob(blob)
+        rgb_feat = torch.randn(R, S, V, 35, generator=gen)
+        rd = torch.randn(R, S, V, 4, generator=gen)
+        rd[..., 3] = 1 - 0.05 * torch.rand(R, S, V, generator=gen)
+        mask = (torch.rand(R, S, V, generator=gen) > 0.25).float()
+        mask[0, :3] = 0
+        args = (p['pos_encoding'], rgb_feat, rd, mask, True)
+        a = ops.ibrnet_fwd(blob, *args)
+        b = ops.ibrnet_fwd_mfma(mblob, blob, *args)
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max()))

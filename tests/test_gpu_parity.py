@@ -61,6 +61,49 @@ def test_render_single_image():
     pc.check_render_single_image('cuda')
 
 
+def test_mfma_fragment_layout():
+    """v_mfma_f32_32x32x2_f32 on the device vs the layout every MFMA kernel (and the CPU stand-in) assumes:
+    lane l: a = A[l&31][l>>5], b = B[l>>5][l&31]; c[r] = C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].  Asymmetric operands."""
+    from nerfool_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    A = torch.randn(32, 2, generator=gen)
+    B = torch.randn(2, 32, generator=gen)
+    C = torch.randn(32, 32, generator=gen)
+    lane = torch.arange(64)
+    a = A[lane & 31, lane >> 5]
+    b = B[lane >> 5, lane & 31]
+    r = torch.arange(16)
+    rows = (r[None] & 3) + 8 * (r[None] >> 2) + 4 * (lane[:, None] >> 5)
+    cols = (lane[:, None] & 31).expand(64, 16)
+    c = C[rows, cols]
+    d = ops.debug_mfma32(a.cuda(), b.cuda(), c.contiguous().cuda()).cpu()
+    want = (A.double() @ B.double() + C.double())[rows, cols]
+    assert float((d.double() - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 4), (37, 128, 4), (16, 64, 8), (9, 32, 2), (5, 24, 16), (3, 16, 1)])
+def test_mfma_forward_matches_generic_kernels(shape):
+    """matrix-core IBRNet forward vs the shape-generic kernels on random inputs (both on the GPU), incl. ragged tiles."""
+    from nerfool_amd import ops
+    from oracle.ibrnet_ref import random_ibrnet_params
+    R, S, V = shape
+    gen = torch.Generator().manual_seed(R * 1000 + S)
+    p = random_ibrnet_params(S, seed=3)
+    blob = ops.pack_ibrnet_blob(p, 'cuda')
+    mblob = ops.pack_ibrnet_mfma_blob(blob)
+    rgb_feat = torch.randn(R, S, V, 35, generator=gen).cuda()
+    rd = torch.randn(R, S, V, 4, generator=gen)
+    rd[..., :3] = torch.nn.functional.normalize(rd[..., :3], dim=-1)
+    rd[..., 3] = 1 - 0.05 * torch.rand(R, S, V, generator=gen)
+    mask = (torch.rand(R, S, V, generator=gen) > 0.25).float()
+    mask[0] = 0                                  # a ray without any valid observation
+    args = (p['pos_encoding'].cuda(), rgb_feat, rd.cuda(), mask.cuda(), True)
+    a = ops.ibrnet_fwd(blob, *args)
+    b = ops.ibrnet_fwd_mfma(mblob, blob, *args)
+    assert torch.isfinite(b).all()
+    assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max()))
+
+
 def test_cpu_tensors_are_rejected():
     from nerfool_amd import ops
     with pytest.raises(RuntimeError):
