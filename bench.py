@@ -182,7 +182,7 @@ def main():
     for name, k in kernels.items():
         per_launch = []
         for ms, meta in zip(k['ms'], k['meta']):
-            if name in ('nf_ibrnet_fwd', 'nf_ibrnet_bwd'):
+            if name in ('nf_ibrnet_fwd', 'nf_ibrnet_bwd', 'nf_ibrnet_fwd_mfma', 'nf_ibrnet_bwd_mfma'):
                 per_launch.append(('mfma', ibrnet_flops(meta['R'], meta['S'], meta['V']) / (ms * 1e-3) / 1e12))
             elif name == 'nf_project_gather_fwd':
                 b = meta['n_pts'] * meta['V'] * (4 * (meta['C'] + 3) * 4 + (3 + meta['C'] + 4 + 1) * 4)

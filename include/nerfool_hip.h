@@ -101,6 +101,12 @@ int64_t nf_ibrnet_mfma_workspace_floats(int64_t n_rays, int n_samples);
 int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
                        const float* ray_diff, const float* mask, int64_t n_rays, int n_samples, int n_views,
                        int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream);
+/* backward of the MFMA path: smp = the per-sample records the forward left in its workspace (keep that buffer);
+ * d_workspace: same size, scratch.  d_raw [R,S,4] -> d_rgb_feat [R,S,V,35]. */
+int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
+                       const float* ray_diff, const float* mask, const float* smp, const float* d_raw, int64_t n_rays,
+                       int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat, float* d_workspace,
+                       nf_stream_t stream);
 /* diagnostics: d[lane][16] = mfma_f32_32x32x2_f32(a[lane], b[lane], c[lane][16]) for one wave -- pins the fragment
  * layout the kernels (and the CPU stand-in of the test-suite) assume */
 int nf_debug_mfma32(const float* a, const float* b, const float* c, float* d, nf_stream_t stream);

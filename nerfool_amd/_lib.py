@@ -37,6 +37,7 @@ _PROTOTYPES = {
     'nf_ibrnet_mfma_supported': (c_int, [c_int, c_int]),
     'nf_ibrnet_mfma_workspace_floats': (c_int64, [c_int64, c_int]),
     'nf_ibrnet_fwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_ibrnet_bwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_debug_mfma32': (c_int, [_P, _P, _P, _P, _P]),
     'nf_composite_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'nf_composite_bwd': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),

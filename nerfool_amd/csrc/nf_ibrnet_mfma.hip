@@ -47,8 +47,20 @@ enum {
     MS_VISB1 = MS_VIS1L + 32 + 4,    // [h][16] vis_fc2.2, bias
     MS_RGB1 = MS_VISB1 + 32 + 4,     // 8 x [h][8], then 8 biases
     MS_RGB2 = MS_RGB1 + 128 + 8,     // 8 weights, bias, |s|
-    MS_END = MS_RGB2 + 12,
-    NF_MFMA_BLOB_FLOATS = MS_END
+    MS_RGB0V = MS_RGB2 + 12,         // [h][8] column 32 (the vis2 input) of rgb_fc.0 -- backward only
+    MS_END = MS_RGB0V + 16,
+    NF_MFMA_FWD_FLOATS = MS_END,     // the forward kernel stages [0, NF_MFMA_FWD_FLOATS)
+    // ---- transposed records for the backward-data GEMMs dX^T[K x rows] = W^T[K x N] . dY^T[N x rows]: lane l holds
+    //      W[n(step, l>>5)][k = 32*kt + (l&31)]
+    MT_BASE = MS_END,
+    MT_RGB0 = 0,                     // 8   (units: records, relative to MT_BASE)
+    MT_VISB0 = MT_RGB0 + 8,          // 16
+    MT_VIS1 = MT_VISB0 + 16,         // 16
+    MT_VIS0 = MT_VIS1 + 16,          // 16
+    MT_BASE1 = MT_VIS0 + 16,         // 2 k-tiles x 16
+    MT_BASE0 = MT_BASE1 + 32,        // 4 output tiles (mean feat, var feat, f feat, the 9 colour inputs) x 2 n-blocks x 16
+    MT_RECORDS = MT_BASE0 + 128,     // 216
+    NF_MFMA_BLOB_FLOATS = MT_BASE + MT_RECORDS * 64
 };
 enum { BT_DIR0, BT_DIR1, BT_BASE0A, BT_BASE0B, BT_BASE1, BT_VIS0, BT_VIS1, BT_VISB0, BT_RGB0 };
 
@@ -67,6 +79,16 @@ static void emit_record(float* rec, const float* W, int N, int K, int row_base, 
 
 static void emit_frag_block(float*& rec, const float* W, int N, int K, int row_base, int nt, int kbase, int nsteps) {
     for (int r = 0; r < nsteps; ++r, rec += 64) emit_record(rec, W, N, K, row_base, nt, kbase + nf_nidx(r, 0), kbase + nf_nidx(r, 1));
+}
+
+// transposed record block: lane (i, h), step r -> W[n = nbase + n(r,h)][k = kbase + i]   (W is [N][K])
+static void emit_frag_block_T(float*& rec, const float* W, int N, int K, int kbase, int nbase, int nsteps) {
+    for (int r = 0; r < nsteps; ++r, rec += 64)
+        for (int lane = 0; lane < 64; ++lane) {
+            int i = lane & 31, h = lane >> 5;
+            int n = nbase + nf_nidx(r, h), k = kbase + i;
+            rec[lane] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
+        }
 }
 
 static void emit_bias_tile(float* dst, const float* b, int N, int base) {
@@ -149,6 +171,29 @@ extern "C" int nf_ibrnet_pack_mfma(const float* nat, float* out) {
     }
     out[MS_RGB2 + 8] = nat[nf_lin_b(NF_L_RGB2)];
     out[MS_RGB2 + 9] = fabsf(nat[0]);
+    const float* W0 = nat + nf_lin_w(NF_L_RGB0);             // [16][37]
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 8; ++r) out[MS_RGB0V + h * 8 + r] = W0[nf_nidx(r, h) * 37 + 32];
+    // ---- transposed records (backward)
+    rec = out + MT_BASE;
+    emit_frag_block_T(rec, nat + nf_lin_w(NF_L_RGB0), 16, 37, 0, 0, 8);
+    emit_frag_block_T(rec, nat + nf_lin_w(NF_L_VISB0), 32, 32, 0, 0, 16);
+    emit_frag_block_T(rec, nat + nf_lin_w(NF_L_VIS1), 32, 32, 0, 0, 16);     // rows 0..31 of the [33][32] matrix
+    emit_frag_block_T(rec, nat + nf_lin_w(NF_L_VIS0), 32, 32, 0, 0, 16);
+    for (int kt = 0; kt < 2; ++kt) emit_frag_block_T(rec, nat + nf_lin_w(NF_L_BASE1), 32, 64, kt * 32, 0, 16);
+    W = nat + nf_lin_w(NF_L_BASE0);                          // [64][105]
+    for (int part = 0; part < 3; ++part)
+        for (int nb = 0; nb < 2; ++nb) emit_frag_block_T(rec, W, 64, 105, part * 35 + 3, nb * 32, 16);
+    {
+        static const int kcol[9] = {0, 1, 2, 35, 36, 37, 70, 71, 72};
+        for (int nb = 0; nb < 2; ++nb)
+            for (int r = 0; r < 16; ++r, rec += 64)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int i = lane & 31, h = lane >> 5, n = nb * 32 + nf_nidx(r, h);
+                    rec[lane] = i < 9 ? W[(size_t)n * 105 + kcol[i]] : 0.f;
+                }
+    }
+    if (rec - out != NF_MFMA_BLOB_FLOATS) return 2;
     return 0;
 }
 
@@ -209,20 +254,171 @@ __device__ __forceinline__ float dot_frag16(const float* vec_h, const f32x16& x)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// kernel A (forward)
+// kernel A: the per-(sample, view) row network.  rows_forward keeps every activation the backward needs in registers
+// (the forward kernel only consumes the outputs, the rest is dead code there).
 // ---------------------------------------------------------------------------------------------------------------
+struct RowIn {
+    f32x16 feat;                 // rgb_feat channels 3 + n(r,h)
+    float c[3], rd[4], mk;       // clean colour taps, ray_diff, validity
+};
+
+struct RowActs {
+    f32x16 F, MEAN, VAR, H1a, H1b, H, V1, XV, X2, U, MEAN2, VAR2;
+    float fc[3], mc[3], vc[3], r1[8], r2[8];
+    float w, logit, sig1, vis1, sig2, vis2, vsum, w2, wmean, nval, beta, rgb[3];
+};
+
+template <int V>
+__device__ __forceinline__ void load_row(const float* __restrict__ rgb_feat, const float* __restrict__ ray_diff,
+                                         const float* __restrict__ mask, int64_t row, int h, RowIn& in) {
+    const float* rf = rgb_feat + row * 35;
+    const float* rd = ray_diff + row * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in.feat[r] = rf[3 + nf_nidx(r, h)];
+    in.c[0] = rf[0]; in.c[1] = rf[1]; in.c[2] = rf[2];
+    in.rd[0] = rd[0]; in.rd[1] = rd[1]; in.rd[2] = rd[2]; in.rd[3] = rd[3];
+    in.mk = mask[row];
+}
+
+template <int V>
+__device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, int aa, const RowIn& in, RowActs& a) {
+    const float s_abs = lds[MS_RGB2 + 9];
+    // ---- direction MLP 4 -> 16 -> 35, f = rgb_feat + dir_feat   (mlp_network.py:231-233)
+    f32x16 d1 = bias_tile(lds, BT_DIR0, h);
+    d1 = NF_MFMA(lds[(MR_DIR0 + 0) * 64 + lane], h ? in.rd[1] : in.rd[0], d1);
+    d1 = NF_MFMA(lds[(MR_DIR0 + 1) * 64 + lane], h ? in.rd[3] : in.rd[2], d1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d1[r] = mf_elu(d1[r]);
+    {
+        f32x16 df = gemm_frag<8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.F[r] = in.feat[r] + mf_elu(df[r]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* wv = lds + MS_DIR1C + c * 16 + h * 8;
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d = fmaf(wv[r], d1[r], d);
+        d = half_sum(d) + lds[MS_DIR1C + 48 + c];
+        a.fc[c] = in.c[c] + mf_elu(d);
+    }
+    // ---- first pooling weight (:234-241)
+    float w;
+    if (aa) {
+        float e = expf(s_abs * (in.rd[3] - 1.f));
+        w = (e - grp_min<V>(e)) * in.mk;
+    } else {
+        w = in.mk;
+    }
+    w = w / (grp_sum<V>(w) + 1e-8f);
+    a.w = w;
+    // ---- weighted mean / variance over the V views of the sample (:144-149)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float mu = grp_sum<V>(a.F[r] * w);
+        float d = a.F[r] - mu;
+        a.MEAN[r] = mu;
+        a.VAR[r] = grp_sum<V>(w * (d * d));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.mc[c] = grp_sum<V>(a.fc[c] * w);
+        float d = a.fc[c] - a.mc[c];
+        a.vc[c] = grp_sum<V>(w * (d * d));
+    }
+    // ---- base_fc.0 (105 -> 64) as two 32-output tiles, base_fc.2 (64 -> 32)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        int rec = MR_BASE0 + nt * 54;
+        f32x16 acc = bias_tile(lds, BT_BASE0A + nt, h);
+        acc = gemm_frag<16>(lds, rec, lane, a.MEAN, acc);
+        acc = NF_MFMA(lds[(rec + 16) * 64 + lane], h ? a.mc[1] : a.mc[0], acc);
+        acc = NF_MFMA(lds[(rec + 17) * 64 + lane], h ? 0.f : a.mc[2], acc);
+        acc = gemm_frag<16>(lds, rec + 18, lane, a.VAR, acc);
+        acc = NF_MFMA(lds[(rec + 34) * 64 + lane], h ? a.vc[1] : a.vc[0], acc);
+        acc = NF_MFMA(lds[(rec + 35) * 64 + lane], h ? 0.f : a.vc[2], acc);
+        acc = gemm_frag<16>(lds, rec + 36, lane, a.F, acc);
+        acc = NF_MFMA(lds[(rec + 52) * 64 + lane], h ? a.fc[1] : a.fc[0], acc);
+        acc = NF_MFMA(lds[(rec + 53) * 64 + lane], h ? 0.f : a.fc[2], acc);
+        if (nt == 0) a.H1a = elu16(acc); else a.H1b = elu16(acc);
+    }
+    {
+        f32x16 acc = bias_tile(lds, BT_BASE1, h);
+        acc = gemm_frag<16>(lds, MR_BASE1, lane, a.H1a, acc);
+        acc = gemm_frag<16>(lds, MR_BASE1 + 16, lane, a.H1b, acc);
+        a.H = elu16(acc);
+    }
+    // ---- vis_fc on h * w, residual; vis_fc2 on x2 * vis1   (:249-254)
+    {
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = a.H[r] * w;
+        a.V1 = elu16(gemm_frag<16>(lds, MR_VIS0, lane, t, bias_tile(lds, BT_VIS0, h)));
+        a.XV = elu16(gemm_frag<16>(lds, MR_VIS1, lane, a.V1, bias_tile(lds, BT_VIS1, h)));
+        a.logit = mf_elu(dot_frag16(lds + MS_VIS1L + h * 16, a.V1) + lds[MS_VIS1L + 32]);
+        a.sig1 = mf_sigmoid(a.logit);
+        a.vis1 = a.sig1 * in.mk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a.X2[r] = a.H[r] + a.XV[r];
+            t[r] = a.X2[r] * a.vis1;
+        }
+        a.U = elu16(gemm_frag<16>(lds, MR_VISB0, lane, t, bias_tile(lds, BT_VISB0, h)));
+        float z2 = dot_frag16(lds + MS_VISB1 + h * 16, a.U) + lds[MS_VISB1 + 32];
+        a.sig2 = mf_sigmoid(z2);
+        a.vis2 = a.sig2 * in.mk;
+    }
+    a.vsum = grp_sum<V>(a.vis2) + 1e-8f;
+    a.w2 = a.vis2 / a.vsum;
+    a.wmean = grp_sum<V>(a.w2) / (float)V;
+    a.nval = grp_sum<V>(in.mk);
+    // ---- second pooling (:255-257)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float mu = grp_sum<V>(a.X2[r] * a.w2);
+        float d = a.X2[r] - mu;
+        a.MEAN2[r] = mu;
+        a.VAR2[r] = grp_sum<V>(a.w2 * (d * d));
+    }
+    // ---- colour head: rgb_fc 37 -> 16 -> 8 -> 1, softmax over views, blend of the clean colours  (:268-273)
+    float y;
+    {
+        f32x16 acc = gemm_frag<16>(lds, MR_RGB0, lane, a.X2, bias_tile(lds, BT_RGB0, h));
+        acc = NF_MFMA(lds[(MR_RGB0 + 16) * 64 + lane], h ? in.rd[0] : a.vis2, acc);
+        acc = NF_MFMA(lds[(MR_RGB0 + 17) * 64 + lane], h ? in.rd[2] : in.rd[1], acc);
+        acc = NF_MFMA(lds[(MR_RGB0 + 18) * 64 + lane], h ? 0.f : in.rd[3], acc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a.r1[r] = mf_elu(acc[r]);
+        y = lds[MS_RGB2 + 8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* wv = lds + MS_RGB1 + j * 16 + h * 8;
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t = fmaf(wv[r], a.r1[r], t);
+            a.r2[j] = mf_elu(half_sum(t) + lds[MS_RGB1 + 128 + j]);
+            y = fmaf(lds[MS_RGB2 + j], a.r2[j], y);
+        }
+    }
+    if (in.mk == 0.f) y = -1e9f;
+    float p = expf(y - grp_max<V>(y));
+    a.beta = p / grp_sum<V>(p);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.rgb[c] = grp_sum<V>(a.beta * in.c[c]);
+}
+
 template <int V>
 __global__ void __launch_bounds__(256, 2) k_ibr_rows_fwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
-                                                      const float* __restrict__ ray_diff, const float* __restrict__ mask,
-                                                      int64_t n_samples, int aa, float* __restrict__ smp) {
+                                                         const float* __restrict__ ray_diff, const float* __restrict__ mask,
+                                                         int64_t n_samples, int aa, float* __restrict__ smp) {
     HIP_DYNAMIC_SHARED(float, lds)
-    for (int i = threadIdx.x; i < NF_MFMA_BLOB_FLOATS; i += blockDim.x) lds[i] = wblob[i];
+    for (int i = threadIdx.x; i < NF_MFMA_FWD_FLOATS; i += blockDim.x) lds[i] = wblob[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
     const int64_t n_rows = n_samples * V;
     const int64_t n_tiles = (n_rows + 31) / 32;
-    const float s_abs = lds[MS_RGB2 + 9];
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
         // compiler barrier: keeps the (tile-invariant) weight reads from being hoisted out of the loop into 200+ VGPRs
         asm volatile("" ::: "memory");
@@ -231,154 +427,216 @@ __global__ void __launch_bounds__(256, 2) k_ibr_rows_fwd(const float* __restrict
         if (!live) row = n_rows - 1;
         const int64_t sample = row / V;
         const int v = (int)(row - sample * V);
-        const float* rf = rgb_feat + row * 35;
-        const float* rd = ray_diff + row * 4;
-        f32x16 F;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) F[r] = rf[3 + nf_nidx(r, h)];
-        const float c0 = rf[0], c1 = rf[1], c2 = rf[2];
-        const float rd0 = rd[0], rd1 = rd[1], rd2 = rd[2], rd3 = rd[3];
-        const float mk = mask[row];
-
-        // ---- direction MLP 4 -> 16 -> 35, f = rgb_feat + dir_feat
-        f32x16 d1 = bias_tile(lds, BT_DIR0, h);
-        d1 = NF_MFMA(lds[(MR_DIR0 + 0) * 64 + lane], h ? rd1 : rd0, d1);
-        d1 = NF_MFMA(lds[(MR_DIR0 + 1) * 64 + lane], h ? rd3 : rd2, d1);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) d1[r] = mf_elu(d1[r]);
-        {
-            f32x16 df = gemm_frag<8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) F[r] += mf_elu(df[r]);
-        }
-        float fc[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* wv = lds + MS_DIR1C + c * 16 + h * 8;
-            float d = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) d = fmaf(wv[r], d1[r], d);
-            d = half_sum(d) + lds[MS_DIR1C + 48 + c];
-            fc[c] = (c == 0 ? c0 : (c == 1 ? c1 : c2)) + mf_elu(d);
-        }
-        // ---- first pooling weight (mlp_network.py:234-241)
-        float w;
-        if (aa) {
-            float e = expf(s_abs * (rd3 - 1.f));
-            w = (e - grp_min<V>(e)) * mk;
-        } else {
-            w = mk;
-        }
-        w = w / (grp_sum<V>(w) + 1e-8f);
-        // ---- weighted mean / variance over the V views of the sample
-        f32x16 MEAN, VAR;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float mu = grp_sum<V>(F[r] * w);
-            float d = F[r] - mu;
-            MEAN[r] = mu;
-            VAR[r] = grp_sum<V>(w * (d * d));
-        }
-        float mc[3], vc[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            mc[c] = grp_sum<V>(fc[c] * w);
-            float d = fc[c] - mc[c];
-            vc[c] = grp_sum<V>(w * (d * d));
-        }
-        // ---- base_fc.0 (105 -> 64) as two 32-output tiles, base_fc.2 (64 -> 32)
-        f32x16 H;
-        {
-            f32x16 h1[2];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                int rec = MR_BASE0 + nt * 54;
-                f32x16 acc = bias_tile(lds, BT_BASE0A + nt, h);
-                acc = gemm_frag<16>(lds, rec, lane, MEAN, acc);
-                acc = NF_MFMA(lds[(rec + 16) * 64 + lane], h ? mc[1] : mc[0], acc);
-                acc = NF_MFMA(lds[(rec + 17) * 64 + lane], h ? 0.f : mc[2], acc);
-                acc = gemm_frag<16>(lds, rec + 18, lane, VAR, acc);
-                acc = NF_MFMA(lds[(rec + 34) * 64 + lane], h ? vc[1] : vc[0], acc);
-                acc = NF_MFMA(lds[(rec + 35) * 64 + lane], h ? 0.f : vc[2], acc);
-                acc = gemm_frag<16>(lds, rec + 36, lane, F, acc);
-                acc = NF_MFMA(lds[(rec + 52) * 64 + lane], h ? fc[1] : fc[0], acc);
-                acc = NF_MFMA(lds[(rec + 53) * 64 + lane], h ? 0.f : fc[2], acc);
-                h1[nt] = elu16(acc);
-            }
-            f32x16 acc = bias_tile(lds, BT_BASE1, h);
-            acc = gemm_frag<16>(lds, MR_BASE1, lane, h1[0], acc);
-            acc = gemm_frag<16>(lds, MR_BASE1 + 16, lane, h1[1], acc);
-            H = elu16(acc);
-        }
-        // ---- vis_fc on h * w, residual; vis_fc2 on x2 * vis1   (:249-254)
-        f32x16 X2;
-        float vis2;
-        {
-            f32x16 t;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t[r] = H[r] * w;
-            f32x16 v1 = elu16(gemm_frag<16>(lds, MR_VIS0, lane, t, bias_tile(lds, BT_VIS0, h)));
-            f32x16 xv = elu16(gemm_frag<16>(lds, MR_VIS1, lane, v1, bias_tile(lds, BT_VIS1, h)));
-            float logit = mf_elu(dot_frag16(lds + MS_VIS1L + h * 16, v1) + lds[MS_VIS1L + 32]);
-            float vis1 = mf_sigmoid(logit) * mk;
+        RowIn in;
+        load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
+        RowActs a;
+        rows_forward<V>(lds, lane, h, aa, in, a);
+        // per-sample record; the lane holding view 0 writes (both lane halves, 16 features each)
+        float* out = smp + sample * NF_SMP_STRIDE;
+        if (live && v == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                X2[r] = H[r] + xv[r];
-                t[r] = X2[r] * vis1;
+                out[nf_nidx(r, h)] = a.MEAN2[r];
+                out[32 + nf_nidx(r, h)] = a.VAR2[r];
             }
-            f32x16 u = elu16(gemm_frag<16>(lds, MR_VISB0, lane, t, bias_tile(lds, BT_VISB0, h)));
-            float z2 = dot_frag16(lds + MS_VISB1 + h * 16, u) + lds[MS_VISB1 + 32];
-            vis2 = mf_sigmoid(z2) * mk;
+            if (h == 0) {
+                out[64] = a.wmean;
+                out[65] = a.rgb[0];
+                out[66] = a.rgb[1];
+                out[67] = a.rgb[2];
+                out[68] = a.nval;
+                out[69] = a.vsum;
+            }
         }
-        const float vsum = grp_sum<V>(vis2) + 1e-8f;
-        const float w2 = vis2 / vsum;
-        const float wmean = grp_sum<V>(w2) / (float)V;
-        const float nval = grp_sum<V>(mk);
-        // ---- second pooling -> per-sample record (the lane holding view 0 writes)
-        float* out = smp + sample * NF_SMP_STRIDE;
-        const bool writer = live && v == 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel A backward: d(per-sample record) -> d rgb_feat.  Follows oracle/ibrnet_manual_bwd.py; the backward-data GEMMs
+// dX^T = W^T . dY^T use the transposed records and chain through registers exactly like the forward.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mf_elu_grad(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+template <int NSTEPS>
+__device__ __forceinline__ f32x16 gemm_frag_T(const float* lds, int rec, int lane, const f32x16& dy, f32x16 acc) {
+    const float* base = lds + MT_BASE;
+#pragma unroll
+    for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(base[(rec + r) * 64 + lane], dy[r], acc);
+    return acc;
+}
+
+// d_feat[r] = d rgb_feat[row][3 + n(r,h)], d_col[c] = d rgb_feat[row][c]
+template <int V>
+__device__ __forceinline__ void rows_backward(const float* lds, int lane, int h, const RowIn& in, const RowActs& a,
+                                              const f32x16& d_mean2, const f32x16& d_var2, float d_wmean,
+                                              const float (&d_rgb)[3], f32x16& d_feat, float (&d_col)[3]) {
+    // ---- colour head: blend softmax over views, rgb_fc 1 <- 8 <- 16 <- 37
+    f32x16 d_x2;
+    float d_vis2;
+    {
+        float d_beta = in.c[0] * d_rgb[0] + in.c[1] * d_rgb[1] + in.c[2] * d_rgb[2];
+        float sbd = grp_sum<V>(a.beta * d_beta);
+        float d_y = in.mk == 0.f ? 0.f : a.beta * (d_beta - sbd);      // masked_fill blocks the gradient
+        float d_r2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d_r2[j] = lds[MS_RGB2 + j] * d_y * mf_elu_grad(a.r2[j]);
+        f32x16 d_r1 = zero16();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t = fmaf(lds[MS_RGB1 + j * 16 + h * 8 + r], d_r2[j], t);
+            d_r1[r] = t * mf_elu_grad(a.r1[r]);
+        }
+        d_x2 = gemm_frag_T<8>(lds, MT_RGB0, lane, d_r1, zero16());
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t = fmaf(lds[MS_RGB0V + h * 8 + r], d_r1[r], t);
+        d_vis2 = half_sum(t);
+    }
+    // ---- second pooling (weights depend on the features through vis2)
+    {
+        float part = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float mu = grp_sum<V>(X2[r] * w2);
-            float d = X2[r] - mu;
-            float va = grp_sum<V>(w2 * (d * d));
-            if (writer) {
-                out[nf_nidx(r, h)] = mu;
-                out[32 + nf_nidx(r, h)] = va;
-            }
+            float dev = a.X2[r] - a.MEAN2[r];
+            float s2 = grp_sum<V>(a.w2 * dev);
+            float dm = d_mean2[r] + d_var2[r] * (-2.f * s2);
+            d_x2[r] += a.w2 * (dm + 2.f * dev * d_var2[r]);
+            part = fmaf(a.X2[r], dm, part);
+            part = fmaf(dev * dev, d_var2[r], part);
         }
-        // ---- colour head: rgb_fc 37 -> 16 -> 8 -> 1, softmax over views, blend of the clean colours  (:268-273)
-        float y;
-        {
-            f32x16 acc = gemm_frag<16>(lds, MR_RGB0, lane, X2, bias_tile(lds, BT_RGB0, h));
-            acc = NF_MFMA(lds[(MR_RGB0 + 16) * 64 + lane], h ? rd0 : vis2, acc);
-            acc = NF_MFMA(lds[(MR_RGB0 + 17) * 64 + lane], h ? rd2 : rd1, acc);
-            acc = NF_MFMA(lds[(MR_RGB0 + 18) * 64 + lane], h ? 0.f : rd3, acc);
-            float r1[8];
+        float d_w2 = half_sum(part) + d_wmean / (float)V;
+        float sdw = grp_sum<V>(d_w2 * a.w2);
+        d_vis2 += (d_w2 - sdw) / a.vsum;
+    }
+    // ---- vis_fc2 (1 <- 32 <- 32) on x2 * vis1
+    float d_vis1;
+    {
+        float d_z2 = d_vis2 * in.mk * a.sig2 * (1.f - a.sig2);
+        f32x16 d_u;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) r1[r] = mf_elu(acc[r]);
-            y = lds[MS_RGB2 + 8];
+        for (int r = 0; r < 16; ++r) d_u[r] = lds[MS_VISB1 + h * 16 + r] * d_z2 * mf_elu_grad(a.U[r]);
+        f32x16 d_xvis = gemm_frag_T<16>(lds, MT_VISB0, lane, d_u, zero16());
+        float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float* wv = lds + MS_RGB1 + j * 16 + h * 8;
-                float t = 0.f;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) t = fmaf(wv[r], r1[r], t);
-                t = mf_elu(half_sum(t) + lds[MS_RGB1 + 128 + j]);
-                y = fmaf(lds[MS_RGB2 + j], t, y);
-            }
+        for (int r = 0; r < 16; ++r) {
+            d_x2[r] = fmaf(d_xvis[r], a.vis1, d_x2[r]);
+            t = fmaf(d_xvis[r], a.X2[r], t);
         }
-        if (mk == 0.f) y = -1e9f;
-        float p = expf(y - grp_max<V>(y));
-        float beta = p / grp_sum<V>(p);
-        float o0 = grp_sum<V>(beta * c0), o1 = grp_sum<V>(beta * c1), o2 = grp_sum<V>(beta * c2);
-        if (writer && h == 0) {
-            out[64] = wmean;
-            out[65] = o0;
-            out[66] = o1;
-            out[67] = o2;
-            out[68] = nval;
-            out[69] = vsum;
+        d_vis1 = half_sum(t);
+    }
+    // ---- vis_fc (33 <- 32 <- 32) on h * w ; x2 = h + xv[:32]
+    f32x16 d_h;
+    {
+        float d_logit = d_vis1 * in.mk * a.sig1 * (1.f - a.sig1) * mf_elu_grad(a.logit);
+        f32x16 d_xv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d_xv[r] = d_x2[r] * mf_elu_grad(a.XV[r]);
+        f32x16 d_v1 = gemm_frag_T<16>(lds, MT_VIS1, lane, d_xv, zero16());
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            d_v1[r] = fmaf(lds[MS_VIS1L + h * 16 + r], d_logit, d_v1[r]) * mf_elu_grad(a.V1[r]);
+        f32x16 d_t = gemm_frag_T<16>(lds, MT_VIS0, lane, d_v1, zero16());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d_h[r] = (d_x2[r] + d_t[r] * a.w) * mf_elu_grad(a.H[r]);
+    }
+    // ---- base_fc (32 <- 64 <- 105)
+    f32x16 g_mean, g_var, g_f, g_col;
+    {
+        f32x16 d_h1a = gemm_frag_T<16>(lds, MT_BASE1, lane, d_h, zero16());
+        f32x16 d_h1b = gemm_frag_T<16>(lds, MT_BASE1 + 16, lane, d_h, zero16());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            d_h1a[r] *= mf_elu_grad(a.H1a[r]);
+            d_h1b[r] *= mf_elu_grad(a.H1b[r]);
+        }
+        g_mean = gemm_frag_T<16>(lds, MT_BASE0 + 16, lane, d_h1b, gemm_frag_T<16>(lds, MT_BASE0, lane, d_h1a, zero16()));
+        g_var = gemm_frag_T<16>(lds, MT_BASE0 + 48, lane, d_h1b, gemm_frag_T<16>(lds, MT_BASE0 + 32, lane, d_h1a, zero16()));
+        g_f = gemm_frag_T<16>(lds, MT_BASE0 + 80, lane, d_h1b, gemm_frag_T<16>(lds, MT_BASE0 + 64, lane, d_h1a, zero16()));
+        g_col = gemm_frag_T<16>(lds, MT_BASE0 + 112, lane, d_h1b, gemm_frag_T<16>(lds, MT_BASE0 + 96, lane, d_h1a, zero16()));
+    }
+    // ---- first pooling (the weights w are constants): feature channels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float dmean = grp_sum<V>(g_mean[r]);
+        float dvar = grp_sum<V>(g_var[r]);
+        float dev = a.F[r] - a.MEAN[r];
+        float s1 = grp_sum<V>(a.w * dev);
+        float dm = dmean + dvar * (-2.f * s1);
+        d_feat[r] = g_f[r] + a.w * (dm + 2.f * dev * dvar);
+    }
+    // ---- ... and the 3 colour channels.  The colour tile holds rows 0..8 = d/d(mean c0..2, var c0..2, f c0..2):
+    //      rows 0-3 and 8 sit in the low lane half (registers 0-3, 4), rows 4-7 in the high half (registers 0-3)
+    {
+        float lo0 = g_col[0], lo1 = g_col[1], lo2 = g_col[2], lo3 = g_col[3], lo4 = g_col[4];
+        float o0 = __shfl_xor(lo0, 32, NF_WAVE), o1 = __shfl_xor(lo1, 32, NF_WAVE), o2 = __shfl_xor(lo2, 32, NF_WAVE),
+              o3 = __shfl_xor(lo3, 32, NF_WAVE), o4 = __shfl_xor(lo4, 32, NF_WAVE);
+        // value of tile row i for this (row, either half): low half owns rows {0,1,2,3,8}, high half rows {4,5,6,7}
+        float row0 = h ? o0 : lo0, row1 = h ? o1 : lo1, row2 = h ? o2 : lo2, row3 = h ? o3 : lo3, row8 = h ? o4 : lo4;
+        float row4 = h ? lo0 : o0, row5 = h ? lo1 : o1, row6 = h ? lo2 : o2, row7 = h ? lo3 : o3;
+        float gm[3] = {row0, row1, row2}, gv[3] = {row3, row4, row5}, gf[3] = {row6, row7, row8};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float dmean = grp_sum<V>(gm[c]);
+            float dvar = grp_sum<V>(gv[c]);
+            float dev = a.fc[c] - a.mc[c];
+            float s1 = grp_sum<V>(a.w * dev);
+            float dm = dmean + dvar * (-2.f * s1);
+            d_col[c] = gf[c] + a.w * (dm + 2.f * dev * dvar) + a.beta * d_rgb[c];
+        }
+    }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256, 1) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
+                                                         const float* __restrict__ ray_diff, const float* __restrict__ mask,
+                                                         const float* __restrict__ d_smp, int64_t n_samples, int aa,
+                                                         float* __restrict__ d_rgb_feat) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    for (int i = threadIdx.x; i < NF_MFMA_BLOB_FLOATS; i += blockDim.x) lds[i] = wblob[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t n_rows = n_samples * V;
+    const int64_t n_tiles = (n_rows + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        asm volatile("" ::: "memory");
+        int64_t row = tile * 32 + m;
+        const bool live = row < n_rows;
+        if (!live) row = n_rows - 1;
+        const int64_t sample = row / V;
+        RowIn in;
+        load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
+        RowActs a;
+        rows_forward<V>(lds, lane, h, aa, in, a);
+        const float* g = d_smp + sample * NF_SMP_STRIDE;
+        f32x16 d_mean2, d_var2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            d_mean2[r] = g[nf_nidx(r, h)];
+            d_var2[r] = g[32 + nf_nidx(r, h)];
+        }
+        float d_rgb[3] = {g[65], g[66], g[67]};
+        f32x16 d_feat;
+        float d_col[3];
+        rows_backward<V>(lds, lane, h, in, a, d_mean2, d_var2, g[64], d_rgb, d_feat, d_col);
+        if (live) {
+            float* o = d_rgb_feat + row * 35;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[3 + nf_nidx(r, h)] = d_feat[r];
+            if (h == 0) {
+                o[0] = d_col[0];
+                o[1] = d_col[1];
+                o[2] = d_col[2];
+            }
         }
     }
 }
@@ -498,6 +756,261 @@ __global__ void __launch_bounds__(MAXT) k_ibr_ray_fwd(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// kernel B backward: d raw -> d(per-sample record).  Recomputes the per-sample forward (cheap), then walks back through
+// the density head, LayerNorm, the ray attention (dQ by query thread, dK/dV by key thread) and geometry_fc.
+// LDS per ray: Q, K, V, dO [S][16]; row max / sum / D [S][4]; n_valid [S].
+// ---------------------------------------------------------------------------------------------------------------
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_ibr_ray_bwd(const float* __restrict__ B, const float* __restrict__ pos_enc,
+                                                      const float* __restrict__ smp, const float* __restrict__ d_raw, int S,
+                                                      float* __restrict__ d_smp) {
+    HIP_DYNAMIC_SHARED(float, sm)
+    float* Qs = sm;
+    float* Ks = Qs + (size_t)S * 16;
+    float* Vs = Ks + (size_t)S * 16;
+    float* Gs = Vs + (size_t)S * 16;     // d_o
+    float* Ms = Gs + (size_t)S * 16;
+    float* Ls = Ms + (size_t)S * 4;
+    float* Ds = Ls + (size_t)S * 4;
+    float* Ns = Ds + (size_t)S * 4;
+    const int64_t ray = blockIdx.x;
+    const int s = threadIdx.x;
+    const bool active = s < S;
+    const float* rec = smp + (ray * S + (active ? s : 0)) * NF_SMP_STRIDE;
+    const float nval = rec[68];
+    float g1[64], g[16], gpe[16], q[16];
+    if (active) {
+#pragma unroll
+        for (int n = 0; n < 64; ++n) g1[n] = B[nf_lin_b(NF_L_GEO0) + n];
+        for (int k = 0; k < 65; ++k) {
+            float xk = rec[k];
+            const float* wr = B + nf_lin_wt(NF_L_GEO0) + k * 64;
+#pragma unroll
+            for (int n = 0; n < 64; ++n) g1[n] = fmaf(wr[n], xk, g1[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) g[n] = B[nf_lin_b(NF_L_GEO1) + n];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            g1[k] = mf_elu(g1[k]);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) g[n] = fmaf(B[nf_lin_wt(NF_L_GEO1) + k * 16 + n], g1[k], g[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            g[n] = mf_elu(g[n]);
+            gpe[n] = g[n] + pos_enc[(size_t)s * 16 + n];
+        }
+        float kk[16], vv[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) q[n] = kk[n] = vv[n] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                q[n] = fmaf(B[nf_att_wt(0) + k * 16 + n], gpe[k], q[n]);
+                kk[n] = fmaf(B[nf_att_wt(1) + k * 16 + n], gpe[k], kk[n]);
+                vv[n] = fmaf(B[nf_att_wt(2) + k * 16 + n], gpe[k], vv[n]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            Qs[s * 16 + n] = q[n];
+            Ks[s * 16 + n] = kk[n];
+            Vs[s * 16 + n] = vv[n];
+        }
+        Ns[s] = nval;
+    }
+    __syncthreads();
+    const bool row_on = nval > 1.f;
+    float d_pre[16];
+    if (active) {
+        float o[16];
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            float q0 = q[hd * 4] / 2.f, q1 = q[hd * 4 + 1] / 2.f, q2 = q[hd * 4 + 2] / 2.f, q3 = q[hd * 4 + 3] / 2.f;
+            float mx = -1e9f;
+            if (row_on) {
+                mx = -3.0e38f;
+                for (int k = 0; k < S; ++k) {
+                    const float* kp = Ks + k * 16 + hd * 4;
+                    mx = fmaxf(mx, fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0]))));
+                }
+            }
+            float l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int k = 0; k < S; ++k) {
+                const float* kp = Ks + k * 16 + hd * 4;
+                const float* vp = Vs + k * 16 + hd * 4;
+                float sc = row_on ? fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0]))) : -1e9f;
+                float p = expf(sc - mx);
+                l += p;
+                a0 = fmaf(p, vp[0], a0); a1 = fmaf(p, vp[1], a1); a2 = fmaf(p, vp[2], a2); a3 = fmaf(p, vp[3], a3);
+            }
+            o[hd * 4] = a0 / l; o[hd * 4 + 1] = a1 / l; o[hd * 4 + 2] = a2 / l; o[hd * 4 + 3] = a3 / l;
+            Ms[s * 4 + hd] = mx;
+            Ls[s * 4 + hd] = l;
+        }
+        float pre[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) pre[n] = gpe[n];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+            for (int n = 0; n < 16; ++n) pre[n] = fmaf(B[nf_att_wt(3) + k * 16 + n], o[k], pre[n]);
+        }
+        float mu = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) mu += pre[n];
+        mu = mu / 16.f;
+        float var = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) var += (pre[n] - mu) * (pre[n] - mu);
+        float rstd = 1.f / sqrtf(var / 16.f + 1e-6f);
+        float xhat[16], og1[16];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) og1[n] = B[nf_lin_b(NF_L_OG0) + n];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            xhat[k] = (pre[k] - mu) * rstd;
+            float gat = xhat[k] * B[NF_LN_W + k] + B[NF_LN_B + k];
+#pragma unroll
+            for (int n = 0; n < 16; ++n) og1[n] = fmaf(B[nf_lin_wt(NF_L_OG0) + k * 16 + n], gat, og1[n]);
+        }
+        float sp = B[nf_lin_b(NF_L_OG1)];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            og1[n] = mf_elu(og1[n]);
+            sp = fmaf(B[nf_lin_wt(NF_L_OG1) + n], og1[n], sp);
+        }
+        // ---- density head + LayerNorm backward
+        float d_sp = (nval >= 1.f && sp > 0.f) ? d_raw[(ray * S + s) * 4 + 3] : 0.f;
+        float d_xh[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d_xh[k] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            float d_og = B[nf_lin_w(NF_L_OG1) + n] * d_sp * mf_elu_grad(og1[n]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d_xh[k] = fmaf(B[nf_lin_w(NF_L_OG0) + n * 16 + k], d_og, d_xh[k]);
+        }
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            d_xh[k] *= B[NF_LN_W + k];
+            m1 += d_xh[k];
+            m2 += d_xh[k] * xhat[k];
+        }
+        m1 = m1 / 16.f;
+        m2 = m2 / 16.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d_pre[k] = rstd * (d_xh[k] - m1 - xhat[k] * m2);
+        float d_o[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) d_o[j] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d_o[j] = fmaf(B[nf_att_w(3) + n * 16 + j], d_pre[n], d_o[j]);
+        }
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            float D = 0.f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                Gs[s * 16 + hd * 4 + d] = d_o[hd * 4 + d];
+                D = fmaf(d_o[hd * 4 + d], o[hd * 4 + d], D);
+            }
+            Ds[s * 4 + hd] = D;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    // ---- attention backward: dQ (this thread as query), dK / dV (this thread as key)
+    float d_gpe[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d_gpe[j] = d_pre[j];      // residual
+    float dq[16], dk[16], dv[16];
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (row_on) {
+            float q0 = q[hd * 4] / 2.f, q1 = q[hd * 4 + 1] / 2.f, q2 = q[hd * 4 + 2] / 2.f, q3 = q[hd * 4 + 3] / 2.f;
+            const float* gp = Gs + s * 16 + hd * 4;
+            float g0 = gp[0], g1v = gp[1], g2 = gp[2], g3 = gp[3];
+            float mx = Ms[s * 4 + hd], l = Ls[s * 4 + hd], D = Ds[s * 4 + hd];
+            for (int k = 0; k < S; ++k) {
+                const float* kp = Ks + k * 16 + hd * 4;
+                const float* vp = Vs + k * 16 + hd * 4;
+                float sc = fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0])));
+                float p = expf(sc - mx) / l;
+                float dA = fmaf(g3, vp[3], fmaf(g2, vp[2], fmaf(g1v, vp[1], g0 * vp[0])));
+                float dS = p * (dA - D);
+                a0 = fmaf(dS, kp[0], a0); a1 = fmaf(dS, kp[1], a1); a2 = fmaf(dS, kp[2], a2); a3 = fmaf(dS, kp[3], a3);
+            }
+        }
+        dq[hd * 4] = a0 / 2.f; dq[hd * 4 + 1] = a1 / 2.f; dq[hd * 4 + 2] = a2 / 2.f; dq[hd * 4 + 3] = a3 / 2.f;
+        const float* kp = Ks + s * 16 + hd * 4;
+        const float* vp = Vs + s * 16 + hd * 4;
+        float k0 = kp[0], k1 = kp[1], k2 = kp[2], k3 = kp[3], v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        for (int qi = 0; qi < S; ++qi) {
+            const float* qp = Qs + qi * 16 + hd * 4;
+            const float* gp = Gs + qi * 16 + hd * 4;
+            bool on = Ns[qi] > 1.f;
+            float q0 = qp[0] / 2.f, q1 = qp[1] / 2.f, q2 = qp[2] / 2.f, q3 = qp[3] / 2.f;
+            float sc = on ? fmaf(q3, k3, fmaf(q2, k2, fmaf(q1, k1, q0 * k0))) : -1e9f;
+            float p = expf(sc - Ms[qi * 4 + hd]) / Ls[qi * 4 + hd];
+            c0 = fmaf(p, gp[0], c0); c1 = fmaf(p, gp[1], c1); c2 = fmaf(p, gp[2], c2); c3 = fmaf(p, gp[3], c3);
+            if (on) {
+                float dA = fmaf(gp[3], v3, fmaf(gp[2], v2, fmaf(gp[1], v1, gp[0] * v0)));
+                float dS = p * (dA - Ds[qi * 4 + hd]);
+                b0 = fmaf(dS, q0, b0); b1 = fmaf(dS, q1, b1); b2 = fmaf(dS, q2, b2); b3 = fmaf(dS, q3, b3);
+            }
+        }
+        dk[hd * 4] = b0; dk[hd * 4 + 1] = b1; dk[hd * 4 + 2] = b2; dk[hd * 4 + 3] = b3;
+        dv[hd * 4] = c0; dv[hd * 4 + 1] = c1; dv[hd * 4 + 2] = c2; dv[hd * 4 + 3] = c3;
+    }
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            d_gpe[j] = fmaf(B[nf_att_w(0) + n * 16 + j], dq[n], d_gpe[j]);
+            d_gpe[j] = fmaf(B[nf_att_w(1) + n * 16 + j], dk[n], d_gpe[j]);
+            d_gpe[j] = fmaf(B[nf_att_w(2) + n * 16 + j], dv[n], d_gpe[j]);
+        }
+    }
+    // ---- geometry_fc backward (16 <- 64 <- 65)
+    float d_g1[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) d_g1[k] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        float dgn = d_gpe[n] * mf_elu_grad(g[n]);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) d_g1[k] = fmaf(B[nf_lin_w(NF_L_GEO1) + n * 64 + k], dgn, d_g1[k]);
+    }
+    float* out = d_smp + (ray * S + s) * NF_SMP_STRIDE;
+    for (int k0 = 0; k0 < 65; k0 += 13) {       // 5 chunks of 13 outputs keep the accumulators in registers
+        float acc[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 64; ++n) {
+            float dn = d_g1[n] * mf_elu_grad(g1[n]);
+            const float* wr = B + nf_lin_w(NF_L_GEO0) + n * 65 + k0;
+#pragma unroll
+            for (int j = 0; j < 13; ++j) acc[j] = fmaf(wr[j], dn, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) out[k0 + j] = acc[j];
+    }
+    const float* gr = d_raw + (ray * S + s) * 4;
+    out[65] = gr[0];
+    out[66] = gr[1];
+    out[67] = gr[2];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int nf_ibrnet_mfma_supported(int n_samples, int n_views) {
@@ -515,7 +1028,7 @@ static void launch_rows_fwd(const float* wblob, const float* rgb_feat, const flo
     int64_t tiles = (n_samples * V + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > 1024) blocks = 1024;     // persistent-ish: 2 workgroups per CU hold the 58 KB weight image each
-    hipLaunchKernelGGL(k_ibr_rows_fwd<V>, dim3((unsigned)blocks), dim3(256), NF_MFMA_BLOB_FLOATS * sizeof(float), st, wblob,
+    hipLaunchKernelGGL(k_ibr_rows_fwd<V>, dim3((unsigned)blocks), dim3(256), NF_MFMA_FWD_FLOATS * sizeof(float), st, wblob,
                        rgb_feat, ray_diff, mask, n_samples, aa, smp);
 }
 
@@ -545,6 +1058,61 @@ extern "C" int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, con
         hipLaunchKernelGGL(k_ibr_ray_fwd<NF_IBR_MAX_S>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc,
                            workspace, n_samples, raw);
     NF_LAUNCH_CHECK("nf_ibrnet_fwd_mfma (ray)");
+    return 0;
+}
+
+template <int V>
+static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
+                           const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, hipStream_t st) {
+    static bool configured = false;      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
+    const size_t smem = NF_MFMA_BLOB_FLOATS * sizeof(float);
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+            hipSuccess) {
+            nf_set_error("nf_ibrnet_bwd_mfma: cannot reserve %zu bytes of LDS", smem);
+            return 1;
+        }
+        configured = true;
+    }
+    int64_t tiles = (n_samples * V + 31) / 32;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 512) blocks = 512;        // one 4-wave workgroup per CU holds the 113 KB weight image (fwd + transposed)
+    hipLaunchKernelGGL(k_ibr_rows_bwd<V>, dim3((unsigned)blocks), dim3(256), smem, st, wblob, rgb_feat, ray_diff, mask, d_smp,
+                       n_samples, aa, d_rgb_feat);
+    return 0;
+}
+
+/* smp = the per-sample records the forward left in its workspace; d_workspace: same size, receives d(records) */
+extern "C" int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
+                                  const float* ray_diff, const float* mask, const float* smp, const float* d_raw,
+                                  int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat,
+                                  float* d_workspace, nf_stream_t stream) {
+    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "nf_ibrnet_bwd_mfma: V must be a power of two <= 32 (got %d)",
+               n_views);
+    if (n_rays == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int threads = ((n_samples + 63) / 64) * 64;
+    size_t smem = (size_t)n_samples * 77 * sizeof(float);
+    NF_REQUIRE(smem <= 64 * 1024, "nf_ibrnet_bwd_mfma: S=%d exceeds the LDS budget of the ray kernel", n_samples);
+    if (threads <= 256)
+        hipLaunchKernelGGL(k_ibr_ray_bwd<256>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc, smp, d_raw,
+                           n_samples, d_workspace);
+    else
+        hipLaunchKernelGGL(k_ibr_ray_bwd<NF_IBR_MAX_S>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc, smp,
+                           d_raw, n_samples, d_workspace);
+    NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (ray)");
+    int64_t ns = n_rays * n_samples;
+    int rc;
+    switch (n_views) {
+        case 1: rc = launch_rows_bwd<1>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 2: rc = launch_rows_bwd<2>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 4: rc = launch_rows_bwd<4>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 8: rc = launch_rows_bwd<8>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 16: rc = launch_rows_bwd<16>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        default: rc = launch_rows_bwd<32>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+    }
+    if (rc) return rc;
+    NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (rows)");
     return 0;
 }
 

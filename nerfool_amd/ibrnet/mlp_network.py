@@ -49,18 +49,24 @@ class _IBRNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb_feat, ray_diff, mask, blob, mfma_blob, pos_enc, anti_alias):
         S, V = rgb_feat.shape[1], rgb_feat.shape[2]
-        if KERNEL_PATH != 'generic' and mfma_blob is not None and ops.ibrnet_mfma_supported(S, V):
-            raw = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
+        ctx.mfma = KERNEL_PATH != 'generic' and mfma_blob is not None and ops.ibrnet_mfma_supported(S, V)
+        if ctx.mfma:
+            raw, smp = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
+            ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp)
         else:
             raw = ops.ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
-        ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc)
+            ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc)
         ctx.anti_alias = anti_alias
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
-        rgb_feat, ray_diff, mask, blob, pos_enc = ctx.saved_tensors
-        d_rgb_feat = ops.ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, ctx.anti_alias)
+        if ctx.mfma:
+            rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp = ctx.saved_tensors
+            d_rgb_feat = ops.ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, ctx.anti_alias)
+        else:
+            rgb_feat, ray_diff, mask, blob, pos_enc = ctx.saved_tensors
+            d_rgb_feat = ops.ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, ctx.anti_alias)
         return d_rgb_feat, None, None, None, None, None, None
 
 

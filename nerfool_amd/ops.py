@@ -159,7 +159,21 @@ def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_ali
     with prof.launch('nf_ibrnet_fwd_mfma', raw, R=R, S=S, V=V):
         _lib.check(L.nf_ibrnet_fwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S,
                                         V, int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd_mfma')
-    return raw
+    return raw, ws
+
+
+def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias):
+    rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
+    d_raw = _c(d_raw, 'd_raw')
+    R, S, V, _ = rgb_feat.shape
+    pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
+    d_ws = torch.empty_like(smp)
+    d_rgb_feat = torch.empty_like(rgb_feat)
+    with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
+        _lib.check(_lib.lib().nf_ibrnet_bwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
+                                                 _ptr(smp), _ptr(d_raw), R, S, V, int(bool(anti_alias)), _ptr(d_rgb_feat),
+                                                 _ptr(d_ws), _stream(d_raw)), 'nf_ibrnet_bwd_mfma')
+    return d_rgb_feat
 
 
 def debug_mfma32(a, b, c):

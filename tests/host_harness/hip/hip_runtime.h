@@ -41,6 +41,8 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 enum { hipDeviceAttributeMultiprocessorCount = 1 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }

@@ -66,7 +66,7 @@ def test_render_single_image():
     pc.check_render_single_image('cpu', rows=4)
 
 
-def test_mfma_forward_matches_generic_kernels():
+def test_mfma_kernels_match_generic_kernels():
     """matrix-core forward (emulated v_mfma_f32_32x32x2_f32) vs the generic kernel, ragged tile count, V = 4 and 2."""
     import torch
     from nerfool_amd import ops
@@ -83,5 +83,9 @@ def test_mfma_forward_matches_generic_kernels():
         mask[0, :3] = 0
         args = (p['pos_encoding'], rgb_feat, rd, mask, True)
         a = ops.ibrnet_fwd(blob, *args)
-        b = ops.ibrnet_fwd_mfma(mblob, blob, *args)
+        b, _ = ops.ibrnet_fwd_mfma(mblob, blob, *args)
         assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max()))
+        d_raw = torch.randn(R, S, 4, generator=gen)
+        ga = ops.ibrnet_bwd(blob, args[0], rgb_feat, rd, mask, d_raw, True)
+        gb = ops.ibrnet_bwd_mfma(mblob, blob, args[0], rgb_feat, rd, mask, _, d_raw, True)
+        assert float((ga - gb).abs().max()) <= 1e-4 * max(1.0, float(ga.abs().max()))

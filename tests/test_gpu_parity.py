@@ -82,8 +82,8 @@ def test_mfma_fragment_layout():
 
 
 @pytest.mark.parametrize('shape', [(64, 64, 4), (37, 128, 4), (16, 64, 8), (9, 32, 2), (5, 24, 16), (3, 16, 1)])
-def test_mfma_forward_matches_generic_kernels(shape):
-    """matrix-core IBRNet forward vs the shape-generic kernels on random inputs (both on the GPU), incl. ragged tiles."""
+def test_mfma_kernels_match_generic_kernels(shape):
+    """matrix-core IBRNet forward AND backward vs the shape-generic kernels on random inputs (both on the GPU), incl. ragged tiles."""
     from nerfool_amd import ops
     from oracle.ibrnet_ref import random_ibrnet_params
     R, S, V = shape
@@ -99,9 +99,14 @@ def test_mfma_forward_matches_generic_kernels(shape):
     mask[0] = 0                                  # a ray without any valid observation
     args = (p['pos_encoding'].cuda(), rgb_feat, rd.cuda(), mask.cuda(), True)
     a = ops.ibrnet_fwd(blob, *args)
-    b = ops.ibrnet_fwd_mfma(mblob, blob, *args)
+    b, _ = ops.ibrnet_fwd_mfma(mblob, blob, *args)
     assert torch.isfinite(b).all()
     assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(a.abs().max()))
+    d_raw = torch.randn(R, S, 4, generator=gen).cuda()
+    ga = ops.ibrnet_bwd(blob, args[0], rgb_feat, args[2], args[3], d_raw, True)
+    gb = ops.ibrnet_bwd_mfma(mblob, blob, args[0], rgb_feat, args[2], args[3], _, d_raw, True)
+    assert torch.isfinite(gb).all()
+    assert float((ga - gb).abs().max()) <= 2e-4 * max(1.0, float(ga.abs().max()))
 
 
 def test_cpu_tensors_are_rejected():
