@@ -20,10 +20,14 @@ def emulated_library():
         pytest.skip('clang++ of the ROCm toolchain is needed to build the CPU stand-in')
     subprocess.run([os.path.join(HARNESS, 'build.sh')], check=True, capture_output=True)
     from nerfool_amd import _lib
-    saved = (_lib._lib, _lib._emulated)
+    from nerfool_amd.ibrnet import mlp_network
+    saved = (_lib._lib, _lib._emulated, mlp_network.KERNEL_PATH)
     _lib.use_library_for_tests(os.path.join(HARNESS, 'libnerfool_emu.so'))
+    # emulating the matrix-core kernels costs ~30x the generic ones: the end-to-end cases below run on the generic
+    # kernels, the MFMA kernels have their own (small) cases at the end of this file
+    mlp_network.KERNEL_PATH = 'generic'
     yield
-    _lib._lib, _lib._emulated = saved
+    _lib._lib, _lib._emulated, mlp_network.KERNEL_PATH = saved
 
 
 @pytest.mark.parametrize('case', TINY)
@@ -89,3 +93,13 @@ def test_mfma_kernels_match_generic_kernels():
         ga = ops.ibrnet_bwd(blob, args[0], rgb_feat, rd, mask, d_raw, True)
         gb = ops.ibrnet_bwd_mfma(mblob, blob, args[0], rgb_feat, rd, mask, _, d_raw, True)
         assert float((ga - gb).abs().max()) <= 1e-4 * max(1.0, float(ga.abs().max()))
+
+
+def test_render_rays_through_mfma_kernels():
+    """end-to-end render_rays + loss + gradients with the matrix-core kernels selected (V = 4 case)."""
+    from nerfool_amd.ibrnet import mlp_network
+    mlp_network.KERNEL_PATH = 'auto'
+    try:
+        pc.check_render_rays('ibrnet_tiny_invu', 'cpu')
+    finally:
+        mlp_network.KERNEL_PATH = 'generic'
