@@ -234,14 +234,16 @@ extern "C" int nf_project_gather_fwd(const float* xyz, int64_t n_pts, const floa
 // ---------------------------------------------------------------------------------------------------------------
 // a3: backward of the feature gather (scatter-add).  ref: autograd of F.grid_sample at ibrnet/projection.py:120-121
 // ---------------------------------------------------------------------------------------------------------------
+#define NF_SUB_BWD 32   // lanes per (point, view) in the scatter: lane = channel => 128 contiguous bytes per tap (C = 32)
+
 __global__ void __launch_bounds__(256) k_project_gather_bwd(const float* __restrict__ xyz, int64_t n_pts,
                                                             const float* __restrict__ cam_ws, int V, int H, int W,
                                                             const float* __restrict__ d_rgb_feat, int C, int Hf, int Wf,
                                                             int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
                                                             float* __restrict__ d_featmap) {
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t pv = gid / NF_SUB;
-    int sub = (int)(gid - pv * NF_SUB);
+    int64_t pv = gid / NF_SUB_BWD;
+    int sub = (int)(gid - pv * NF_SUB_BWD);
     if (pv >= n_pts * V) return;
     int64_t n = pv / V;
     int v = (int)(pv - n * V);
@@ -254,20 +256,13 @@ __global__ void __launch_bounds__(256) k_project_gather_bwd(const float* __restr
     if (!(tf.in[0] || tf.in[1] || tf.in[2] || tf.in[3])) return;
     const float* g = d_rgb_feat + pv * (int64_t)(3 + C) + 3;
     float* fbase = d_featmap + (int64_t)v * fs_v;
-    // channel-quad per lane: with a channels-last map the 8 lanes of a pair add to one 128-byte record per tap
-    for (int c0 = sub * 4; c0 < C; c0 += NF_SUB * 4) {
+    for (int c = sub; c < C; c += NF_SUB_BWD) {
+        float gv = g[c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int c = c0 + j;
-            if (c >= C) break;
-            float gv = g[c];
-            if (gv == 0.f) continue;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (tf.in[t]) {
-                    int xx = tf.x0 + (t & 1), yy = tf.y0 + (t >> 1);
-                    atomicAdd(fbase + (int64_t)c * fs_c + (int64_t)yy * fs_h + (int64_t)xx * fs_w, gv * tf.w[t]);
-                }
+        for (int t = 0; t < 4; ++t) {
+            if (tf.in[t]) {
+                int xx = tf.x0 + (t & 1), yy = tf.y0 + (t >> 1);
+                atomicAdd(fbase + (int64_t)c * fs_c + (int64_t)yy * fs_h + (int64_t)xx * fs_w, gv * tf.w[t]);
             }
         }
     }
@@ -278,7 +273,7 @@ extern "C" int nf_project_gather_bwd(const float* xyz, int64_t n_pts, const floa
                                      int64_t fs_h, int64_t fs_w, float* d_featmap, nf_stream_t stream) {
     NF_REQUIRE(n_pts >= 0 && n_views >= 1 && C >= 1 && Hf >= 1 && Wf >= 1, "nf_project_gather_bwd: bad sizes");
     if (n_pts == 0) return 0;
-    int64_t threads = n_pts * n_views * NF_SUB;
+    int64_t threads = n_pts * n_views * NF_SUB_BWD;
     hipLaunchKernelGGL(k_project_gather_bwd, dim3(nf_blocks(threads, 256)), dim3(256), 0, (hipStream_t)stream, xyz, n_pts,
                        cam_ws, n_views, H, W, d_rgb_feat, C, Hf, Wf, fs_v, fs_c, fs_h, fs_w, d_featmap);
     NF_LAUNCH_CHECK("nf_project_gather_bwd");

@@ -112,6 +112,7 @@ static inline float atomicAdd(float* addr, float val) {
     }
 }
 
+#define __expf(x) expf(x)   // v_exp_f32-based fast exp on the device
 using std::max;
 using std::min;
 
