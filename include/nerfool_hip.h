@@ -131,6 +131,10 @@ int nf_composite_bwd(const float* raw, const float* z_vals, int64_t n_rays, int 
  * ---------------------------------------------------------------------------------------------------------------- */
 int nf_sample_fine(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance,
                    int inv_uniform, const float* u_rand, float* z_out, nf_stream_t stream);
+/* sample_pdf alone (ibrnet/render_ray.py:24-70): bins [R,M+1], weights [R,M] (1e-5 is added inside, as the reference
+ * does), u_rand nullable [R,N] -> samples [R,N] */
+int nf_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int n_bins, int n_samples,
+                  const float* u_rand, float* samples, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a8  Criterion / img2mse (masked)         ref: ibrnet/criterion.py:23-33, utils.py:48-58

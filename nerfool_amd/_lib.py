@@ -42,6 +42,7 @@ _PROTOTYPES = {
     'nf_composite_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'nf_composite_bwd': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'nf_sample_fine': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_sample_pdf': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),
     'nf_masked_mse_fwd': (c_int, [_P, _P, _P, c_int64, _P, _P, _P]),
     'nf_masked_mse_bwd': (c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P]),
     'nf_project_perturb': (c_int, [_P, _P, c_int64, c_float, c_float, c_float, _P]),

@@ -189,18 +189,17 @@ __global__ void __launch_bounds__(256) k_sample_fine(const float* __restrict__ z
         loc += wgt[1 + src] + 1e-5f;
     }
     float total = nf_wave_sum(loc);
-    float incl = loc;
-#pragma unroll
-    for (int d = 1; d < NF_WAVE; d <<= 1) {
-        float o = __shfl_up(incl, d, NF_WAVE);
-        if (lane >= d) incl += o;
-    }
-    float run = incl - loc;                               // sum of q over earlier lanes
-    if (lane == 0) cdf[0] = 0.f;
-    for (int i = i0; i < i1; ++i) {
-        int src = inv_uniform ? (M - 1 - i) : i;
-        run += wgt[1 + src] + 1e-5f;
-        cdf[i + 1] = run / total;
+    // cdf = cumsum(q / total): torch's CPU cumsum is a sequential scan with a double accumulator rounded to float per
+    // element; one lane reproduces exactly that (M <= ~1000 adds, negligible) so that edge samples (u = 1 lands on the
+    // last, possibly tiny, bin) agree with the reference instead of differing by the rounding of a parallel scan
+    if (lane == 0) {
+        double run = 0.0;
+        cdf[0] = 0.f;
+        for (int i = 0; i < M; ++i) {
+            int src = inv_uniform ? (M - 1 - i) : i;
+            run += (double)((wgt[1 + src] + 1e-5f) / total);
+            cdf[i + 1] = (float)run;
+        }
     }
     for (int i = lane; i <= M; i += NF_WAVE) {
         if (inv_uniform) {
@@ -253,6 +252,62 @@ extern "C" int nf_sample_fine(const float* z_vals, const float* weights, int64_t
     hipLaunchKernelGGL(k_sample_fine, dim3(nf_blocks(n_rays, NF_RAYS_PER_BLOCK)), dim3(256), smem, (hipStream_t)stream,
                        z_vals, weights, n_rays, n_samples, n_importance, inv_uniform, u_rand, z_out);
     NF_LAUNCH_CHECK("nf_sample_fine");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sample_pdf as a stand-alone entry point (ibrnet/render_ray.py:24-70): bins [R,M+1], weights [R,M] -> samples [R,N].
+// Same wave-per-ray scheme as k_sample_fine without the flips / reciprocals / union.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bins, const float* __restrict__ weights,
+                                                    int64_t n_rays, int M, int N, const float* __restrict__ u_rand,
+                                                    float* __restrict__ out) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    int lane = threadIdx.x & (NF_WAVE - 1);
+    int wave = threadIdx.x >> 6;
+    int64_t r = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wave;
+    bool live = r < n_rays;
+    int64_t rr = live ? r : 0;
+    float* cdf = smem + (size_t)wave * (M + 1);
+    const float* wgt = weights + rr * M;
+    const float* b = bins + rr * (M + 1);
+    int K = (M + NF_WAVE - 1) / NF_WAVE;
+    int i0 = min(lane * K, M), i1 = min(i0 + K, M);
+    float loc = 0.f;
+    for (int i = i0; i < i1; ++i) loc += wgt[i] + 1e-5f;
+    float total = nf_wave_sum(loc);
+    if (lane == 0) {      // sequential double-accumulator scan, as torch.cumsum on the CPU (see k_sample_fine)
+        double run = 0.0;
+        cdf[0] = 0.f;
+        for (int i = 0; i < M; ++i) {
+            run += (double)((wgt[i] + 1e-5f) / total);
+            cdf[i + 1] = (float)run;
+        }
+    }
+    __syncthreads();
+    for (int k = lane; k < N; k += NF_WAVE) {
+        float u = u_rand ? u_rand[rr * N + k] : (N > 1 ? (float)k / (float)(N - 1) : 0.f);
+        if (!u_rand && k == N - 1 && N > 1) u = 1.f;
+        int above = 0;
+        for (int i = 0; i < M; ++i) above += (u >= cdf[i]) ? 1 : 0;
+        int below = max(above - 1, 0);
+        float c0 = cdf[below], c1 = cdf[above];
+        float den = c1 - c0;
+        den = den < 1e-5f ? 1.f : den;
+        float t = (u - c0) / den;
+        if (live) out[r * N + k] = b[below] + t * (b[above] - b[below]);
+    }
+}
+
+extern "C" int nf_sample_pdf(const float* bins, const float* weights, int64_t n_rays, int n_bins, int n_samples,
+                             const float* u_rand, float* samples, nf_stream_t stream) {
+    NF_REQUIRE(n_rays >= 0 && n_bins >= 1 && n_samples >= 1, "nf_sample_pdf: bad sizes");
+    size_t smem = (size_t)NF_RAYS_PER_BLOCK * (n_bins + 1) * sizeof(float);
+    NF_REQUIRE(smem <= 64 * 1024, "nf_sample_pdf: %d bins exceed the LDS staging budget", n_bins);
+    if (n_rays == 0) return 0;
+    hipLaunchKernelGGL(k_sample_pdf, dim3(nf_blocks(n_rays, NF_RAYS_PER_BLOCK)), dim3(256), smem, (hipStream_t)stream, bins,
+                       weights, n_rays, n_bins, n_samples, u_rand, samples);
+    NF_LAUNCH_CHECK("nf_sample_pdf");
     return 0;
 }
 

@@ -6,7 +6,7 @@ from collections import OrderedDict
 
 import torch
 
-from .render_ray import render_rays
+from .render_ray import render_rays, render_rays_hybrid
 
 _WHOLE = ('camera', 'depth_range', 'src_rgbs', 'src_cameras')
 
@@ -14,8 +14,9 @@ _WHOLE = ('camera', 'depth_range', 'src_rgbs', 'src_cameras')
 def render_single_image(ray_sampler, ray_batch, model, projector, chunk_size, N_samples, inv_uniform=False,
                         N_importance=0, det=False, white_bkgd=False, render_stride=1, featmaps=None, args=None,
                         featmaps_clean=None, src_ray_batch=None):
-    if args is not None and (getattr(args, 'use_clean_color', False) or getattr(args, 'use_clean_density', False)):
-        raise NotImplementedError('render_rays_hybrid (clean colour / clean density ablation) is not built yet')
+    hybrid = args is not None and (getattr(args, 'use_clean_color', False) or getattr(args, 'use_clean_density', False))
+    if hybrid:
+        assert featmaps_clean is not None
     parts = {'outputs_coarse': OrderedDict(), 'outputs_fine': OrderedDict()}
     n_rays = ray_batch['ray_o'].shape[0]
     with torch.no_grad():
@@ -23,9 +24,14 @@ def render_single_image(ray_sampler, ray_batch, model, projector, chunk_size, N_
             chunk = OrderedDict()
             for k, v in ray_batch.items():
                 chunk[k] = v if (k in _WHOLE or v is None) else v[i:i + chunk_size]
-            ret = render_rays(chunk, model, featmaps, projector=projector, N_samples=N_samples, inv_uniform=inv_uniform,
-                              N_importance=N_importance, det=det, white_bkgd=white_bkgd, args=args,
-                              src_ray_batch=src_ray_batch)
+            if hybrid:
+                ret = render_rays_hybrid(chunk, model, featmaps, projector=projector, N_samples=N_samples,
+                                         inv_uniform=inv_uniform, N_importance=N_importance, det=det, white_bkgd=white_bkgd,
+                                         args=args, src_ray_batch=src_ray_batch, featmaps_clean=featmaps_clean)
+            else:
+                ret = render_rays(chunk, model, featmaps, projector=projector, N_samples=N_samples,
+                                  inv_uniform=inv_uniform, N_importance=N_importance, det=det, white_bkgd=white_bkgd,
+                                  args=args, src_ray_batch=src_ray_batch)
             for level in ('outputs_coarse', 'outputs_fine'):
                 if ret[level] is None:
                     parts[level] = None

@@ -16,6 +16,13 @@ def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=Fa
     return ops.sample_along_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform, t_rand)
 
 
+def sample_pdf(bins, weights, N_samples, det=False):
+    """ref: ibrnet/render_ray.py:24-70.  bins [N_rays, M+1], weights [N_rays, M] -> [N_rays, N_samples].  Unlike the
+    reference the caller's `weights` tensor is not modified in place (the 1e-5 is added inside the kernel)."""
+    u = None if det else torch.rand(bins.shape[0], N_samples, dtype=torch.float32, device=bins.device)
+    return ops.sample_pdf(bins.detach(), weights.detach(), N_samples, u)
+
+
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, z_vals, pixel_mask, white_bkgd):
@@ -79,4 +86,37 @@ def render_rays(ray_batch, model, featmaps, projector, N_samples, inv_uniform=Fa
         pts = ops.points_from_depths(ray_batch['ray_o'], ray_batch['ray_d'], z_vals)
         ret['outputs_fine'] = _level(pts, z_vals, ray_batch, src, model.net_fine, featmaps[1], projector, white_bkgd,
                                      geo_noise)
+    return ret
+
+
+def render_rays_hybrid(ray_batch, model, featmaps, projector, N_samples, inv_uniform=False, N_importance=0, det=False,
+                       white_bkgd=False, args=None, src_ray_batch=None, featmaps_clean=None):
+    """Clean-colour / clean-density ablation (ibrnet/render_ray.py:261-389): every level is evaluated twice, on the
+    attacked and on the clean feature maps, and the composited `raw` takes colour and density from the source selected
+    by args.use_clean_color / args.use_clean_density.  The sample mask comes from the attacked pass (identical geometry)."""
+    src = ray_batch if src_ray_batch is None else src_ray_batch
+    assert featmaps_clean is not None
+
+    def level(pts, z_vals, net, fm_adv, fm_clean):
+        rgb_feat, ray_diff, mask = projector.compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'],
+                                                     featmaps=fm_adv)
+        pixel_mask = ops.pixel_mask(mask[..., 0])
+        raw_adv = net(rgb_feat, ray_diff, mask)
+        rgb_feat_c, ray_diff_c, mask_c = projector.compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'],
+                                                           featmaps=fm_clean)
+        raw_clean = net(rgb_feat_c, ray_diff_c, mask_c)
+        colour = raw_clean if args.use_clean_color else raw_adv
+        density = raw_clean if args.use_clean_density else raw_adv
+        raw = torch.cat([colour[:, :, :3], density[:, :, 3:4]], dim=2)       # channel select, no arithmetic
+        return raw2outputs(raw, z_vals, pixel_mask, white_bkgd=white_bkgd)
+
+    ret = {'outputs_coarse': None, 'outputs_fine': None}
+    pts, z_vals = sample_along_camera_ray(ray_batch['ray_o'], ray_batch['ray_d'], ray_batch['depth_range'], N_samples,
+                                          inv_uniform=inv_uniform, det=det)
+    ret['outputs_coarse'] = level(pts, z_vals, model.net_coarse, featmaps[0], featmaps_clean[0])
+    if N_importance > 0:
+        assert model.net_fine is not None
+        z_vals = sample_fine_depths(z_vals, ret['outputs_coarse']['weights'], N_importance, inv_uniform, det)
+        pts = ops.points_from_depths(ray_batch['ray_o'], ray_batch['ray_d'], z_vals)
+        ret['outputs_fine'] = level(pts, z_vals, model.net_fine, featmaps[1], featmaps_clean[1])
     return ret

@@ -253,6 +253,19 @@ def sample_fine(z_vals, weights, n_importance, inv_uniform, u_rand=None):
     return out
 
 
+def sample_pdf(bins, weights, n_samples, u_rand=None):
+    bins, weights = _c(bins, 'bins'), _c(weights, 'weights')
+    R, M = weights.shape
+    if bins.shape != (R, M + 1):
+        raise ValueError('bins must be [N_rays, M+1] for weights [N_rays, M]')
+    out = torch.empty(R, n_samples, dtype=torch.float32, device=bins.device)
+    if u_rand is not None:
+        u_rand = _c(u_rand, 'u_rand')
+    _lib.check(_lib.lib().nf_sample_pdf(_ptr(bins), _ptr(weights), R, M, n_samples, _ptr(u_rand), _ptr(out), _stream(out)),
+               'nf_sample_pdf')
+    return out
+
+
 def masked_mse_fwd(rgb, gt, mask_b=None, cnt_override=None):
     rgb, gt = _c(rgb, 'rgb'), _c(gt, 'gt')
     R = rgb.shape[0]

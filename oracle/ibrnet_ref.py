@@ -336,6 +336,34 @@ def render_rays(ray_batch, params_coarse, params_fine, featmaps, N_samples, inv_
     return ret
 
 
+def render_rays_hybrid(ray_batch, params_coarse, params_fine, featmaps, featmaps_clean, N_samples, use_clean_color,
+                       use_clean_density, inv_uniform=False, N_importance=0, det=False, white_bkgd=False,
+                       src_ray_batch=None, anti_alias_pooling=True):
+    """ref: ibrnet/render_ray.py:261-389 -- each level evaluated on attacked and on clean feature maps, colour and
+    density picked per flag, sample mask of the attacked pass."""
+    src = ray_batch if src_ray_batch is None else src_ray_batch
+
+    def level(pts, z_vals, params, fm_adv, fm_clean):
+        outs = []
+        for fm in (fm_adv, fm_clean):
+            rgb_feat, ray_diff, mask = projector_compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'], fm)
+            outs.append((ibrnet_forward(params, rgb_feat, ray_diff, mask, anti_alias_pooling), mask))
+        (raw_adv, mask_adv), (raw_clean, _) = outs
+        colour = (raw_clean if use_clean_color else raw_adv)[:, :, :3]
+        sigma = (raw_clean if use_clean_density else raw_adv)[:, :, 3:4]
+        return raw2outputs(torch.cat([colour, sigma], dim=2), z_vals, mask_adv[..., 0].sum(dim=2) > 1, white_bkgd)
+
+    ret = {'outputs_coarse': None, 'outputs_fine': None}
+    pts, z_vals = sample_along_camera_ray(ray_batch['ray_o'], ray_batch['ray_d'], ray_batch['depth_range'], N_samples,
+                                          inv_uniform=inv_uniform, det=det)
+    ret['outputs_coarse'] = level(pts, z_vals, params_coarse, featmaps[0], featmaps_clean[0])
+    if N_importance > 0:
+        z_vals = fine_depths(z_vals, ret['outputs_coarse']['weights'], N_importance, inv_uniform, det)
+        pts = z_vals[:, :, None] * ray_batch['ray_d'][:, None, :] + ray_batch['ray_o'][:, None, :]
+        ret['outputs_fine'] = level(pts, z_vals, params_fine, featmaps[1], featmaps_clean[1])
+    return ret
+
+
 # --------------------------------------------------------------------------------------------------
 # a8  masked MSE                                        ref: utils.py:48-58, ibrnet/criterion.py:23-33
 # --------------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ from ibrnet.feature_network import ResUNet  # noqa: E402
 from ibrnet.mlp_network import IBRNet  # noqa: E402
 from ibrnet.projection import Projector  # noqa: E402
 from ibrnet.render_image import render_single_image  # noqa: E402
-from ibrnet.render_ray import render_rays, sample_along_camera_ray  # noqa: E402
+from ibrnet.render_ray import render_rays, render_rays_hybrid, sample_along_camera_ray, sample_pdf  # noqa: E402
 import ibrnet.sample_ray as ref_sample_ray  # noqa: E402
 
 from nerfool_amd.synthetic import make_scene, smooth_featmaps  # noqa: E402
@@ -260,12 +260,48 @@ def attack_case(name, H, W, V, R, S, N_imp, seed, n_adam=10, n_sign=3):
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
 
 
+def hybrid_case(name, base):
+    """render_rays_hybrid (clean colour / clean density) of the reference on the inputs of stage case `base`; the clean
+    feature maps are smooth_featmaps(seed 50 / 51) and are regenerated, not stored.  Also a stand-alone sample_pdf."""
+    z = np.load(os.path.join(HERE, base + '.npz'))
+    H, W, V, R, S, N_imp, inv_u, white, aa, Hf, Wf = [int(x) for x in z['cfg']]
+    t = lambda k: torch.from_numpy(z[k])
+    pc = {k[7:]: t(k) for k in z.files if k.startswith('coarse/') and ('.' in k or k in ('coarse/s', 'coarse/pos_encoding'))}
+    pf = {k[5:]: t(k) for k in z.files if k.startswith('fine/') and ('.' in k or k in ('fine/s', 'fine/pos_encoding'))}
+    model = SimpleNamespace(net_coarse=ref_net(pc, S, aa), net_fine=ref_net(pf, S + N_imp, aa))
+    batch = {'ray_o': t('in/ray_o'), 'ray_d': t('in/ray_d'), 'rgb': t('in/gt_rgb'), 'camera': t('in/camera'),
+             'depth_range': t('in/depth_range'), 'src_rgbs': t('in/src_rgbs'), 'src_cameras': t('in/src_cameras')}
+    fm = (t('in/featmap_coarse'), t('in/featmap_fine'))
+    fm_clean = (smooth_featmaps(V, 32, Hf, Wf, seed=50), smooth_featmaps(V, 32, Hf, Wf, seed=51))
+    out = {'cfg': z['cfg'], 'base': np.array(base)}
+    for tag, cc, cd in (('clean_color', True, False), ('clean_density', False, True)):
+        args = SimpleNamespace(use_clean_color=cc, use_clean_density=cd)
+        with torch.no_grad():
+            ret = render_rays_hybrid(batch, model, fm, Projector(device='cpu'), S, inv_uniform=bool(inv_u),
+                                     N_importance=N_imp, det=True, white_bkgd=bool(white), args=args,
+                                     featmaps_clean=fm_clean)
+        for level in ('outputs_coarse', 'outputs_fine'):
+            for k in ('rgb', 'depth', 'weights', 'z_vals'):
+                out['%s/%s/%s' % (tag, level, k)] = npy(ret[level][k])
+    gen = torch.Generator().manual_seed(9)
+    bins = torch.sort(torch.rand(12, 21, generator=gen) * 4 + 2, dim=1)[0]
+    w = torch.rand(12, 20, generator=gen) ** 3
+    w[3] = 0                                     # an all-zero row: uniform pdf from the +1e-5
+    out['pdf/bins'] = npy(bins)
+    out['pdf/weights'] = npy(w)
+    out['pdf/samples_17'] = npy(sample_pdf(bins.clone(), w.clone(), 17, det=True))
+    out['pdf/samples_64'] = npy(sample_pdf(bins.clone(), w.clone(), 64, det=True))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('%-28s written' % name)
+
+
 if __name__ == '__main__':
     stage_case('ibrnet_tiny_invu', 40, 56, 4, 24, 16, 16, True, False, seed=0, tilt=0.45)
     stage_case('ibrnet_tiny_lin_white', 40, 56, 3, 24, 12, 10, False, True, seed=1, tilt=0.25, push_forward=2.5)
     stage_case('ibrnet_tiny_noaa_v5', 32, 48, 5, 16, 16, 0, True, False, seed=2, aa=0, tilt=0.4)
     stage_case('ibrnet_medium', 96, 128, 4, 256, 64, 64, True, False, seed=3, tilt=0.35, store_stages=False)
     attack_case('attack_tiny', 48, 64, 4, 64, 8, 8, seed=4)
+    hybrid_case('hybrid_and_pdf', 'ibrnet_tiny_invu')
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print('%-32s %8.1f KB' % (f, os.path.getsize(os.path.join(HERE, f)) / 1024.))

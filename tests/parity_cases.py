@@ -13,7 +13,8 @@ from nerfool_amd.ibrnet.feature_network import ResUNet
 from nerfool_amd.ibrnet.mlp_network import IBRNet
 from nerfool_amd.ibrnet.projection import Projector
 from nerfool_amd.ibrnet.render_image import render_single_image
-from nerfool_amd.ibrnet.render_ray import raw2outputs, render_rays, sample_along_camera_ray, sample_fine_depths
+from nerfool_amd.ibrnet.render_ray import (raw2outputs, render_rays, render_rays_hybrid, sample_along_camera_ray,
+                                           sample_fine_depths, sample_pdf)
 from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
 from nerfool_amd.ibrnet import sample_ray as product_sample_ray
 from oracle import attack_ref as atk
@@ -291,3 +292,32 @@ def check_render_single_image(dev, rows=None):
     if rows is None:
         mse = float(torch.mean((ret['outputs_fine']['rgb'] - g.t('in/rgb')[0]) ** 2))
         assert abs(ib.mse2psnr(mse) - float(g.np('image/psnr_fine'))) < 1e-2, 'PSNR'
+
+
+def check_hybrid_and_sample_pdf(dev):
+    """render_rays_hybrid (clean colour / clean density) and the stand-alone sample_pdf against the reference."""
+    from nerfool_amd.synthetic import smooth_featmaps
+    h = Golden('hybrid_and_pdf')
+    g = Golden(str(h.np('base')))
+    cfg = g.stage_cfg()
+    model = make_model(g, cfg, dev)
+    fm = (g.t('in/featmap_coarse', dev), g.t('in/featmap_fine', dev))
+    fm_clean = (smooth_featmaps(cfg['V'], 32, cfg['Hf'], cfg['Wf'], seed=50).to(dev),
+                smooth_featmaps(cfg['V'], 32, cfg['Hf'], cfg['Wf'], seed=51).to(dev))
+    for tag in ('clean_color', 'clean_density'):
+        args = SimpleNamespace(use_clean_color=tag == 'clean_color', use_clean_density=tag == 'clean_density')
+        with torch.no_grad():
+            ret = render_rays_hybrid(g.ray_batch(dev), model, fm, Projector(dev), cfg['S'], inv_uniform=cfg['inv_uniform'],
+                                     N_importance=cfg['N_importance'], det=True, white_bkgd=cfg['white_bkgd'], args=args,
+                                     featmaps_clean=fm_clean)
+        for level in ('outputs_coarse', 'outputs_fine'):
+            assert_close(ret[level]['rgb'], h.np('%s/%s/rgb' % (tag, level)), 1e-3, 1e-3, '%s %s rgb' % (tag, level))
+            assert_close(ret[level]['depth'], h.np('%s/%s/depth' % (tag, level)), 1e-3, 2e-3, '%s %s depth' % (tag, level))
+            assert_close(ret[level]['weights'], h.np('%s/%s/weights' % (tag, level)), 2e-3, 5e-4,
+                         '%s %s weights' % (tag, level), frac_ok=2e-3)
+    for n in (17, 64):
+        got = sample_pdf(h.t('pdf/bins', dev), h.t('pdf/weights', dev), n, det=True)
+        # the u = 1 sample sits on the edge of the last bin, where t = (1 - cdf[M-1]) / (cdf[M] - cdf[M-1]) amplifies
+        # the 1-ulp difference between two roundings of sum(weights): 1e-4 relative there, 1e-5 elsewhere
+        assert_close(got[:, :-1], h.np('pdf/samples_%d' % n)[:, :-1], 1e-5, 2e-5, 'sample_pdf %d' % n)
+        assert_close(got[:, -1], h.np('pdf/samples_%d' % n)[:, -1], 1e-4, 2e-5, 'sample_pdf %d (u = 1)' % n)

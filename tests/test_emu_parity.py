@@ -66,6 +66,10 @@ def test_attack_steps():
     pc.check_attack_steps('cpu', free_steps=2)
 
 
+def test_hybrid_and_sample_pdf():
+    pc.check_hybrid_and_sample_pdf('cpu')
+
+
 def test_render_single_image():
     pc.check_render_single_image('cpu', rows=4)
 

@@ -57,6 +57,10 @@ def test_attack_steps():
     pc.check_attack_steps('cuda')
 
 
+def test_hybrid_and_sample_pdf():
+    pc.check_hybrid_and_sample_pdf('cuda')
+
+
 def test_render_single_image():
     pc.check_render_single_image('cuda')
 

@@ -187,3 +187,34 @@ def test_render_single_image_matches_reference():
         assert_close(ret[level]['depth'], g.np('image/%s/depth' % level), 1e-3, 1e-4, level + ' image depth', frac_ok=2e-3)
     mse = float(torch.mean((ret['outputs_fine']['rgb'] - g.t('in/rgb')[0]) ** 2))
     assert abs(ib.mse2psnr(mse) - float(g.np('image/psnr_fine'))) < 1e-3
+
+
+def _hybrid_inputs(device='cpu'):
+    from nerfool_amd.synthetic import smooth_featmaps
+    h = Golden('hybrid_and_pdf')
+    g = Golden(str(h.np('base')))
+    cfg = g.stage_cfg()
+    fm = (g.t('in/featmap_coarse', device), g.t('in/featmap_fine', device))
+    fm_clean = (smooth_featmaps(cfg['V'], 32, cfg['Hf'], cfg['Wf'], seed=50).to(device),
+                smooth_featmaps(cfg['V'], 32, cfg['Hf'], cfg['Wf'], seed=51).to(device))
+    return h, g, cfg, fm, fm_clean
+
+
+@pytest.mark.parametrize('tag', ['clean_color', 'clean_density'])
+def test_render_rays_hybrid_matches_reference(tag):
+    h, g, cfg, fm, fm_clean = _hybrid_inputs()
+    with torch.no_grad():
+        ret = ib.render_rays_hybrid(g.ray_batch(), g.params('coarse'), g.params('fine'), fm, fm_clean, cfg['S'],
+                                    tag == 'clean_color', tag == 'clean_density', inv_uniform=cfg['inv_uniform'],
+                                    N_importance=cfg['N_importance'], det=True, white_bkgd=cfg['white_bkgd'])
+    for level in ('outputs_coarse', 'outputs_fine'):
+        for k in ('rgb', 'depth', 'weights', 'z_vals'):
+            assert_close(ret[level][k], h.np('%s/%s/%s' % (tag, level, k)), 1e-3, 2e-4, '%s %s %s' % (tag, level, k),
+                         frac_ok=1e-3 if k == 'weights' else 0.0)
+
+
+def test_sample_pdf_matches_reference():
+    h = Golden('hybrid_and_pdf')
+    for n in (17, 64):
+        got = ib.sample_pdf(h.t('pdf/bins'), h.t('pdf/weights'), n, det=True)
+        assert_close(got, h.np('pdf/samples_%d' % n), 1e-5, 1e-5, 'sample_pdf %d' % n)
