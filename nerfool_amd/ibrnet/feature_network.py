@@ -5,9 +5,17 @@ out_conv) so that reference checkpoints load by key.
 
 The output is produced channels-last ([V, Hf, Wf, 64] in memory): each feature-map pixel is one 256-byte record whose
 halves are the coarse / fine 32-channel maps, which is what the gather kernels want (one cache line per bilinear tap)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import ops
+
+# 'fused' (default): MIOpen convolutions with padding 0 + the hand-written InstanceNorm/activation/reflect-pad kernels of
+# csrc/nf_cnn.hip in between, explicit backward-data only;  'torch': the plain nn.Module graph (ATen + MIOpen + autograd)
+CNN_PATH = os.environ.get('NERFOOL_CNN', 'fused')
 
 
 def _c3(cin, cout, stride=1):
@@ -86,6 +94,10 @@ class ResUNet(nn.Module):
         self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
 
     def forward(self, x):
+        frozen = not any(p.requires_grad for p in self.parameters())
+        if CNN_PATH == 'fused' and frozen and not self.coarse_only and (x.is_cuda or ops._lib.emulated()):
+            out = _FusedResUNet.apply(x, self)
+            return out[:, :self.coarse_out_ch], out[:, -self.fine_out_ch:]
         x = F.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
@@ -96,3 +108,160 @@ class ResUNet(nn.Module):
         if self.coarse_only:
             return out, None
         return out[:, :self.coarse_out_ch], out[:, -self.fine_out_ch:]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Fused executor: same network, same parameters, explicit forward tape + backward-data pass.
+# Per convolution the module graph launches reflection_pad2d, conv, batch_norm (instance norm), add, relu (and their five
+# backward kernels); here it is conv (padding 0, MIOpen) + ONE fused kernel per direction (csrc/nf_cnn.hip).
+# Convolution biases in front of an InstanceNorm are dropped: the norm subtracts the plane mean, so they cancel exactly.
+# ----------------------------------------------------------------------------------------------------------------------
+_aten = torch.ops.aten
+
+
+class _Slot:
+    """a plain tensor with a gradient accumulator"""
+    __slots__ = ('v', 'g')
+
+    def __init__(self, v):
+        self.v, self.g = v, None
+
+    def add(self, g):
+        self.g = g if self.g is None else self.g + g
+
+
+class _Act:
+    """an activation written by the fused kernel: padded storage, gradient w.r.t. the padded tensor (from the next
+    convolution) and w.r.t. its interior (residual / skip / upsample consumers)"""
+    __slots__ = ('yp', 'pad', 'gp', 'gi')
+
+    def __init__(self, yp, pad):
+        self.yp, self.pad, self.gp, self.gi = yp, pad, None, None
+
+    def interior(self):
+        p = self.pad
+        return self.yp if p == 0 else self.yp[:, :, p:-p, p:-p]
+
+    def add_p(self, g):
+        self.gp = g if self.gp is None else self.gp + g
+
+    def add_i(self, g):
+        self.gi = g if self.gi is None else self.gi + g
+
+
+def _conv(tape, inp, w, stride, sink, bias=None):
+    out = _Slot(_aten.convolution(inp, w, bias, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1))
+
+    def bwd():
+        g = _aten.convolution_backward(out.g, inp, w, None, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1,
+                                       [True, False, False])[0]
+        sink(g)
+        out.g = None
+    tape.append(bwd)
+    return out
+
+
+def _fuse(tape, xs, norm, res, act, pad):
+    gamma, beta = (norm.weight, norm.bias) if norm is not None else (None, None)
+    yp, mean, rstd = ops.in_act_pad_fwd(xs.v, gamma, beta, None if res is None else res.interior(), act, pad,
+                                        eps=norm.eps if norm is not None else 0.0)
+    a = _Act(yp, pad)
+
+    def bwd():
+        dx, d_res = ops.in_act_pad_bwd(a.gp, a.gi, yp, xs.v if norm is not None else None, gamma, mean, rstd, act, pad,
+                                       res is not None)
+        xs.add(dx)
+        if res is not None:
+            res.add_i(d_res)
+        a.gp = a.gi = None
+    tape.append(bwd)
+    return a
+
+
+def _resblock(tape, blk, xin):
+    """xin: _Act padded by 1.  conv3x3(s) -> IN -> ReLU -> conv3x3 -> IN -> (+ identity | 1x1 conv + IN) -> ReLU."""
+    stride = blk.conv1.stride[0]
+    t1 = _conv(tape, xin.yp, blk.conv1.weight, stride, xin.add_p)
+    a1 = _fuse(tape, t1, blk.bn1, None, ops.ACT_RELU, 1)
+    t2 = _conv(tape, a1.yp, blk.conv2.weight, 1, a1.add_p)
+    if blk.downsample is not None:
+        d = _conv(tape, xin.interior(), blk.downsample[0].weight, stride, xin.add_i)
+        res = _fuse(tape, d, blk.downsample[1], None, ops.ACT_NONE, 0)
+    else:
+        res = xin
+    return _fuse(tape, t2, blk.bn2, res, ops.ACT_RELU, 1)
+
+
+def _upsample(tape, a):
+    src = a.interior()
+    out = _Slot(F.interpolate(src, scale_factor=2, mode='bilinear', align_corners=True))
+    in_size = list(src.shape)
+
+    def bwd():
+        a.add_i(_aten.upsample_bilinear2d_backward(out.g, list(out.v.shape[2:]), in_size, True, None, None))
+        out.g = None
+    tape.append(bwd)
+    return out
+
+
+def _join_tape(tape, enc, dec):
+    """cat([dec, zero-pad(enc)], dim=1) with the gradient split back (dec: _Act with pad 0, enc: _Act)."""
+    e, d = enc.interior(), dec.interior()
+    dy, dx = d.shape[2] - e.shape[2], d.shape[3] - e.shape[3]
+    top, left = dy // 2, dx // 2
+    out = _Slot(torch.cat([d, F.pad(e, (left, dx - left, top, dy - top))], dim=1))
+    cd, eh, ew = d.shape[1], e.shape[2], e.shape[3]
+
+    def bwd():
+        dec.add_i(out.g[:, :cd].contiguous())
+        enc.add_i(out.g[:, cd:, top:top + eh, left:left + ew].contiguous())
+        out.g = None
+    tape.append(bwd)
+    return out
+
+
+def fused_forward(net, x):
+    """x [V,3,H,W] -> (out [V,64,Hf,Wf] NCHW, tape, input slot)."""
+    tape = []
+    xin = _Slot(x.contiguous())
+    a = _fuse(tape, xin, None, None, ops.ACT_NONE, 3)
+    t = _conv(tape, a.yp, net.conv1.weight, 2, a.add_p)
+    a = _fuse(tape, t, net.bn1, None, ops.ACT_RELU, 1)
+    feats = []
+    for layer in (net.layer1, net.layer2, net.layer3):
+        for blk in layer:
+            a = _resblock(tape, blk, a)
+        feats.append(a)
+    x1, x2, x3 = feats
+
+    def decoder_stage(src, up, iconv, enc):
+        u = _upsample(tape, src)
+        up_p = _fuse(tape, u, None, None, ops.ACT_NONE, 1)
+        t = _conv(tape, up_p.yp, up.conv.conv.weight, 1, up_p.add_p)
+        dec = _fuse(tape, t, up.conv.bn, None, ops.ACT_ELU, 0)
+        j = _join_tape(tape, enc, dec)
+        jp = _fuse(tape, j, None, None, ops.ACT_NONE, 1)
+        t = _conv(tape, jp.yp, iconv.conv.weight, 1, jp.add_p)
+        return _fuse(tape, t, iconv.bn, None, ops.ACT_ELU, 0)
+
+    y = decoder_stage(x3, net.upconv3, net.iconv3, x2)
+    y = decoder_stage(y, net.upconv2, net.iconv2, x1)
+    out = _conv(tape, y.yp, net.out_conv.weight, 1, y.add_p, bias=net.out_conv.bias)
+    return out, tape, xin
+
+
+class _FusedResUNet(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net):
+        out, tape, xin = fused_forward(net, x)
+        ctx.tape, ctx.out, ctx.xin = tape, out, xin
+        return out.v.contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ctx.out.g = d_out.contiguous()           # NCHW for the convolution backward
+        for step in reversed(ctx.tape):
+            step()
+        g = ctx.xin.g
+        ctx.tape = ctx.out = ctx.xin = None
+        return g, None

@@ -326,3 +326,44 @@ def pgd_sign_step_(delta, grad, src, alpha, epsilon, lower=0.0, upper=1.0):
     _lib.check(_lib.lib().nf_pgd_sign_step(_ptr(delta), _ptr(grad), _ptr(src), delta.numel(), float(alpha), float(epsilon),
                                            float(lower), float(upper), _stream(delta)), 'nf_pgd_sign_step')
     return delta
+
+
+ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
+
+
+def in_act_pad_fwd(x, gamma, beta, res, act, pad, eps=1e-5):
+    """y_padded = reflect_pad(act(instance_norm(x) * gamma + beta + res), pad); res may be any strided [N,C,H,W] view."""
+    x = _c(x, 'x')
+    N, C, H, W = x.shape
+    yp = torch.empty(N, C, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=x.device)
+    mean = rstd = None
+    if gamma is not None:
+        mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(N * C, dtype=torch.float32, device=x.device)
+    rs = (0, 0, 0, 0)
+    if res is not None:
+        _f32(res, 'res')
+        if tuple(res.shape) != (N, C, H, W):
+            raise ValueError('residual shape %s does not match %s' % (tuple(res.shape), (N, C, H, W)))
+        rs = res.stride()
+    with prof.launch('nf_in_act_pad_fwd', x, n=x.numel()):
+        _lib.check(_lib.lib().nf_in_act_pad_fwd(_ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta), float(eps), _ptr(res), rs[0], rs[1],
+                                                rs[2], rs[3], int(act), int(pad), _ptr(yp), _ptr(mean), _ptr(rstd), _stream(x)),
+                   'nf_in_act_pad_fwd')
+    return yp, mean, rstd
+
+
+def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res):
+    N, C, Hp, Wp = yp.shape
+    H, W = Hp - 2 * pad, Wp - 2 * pad
+    if dyp is not None:
+        dyp = _c(dyp, 'dy_padded')
+    if d_extra is not None:
+        d_extra = _c(d_extra, 'd_extra')
+    dx = torch.empty(N, C, H, W, dtype=torch.float32, device=yp.device)
+    d_res = torch.empty_like(dx) if want_d_res else None
+    with prof.launch('nf_in_act_pad_bwd', yp, n=dx.numel()):
+        _lib.check(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(mean),
+                                                _ptr(rstd), int(act), int(pad), _ptr(d_res), _ptr(dx), _stream(yp)),
+                   'nf_in_act_pad_bwd')
+    return dx, d_res

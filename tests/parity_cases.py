@@ -321,3 +321,69 @@ def check_hybrid_and_sample_pdf(dev):
         # the 1-ulp difference between two roundings of sum(weights): 1e-4 relative there, 1e-5 elsewhere
         assert_close(got[:, :-1], h.np('pdf/samples_%d' % n)[:, :-1], 1e-5, 2e-5, 'sample_pdf %d' % n)
         assert_close(got[:, -1], h.np('pdf/samples_%d' % n)[:, -1], 1e-4, 2e-5, 'sample_pdf %d (u = 1)' % n)
+
+
+def check_fused_cnn_glue(dev):
+    """One fused InstanceNorm + affine + residual + activation + reflect-pad op (and its backward) against the same thing
+    composed from torch ops with autograd."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(3)
+    for (N, C, H, W, pad, act, use_norm, use_res) in ((2, 5, 9, 11, 1, ops.ACT_RELU, True, True), (1, 3, 8, 6, 3, ops.ACT_NONE, False, False),
+                                                      (2, 4, 7, 10, 0, ops.ACT_ELU, True, False), (1, 6, 12, 9, 1, ops.ACT_NONE, True, True)):
+        x = torch.randn(N, C, H, W, generator=gen)
+        gamma = (1 + 0.3 * torch.randn(C, generator=gen)) if use_norm else None
+        beta = 0.2 * torch.randn(C, generator=gen) if use_norm else None
+        res_store = torch.randn(N, C, H + 2, W + 2, generator=gen)
+        res = res_store[:, :, 1:-1, 1:-1] if use_res else None           # a strided view, like a padded activation
+        dyp = torch.randn(N, C, H + 2 * pad, W + 2 * pad, generator=gen)
+        dex = torch.randn(N, C, H, W, generator=gen)
+        xr = x.clone().requires_grad_(True)
+        rr = res.clone().requires_grad_(True) if use_res else None
+        t = F.instance_norm(xr, weight=gamma, bias=beta, eps=1e-5) if use_norm else xr
+        if use_res:
+            t = t + rr
+        t = F.relu(t) if act == ops.ACT_RELU else (F.elu(t) if act == ops.ACT_ELU else t)
+        ref_y = F.pad(t, (pad,) * 4, mode='reflect') if pad else t
+        grads = torch.autograd.grad([ref_y, t], [xr] + ([rr] if use_res else []), [dyp, dex])
+        dv = lambda z: None if z is None else z.to(dev)
+        yp, mean, rstd = ops.in_act_pad_fwd(x.to(dev), dv(gamma), dv(beta), None if res is None else res_store.to(dev)[:, :, 1:-1, 1:-1],
+                                            act, pad)
+        assert_close(yp, ref_y, 1e-4, 1e-5, 'fused glue forward')
+        dx, d_res = ops.in_act_pad_bwd(dyp.to(dev), dex.to(dev), yp, x.to(dev) if use_norm else None, dv(gamma), mean, rstd, act,
+                                       pad, use_res)
+        assert_close(dx, grads[0], 1e-3, 1e-4 * float(grads[0].abs().max()), 'fused glue d x')
+        if use_res:
+            assert_close(d_res, grads[1], 1e-4, 1e-5, 'fused glue d residual')
+
+
+def check_fused_resunet(dev, size=(96, 128)):
+    """The whole ResUNet through the fused executor vs the plain nn.Module graph (same parameters, same device)."""
+    from nerfool_amd.ibrnet import feature_network as fn
+    torch.manual_seed(0)
+    net = fn.ResUNet()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.InstanceNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    net = net.to(dev)
+    x = torch.rand(2, 3, *size, device=dev)
+    res = {}
+    saved = fn.CNN_PATH
+    try:
+        for path in ('torch', 'fused'):
+            fn.CNN_PATH = path
+            xi = x.clone().requires_grad_(True)
+            c, f = net(xi)
+            G = torch.randn(c.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+            g, = torch.autograd.grad((c * G).sum() + 0.5 * (f * G).sum(), xi)
+            res[path] = (c.detach(), f.detach(), g)
+    finally:
+        fn.CNN_PATH = saved
+    for i, name in enumerate(('coarse', 'fine', 'd input')):
+        a, b = res['torch'][i], res['fused'][i]
+        err = float((a - b).norm() / a.norm())
+        assert err < (5e-3 if i == 2 else 1e-4), 'fused ResUNet %s: relative L2 error %.3e' % (name, err)
+    assert res['fused'][0].stride(1) == 1, 'feature maps must come out channels-last'

@@ -52,7 +52,7 @@ def test_ray_sharded_step_equals_single_process(tmp_path):
     script.write_text(WORKER % dict(root=ROOT, harness=HARNESS, out=str(tmp_path)))
     # the shape-generic kernels emulate ~30x faster than the MFMA ones; the sharding logic under test is the same
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', OMP_NUM_THREADS='2',
-               NERFOOL_IBRNET_KERNELS='generic')
+               NERFOOL_IBRNET_KERNELS='generic', NERFOOL_CNN='torch')
     single = subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK='0', WORLD_SIZE='1'))
     assert single.wait() == 0
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE='2')) for r in range(2)]

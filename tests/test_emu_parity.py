@@ -26,8 +26,11 @@ def emulated_library():
     # emulating the matrix-core kernels costs ~30x the generic ones: the end-to-end cases below run on the generic
     # kernels, the MFMA kernels have their own (small) cases at the end of this file
     mlp_network.KERNEL_PATH = 'generic'
+    from nerfool_amd.ibrnet import feature_network
+    saved_cnn, feature_network.CNN_PATH = feature_network.CNN_PATH, 'torch'    # ditto for the fused CNN glue
     yield
     _lib._lib, _lib._emulated, mlp_network.KERNEL_PATH = saved
+    feature_network.CNN_PATH = saved_cnn
 
 
 @pytest.mark.parametrize('case', TINY)
@@ -56,6 +59,10 @@ def test_ray_sampler():
 
 def test_feature_net():
     pc.check_feature_net('cpu')
+
+
+def test_fused_cnn_glue():
+    pc.check_fused_cnn_glue('cpu')
 
 
 def test_init_perturb():

@@ -49,6 +49,14 @@ def test_feature_net():
     pc.check_feature_net('cuda')
 
 
+def test_fused_cnn_glue():
+    pc.check_fused_cnn_glue('cuda')
+
+
+def test_fused_resunet_matches_module_graph():
+    pc.check_fused_resunet('cuda')
+
+
 def test_init_perturb():
     pc.check_init_perturb('cuda')
 
