@@ -7,24 +7,32 @@
 //      :127-140 (conv + IN + ELU), :28-36 (padding_mode='reflect').  PyTorch runs this as 4-5 memory-bound kernels per
 //      convolution (reflection_pad2d, batch_norm x2 passes, add, relu) in each direction.
 //
-// One workgroup (1024 threads) per (image, channel) plane: plane statistics are block reductions, the data is re-read
-// from L2 / Infinity Cache for the later passes.
+// Two fully parallel launches per direction: plane statistics (block partial sums in double, one fp64 atomic pair per
+// block) and an element-wise apply; the second read of the convolution output comes from L2 / Infinity Cache.
 #include "nf_common.h"
 
-#ifndef NF_CNN_THREADS
-#define NF_CNN_THREADS 1024   // the CPU stand-in build of the tests overrides this with 64 (one OS thread per GPU thread)
-#endif
+#define NF_CNN_BLOCK 256
 
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    v = nf_wave_sum(v);
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, NF_WAVE);
+    return v;
+}
+
+// block partial sums (double) -> two atomics per block into sums[plane][0..1]
+__device__ __forceinline__ void block_atomic_sums(double a, double b, double* dst) {
+    __shared__ double red[2][NF_CNN_BLOCK / 64];
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();                 // protect `red` from the previous use
-    if (lane == 0) red[wave] = v;
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
     __syncthreads();
-    float t = 0.f;
-    int nw = blockDim.x >> 6;
-    for (int w = 0; w < nw; ++w) t += red[w];
-    return t;
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ta += red[0][w]; tb += red[1][w]; }
+        atomicAdd(dst, ta);
+        atomicAdd(dst + 1, tb);
+    }
 }
 
 __device__ __forceinline__ int reflect_src(int i, int n) {      // index into [0,n) of position i of the reflect-padded axis
@@ -45,79 +53,84 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     return 1.f;
 }
 
-// y_p[p, i, j] = act( gamma * (x[p, si, sj] - mean_p) * rstd_p + beta + res[si, sj] ),  (si, sj) = reflect(i - pad, j - pad)
-// gamma == nullptr: no normalisation (pure padding / activation).
-__global__ void __launch_bounds__(NF_CNN_THREADS) k_in_act_pad_fwd(const float* __restrict__ x, int C, int H, int W,
-                                                                   const float* __restrict__ gamma,
-                                                                   const float* __restrict__ beta, float eps,
-                                                                   const float* __restrict__ res, int64_t rs_n, int64_t rs_c,
-                                                                   int64_t rs_h, int64_t rs_w, int act, int pad,
-                                                                   float* __restrict__ yp, float* __restrict__ mean_out,
-                                                                   float* __restrict__ rstd_out) {
-    __shared__ float red[NF_CNN_THREADS / 64];
-    const int64_t p = blockIdx.x;
+// ---- forward, pass 1: per-plane sum and sum of squares (double accumulation).  grid (splits, planes)
+__global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_stats(const float* __restrict__ x, int HW, double* __restrict__ sums) {
+    const int64_t p = blockIdx.y;
+    const float* xp = x + p * HW;
+    int seg = (HW + gridDim.x - 1) / gridDim.x;
+    seg = (seg + 3) & ~3;
+    int lo = blockIdx.x * seg, hi = min(lo + seg, HW);
+    double s = 0.0, q = 0.0;
+    if ((HW & 3) == 0) {       // planes are 16-byte aligned when HW % 4 == 0: float4 stream
+        const float4* x4 = reinterpret_cast<const float4*>(xp);
+        for (int i = lo / 4 + threadIdx.x; i < hi / 4; i += blockDim.x) {
+            float4 v = x4[i];
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            float v = xp[i];
+            s += (double)v;
+            q += (double)v * v;
+        }
+    }
+    block_atomic_sums(s, q, sums + p * 2);
+}
+
+// ---- forward, pass 2: y_p[p, i, j] = act( gamma * (x[p, si, sj] - mean_p) * rstd_p + beta + res[si, sj] ),
+//      (si, sj) = reflect(i - pad, j - pad).  gamma == nullptr: no normalisation.  grid (chunks of the padded plane, planes)
+__global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_fwd(const float* __restrict__ x, int C, int H, int W,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, const double* __restrict__ sums,
+                                                                 const float* __restrict__ res, int64_t rs_n, int64_t rs_c,
+                                                                 int64_t rs_h, int64_t rs_w, int act, int pad,
+                                                                 float* __restrict__ yp, float* __restrict__ mean_out,
+                                                                 float* __restrict__ rstd_out) {
+    const int64_t p = blockIdx.y;
     const int n = (int)(p / C), c = (int)(p - (int64_t)n * C);
     const int HW = H * W;
-    const float* xp = x + p * HW;
     float mean = 0.f, rstd = 1.f, g = 1.f, b = 0.f;
     if (gamma) {
-        float s = 0.f;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += xp[i];
-        mean = block_sum(s, red) / (float)HW;
-        float q = 0.f;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            float d = xp[i] - mean;
-            q += d * d;
-        }
-        float var = block_sum(q, red) / (float)HW;
-        rstd = 1.f / sqrtf(var + eps);
+        double m = sums[p * 2] / (double)HW;
+        double var = sums[p * 2 + 1] / (double)HW - m * m;
+        mean = (float)m;
+        rstd = 1.f / sqrtf(fmaxf((float)var, 0.f) + eps);
         g = gamma[c];
         b = beta[c];
-        if (threadIdx.x == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
             mean_out[p] = mean;
             rstd_out[p] = rstd;
         }
     }
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    float* out = yp + p * (int64_t)Hp * Wp;
-    const float* rp = res ? res + n * rs_n + c * rs_c : nullptr;
-    for (int i = threadIdx.x; i < Hp * Wp; i += blockDim.x) {
-        int ph = i / Wp, pw = i - ph * Wp;
-        int sh = reflect_src(ph - pad, H), sw = reflect_src(pw - pad, W);
-        float v = (xp[sh * W + sw] - mean) * rstd * g + b;
-        if (rp) v += rp[sh * rs_h + sw * rs_w];
-        out[i] = act_fwd(v, act);
-    }
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Hp * Wp) return;
+    int ph = i / Wp, pw = i - ph * Wp;
+    int sh = reflect_src(ph - pad, H), sw = reflect_src(pw - pad, W);
+    float v = (x[p * HW + sh * W + sw] - mean) * rstd * g + b;
+    if (res) v += res[n * rs_n + c * rs_c + sh * rs_h + sw * rs_w];
+    yp[p * (int64_t)Hp * Wp + i] = act_fwd(v, act);
 }
 
-// Backward of the above for one plane.
-//   d[h,w]   = sum of dyp over the padded positions that mirror onto (h,w)   (+ d_extra[h,w])
-//   d_pre    = d * act'(y)                                  -> d_res (gradient of the residual input), if requested
-//   dx       = gamma rstd (d_pre - mean(d_pre) - xhat mean(d_pre xhat))       (InstanceNorm backward; = d_pre without norm)
-__global__ void __launch_bounds__(NF_CNN_THREADS) k_in_act_pad_bwd(const float* __restrict__ dyp, const float* __restrict__ d_extra,
-                                                                   const float* __restrict__ yp, const float* __restrict__ x,
-                                                                   int C, int H, int W, const float* __restrict__ gamma,
-                                                                   const float* __restrict__ mean_in,
-                                                                   const float* __restrict__ rstd_in, int act, int pad,
-                                                                   float* __restrict__ d_res, float* __restrict__ dx) {
-    __shared__ float red[NF_CNN_THREADS / 64];
-    const int64_t p = blockIdx.x;
-    const int c = (int)(p % C);
+// ---- backward, pass 1: fold the padded gradient, activation derivative -> d_pre (written to dx and d_res), and the two
+//      plane sums of the InstanceNorm backward.  grid (chunks of the plane, planes)
+__global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd1(const float* __restrict__ dyp, const float* __restrict__ d_extra,
+                                                                  const float* __restrict__ yp, const float* __restrict__ x,
+                                                                  int H, int W, const float* __restrict__ mean_in,
+                                                                  const float* __restrict__ rstd_in, int has_norm, int act, int pad,
+                                                                  float* __restrict__ d_res, float* __restrict__ dx,
+                                                                  double* __restrict__ sums) {
+    const int64_t p = blockIdx.y;
     const int HW = H * W, Hp = H + 2 * pad, Wp = W + 2 * pad;
-    const float* gp = dyp ? dyp + p * (int64_t)Hp * Wp : nullptr;
-    const float* ep = d_extra ? d_extra + p * HW : nullptr;
-    const float* yq = yp + p * (int64_t)Hp * Wp;
-    const float* xq = x ? x + p * HW : nullptr;
-    float* dxp = dx + p * HW;
-    float* drp = d_res ? d_res + p * HW : nullptr;
-    const float mean = gamma ? mean_in[p] : 0.f, rstd = gamma ? rstd_in[p] : 1.f;
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    if (i < HW) {
         int h = i / W, w = i - h * W;
-        float d = ep ? ep[i] : 0.f;
-        if (gp) {
-            // rows / columns of the padded gradient that mirror onto (h, w)
-            int rows[3], cols[3], nr = 0, nc = 0;
+        float d = d_extra ? d_extra[p * HW + i] : 0.f;
+        if (dyp) {
+            const float* gp = dyp + p * (int64_t)Hp * Wp;
+            int rows[3], cols[3], nr = 0, nc = 0;      // rows / columns of the padded gradient that mirror onto (h, w)
             rows[nr++] = h + pad;
             if (h >= 1 && h <= pad) rows[nr++] = pad - h;
             if (h <= H - 2 && h >= H - 1 - pad) rows[nr++] = 2 * (H - 1) + pad - h;
@@ -127,45 +140,87 @@ __global__ void __launch_bounds__(NF_CNN_THREADS) k_in_act_pad_bwd(const float* 
             for (int a = 0; a < nr; ++a)
                 for (int b = 0; b < nc; ++b) d += gp[rows[a] * Wp + cols[b]];
         }
-        float y = yq[(h + pad) * Wp + (w + pad)];
+        float y = yp[p * (int64_t)Hp * Wp + (h + pad) * Wp + (w + pad)];
         float dpre = d * act_grad_from_out(y, act);
-        if (drp) drp[i] = dpre;
-        dxp[i] = dpre;
-        if (gamma) {
-            float xh = (xq[i] - mean) * rstd;
-            s1 += dpre;
-            s2 += dpre * xh;
+        if (d_res) d_res[p * HW + i] = dpre;
+        dx[p * HW + i] = dpre;
+        if (has_norm) {
+            float xh = (x[p * HW + i] - mean_in[p]) * rstd_in[p];
+            s1 = (double)dpre;
+            s2 = (double)dpre * xh;
         }
     }
-    if (!gamma) return;
-    float m1 = block_sum(s1, red) / (float)HW;
-    float m2 = block_sum(s2, red) / (float)HW;
-    const float gr = gamma[c] * rstd;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {        // each thread re-reads the elements it wrote
-        float xh = (xq[i] - mean) * rstd;
-        dxp[i] = gr * (dxp[i] - m1 - xh * m2);
-    }
+    if (has_norm) block_atomic_sums(s1, s2, sums + p * 2);
+}
+
+// ---- backward, pass 2: dx = gamma rstd (d_pre - mean(d_pre) - xhat mean(d_pre xhat)), in place on dx
+__global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd2(const float* __restrict__ x, int C, int HW,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                                  const float* __restrict__ rstd_in, const double* __restrict__ sums,
+                                                                  float* __restrict__ dx) {
+    const int64_t p = blockIdx.y;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const int c = (int)(p % C);
+    float mean = mean_in[p], rstd = rstd_in[p];
+    float m1 = (float)(sums[p * 2] / (double)HW), m2 = (float)(sums[p * 2 + 1] / (double)HW);
+    float xh = (x[p * HW + i] - mean) * rstd;
+    dx[p * HW + i] = gamma[c] * rstd * (dx[p * HW + i] - m1 - xh * m2);
+}
+
+static unsigned nf_stat_splits(int planes, int HW) {
+    int splits = 2048 / planes;
+    int cap = HW / 4096;
+    if (splits > cap) splits = cap;
+    return (unsigned)(splits < 1 ? 1 : splits);
 }
 
 extern "C" int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W, const float* gamma, const float* beta, float eps,
                                  const float* res, int64_t rs_n, int64_t rs_c, int64_t rs_h, int64_t rs_w, int act, int pad,
-                                 float* y_padded, float* mean, float* rstd, nf_stream_t stream) {
+                                 float* y_padded, float* mean, float* rstd, void* scratch, nf_stream_t stream) {
     NF_REQUIRE(n_img >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad < H && pad < W && act >= 0 && act <= 2,
                "nf_in_act_pad_fwd: bad arguments (N %d C %d H %d W %d pad %d act %d)", n_img, C, H, W, pad, act);
-    hipLaunchKernelGGL(k_in_act_pad_fwd, dim3((unsigned)(n_img * C)), dim3(NF_CNN_THREADS), 0, (hipStream_t)stream, x, C, H, W,
-                       gamma, beta, eps, res, rs_n, rs_c, rs_h, rs_w, act, pad, y_padded, mean, rstd);
+    hipStream_t st = (hipStream_t)stream;
+    const int planes = n_img * C, HW = H * W, HWp = (H + 2 * pad) * (W + 2 * pad);
+    if (gamma) {
+        NF_REQUIRE(scratch != nullptr, "nf_in_act_pad_fwd: scratch (16 bytes per plane) required with normalisation");
+        if (hipMemsetAsync(scratch, 0, (size_t)planes * 2 * sizeof(double), st) != hipSuccess) {
+            nf_set_error("nf_in_act_pad_fwd: memset failed");
+            return 2;
+        }
+        hipLaunchKernelGGL(k_in_stats, dim3(nf_stat_splits(planes, HW), (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, HW,
+                           (double*)scratch);
+        NF_LAUNCH_CHECK("nf_in_act_pad_fwd (stats)");
+    }
+    hipLaunchKernelGGL(k_in_act_pad_fwd, dim3(nf_blocks(HWp, NF_CNN_BLOCK), (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, C, H, W,
+                       gamma, beta, eps, (const double*)scratch, res, rs_n, rs_c, rs_h, rs_w, act, pad, y_padded, mean, rstd);
     NF_LAUNCH_CHECK("nf_in_act_pad_fwd");
     return 0;
 }
 
 extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, const float* y_padded, const float* x, int n_img,
                                  int C, int H, int W, const float* gamma, const float* mean, const float* rstd, int act, int pad,
-                                 float* d_res, float* dx, nf_stream_t stream) {
+                                 float* d_res, float* dx, void* scratch, nf_stream_t stream) {
     NF_REQUIRE(n_img >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad < H && pad < W && act >= 0 && act <= 2 &&
                    (dy_padded || d_extra),
                "nf_in_act_pad_bwd: bad arguments");
-    hipLaunchKernelGGL(k_in_act_pad_bwd, dim3((unsigned)(n_img * C)), dim3(NF_CNN_THREADS), 0, (hipStream_t)stream, dy_padded,
-                       d_extra, y_padded, x, C, H, W, gamma, mean, rstd, act, pad, d_res, dx);
-    NF_LAUNCH_CHECK("nf_in_act_pad_bwd");
+    hipStream_t st = (hipStream_t)stream;
+    const int planes = n_img * C, HW = H * W;
+    if (gamma) {
+        NF_REQUIRE(scratch != nullptr, "nf_in_act_pad_bwd: scratch (16 bytes per plane) required with normalisation");
+        if (hipMemsetAsync(scratch, 0, (size_t)planes * 2 * sizeof(double), st) != hipSuccess) {
+            nf_set_error("nf_in_act_pad_bwd: memset failed");
+            return 2;
+        }
+    }
+    dim3 grid(nf_blocks(HW, NF_CNN_BLOCK), (unsigned)planes);
+    hipLaunchKernelGGL(k_in_act_pad_bwd1, grid, dim3(NF_CNN_BLOCK), 0, st, dy_padded, d_extra, y_padded, x, H, W, mean, rstd,
+                       gamma ? 1 : 0, act, pad, d_res, dx, (double*)scratch);
+    NF_LAUNCH_CHECK("nf_in_act_pad_bwd (fold)");
+    if (gamma) {
+        hipLaunchKernelGGL(k_in_act_pad_bwd2, grid, dim3(NF_CNN_BLOCK), 0, st, x, C, HW, gamma, mean, rstd, (const double*)scratch,
+                           dx);
+        NF_LAUNCH_CHECK("nf_in_act_pad_bwd (norm)");
+    }
     return 0;
 }

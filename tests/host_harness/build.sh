@@ -10,7 +10,7 @@ mkdir -p "$HERE/build"
 for s in $SRCS "$HERE/hip_emu.cpp"; do
   o="$HERE/build/$(basename "$s").o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$o" ] || [ -n "$(find "$ROOT/nerfool_amd/csrc" "$ROOT/include" -name '*.h' -newer "$o")" ]; then
-    $CXX -O1 -std=c++17 -fPIC -pthread -ffp-contract=off -Wno-unknown-pragmas -Wno-unknown-attributes -Wno-pass-failed -Wno-psabi -DNF_CNN_THREADS=64 -x c++ -I "$HERE" -c "$s" -o "$o" &
+    $CXX -O1 -std=c++17 -fPIC -pthread -ffp-contract=off -Wno-unknown-pragmas -Wno-unknown-attributes -Wno-pass-failed -Wno-psabi -x c++ -I "$HERE" -c "$s" -o "$o" &
   fi
   OBJS="$OBJS $o"
 done

@@ -43,6 +43,7 @@ typedef int hipError_t;
 enum { hipDeviceAttributeMultiprocessorCount = 1 };
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
@@ -113,6 +114,22 @@ static inline float atomicAdd(float* addr, float val) {
 }
 
 #define __expf(x) expf(x)   // v_exp_f32-based fast exp on the device
+static inline double atomicAdd(double* addr, double val) {
+    uint64_t* p = (uint64_t*)addr;
+    uint64_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    for (;;) {
+        double f;
+        memcpy(&f, &old, 8);
+        f += val;
+        uint64_t nw;
+        memcpy(&nw, &f, 8);
+        if (__atomic_compare_exchange_n(p, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+            memcpy(&f, &old, 8);
+            return f;
+        }
+    }
+}
+
 using std::max;
 using std::min;
 
