@@ -173,7 +173,7 @@ int nf_pgd_sign_step(float* delta, const float* grad, const float* src, int64_t 
  *   act 0 none / 1 ReLU / 2 ELU; y_padded [N,C,H+2p,W+2p]; mean, rstd [N*C] out (saved for the backward).
  * Backward: dy_padded (nullable) = gradient w.r.t. y_padded, d_extra (nullable, [N,C,H,W]) = additional gradient w.r.t.
  * the unpadded activated output (residual / skip consumers); d_res (nullable out) = gradient of the residual input;
- * dx [N,C,H,W] = gradient of x.   scratch: 16 bytes per (image, channel) plane (fp64 partial sums; zeroed by the call).
+ * dx [N,C,H,W] = gradient of x.   scratch: 512 bytes per (image, channel) plane (fp64 partial sums of up to 32 workgroups; no atomics).
  * ---------------------------------------------------------------------------------------------------------------- */
 int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W, const float* gamma, const float* beta, float eps,
                       const float* res, int64_t rs_n, int64_t rs_c, int64_t rs_h, int64_t rs_w, int act, int pad,

@@ -19,8 +19,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// block partial sums (double) -> two atomics per block into sums[plane][0..1]
-__device__ __forceinline__ void block_atomic_sums(double a, double b, double* dst) {
+#define NF_MAX_SPLITS 32   // partial sums per plane: scratch holds [planes][NF_MAX_SPLITS][2] doubles, no atomics, no memset
+
+// block partial sums (double) -> this block's slot dst[0..1]
+__device__ __forceinline__ void block_store_sums(double a, double b, double* dst) {
     __shared__ double red[2][NF_CNN_BLOCK / 64];
     a = wave_sum_f64(a);
     b = wave_sum_f64(b);
@@ -30,8 +32,8 @@ __device__ __forceinline__ void block_atomic_sums(double a, double b, double* ds
     if (threadIdx.x == 0) {
         double ta = 0.0, tb = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ta += red[0][w]; tb += red[1][w]; }
-        atomicAdd(dst, ta);
-        atomicAdd(dst + 1, tb);
+        dst[0] = ta;
+        dst[1] = tb;
     }
 }
 
@@ -75,14 +77,23 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_stats(const float* __restri
             q += (double)v * v;
         }
     }
-    block_atomic_sums(s, q, sums + p * 2);
+    block_store_sums(s, q, sums + (p * NF_MAX_SPLITS + blockIdx.x) * 2);
+}
+
+__device__ __forceinline__ void plane_sums(const double* __restrict__ sums, int64_t p, int n_splits, double& a, double& b) {
+    a = 0.0;
+    b = 0.0;
+    for (int i = 0; i < n_splits; ++i) {
+        a += sums[(p * NF_MAX_SPLITS + i) * 2];
+        b += sums[(p * NF_MAX_SPLITS + i) * 2 + 1];
+    }
 }
 
 // ---- forward, pass 2: y_p[p, i, j] = act( gamma * (x[p, si, sj] - mean_p) * rstd_p + beta + res[si, sj] ),
 //      (si, sj) = reflect(i - pad, j - pad).  gamma == nullptr: no normalisation.  grid (chunks of the padded plane, planes)
 __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_fwd(const float* __restrict__ x, int C, int H, int W,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 float eps, const double* __restrict__ sums,
+                                                                 float eps, const double* __restrict__ sums, int n_splits,
                                                                  const float* __restrict__ res, int64_t rs_n, int64_t rs_c,
                                                                  int64_t rs_h, int64_t rs_w, int act, int pad,
                                                                  float* __restrict__ yp, float* __restrict__ mean_out,
@@ -92,8 +103,10 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_fwd(const float* __
     const int HW = H * W;
     float mean = 0.f, rstd = 1.f, g = 1.f, b = 0.f;
     if (gamma) {
-        double m = sums[p * 2] / (double)HW;
-        double var = sums[p * 2 + 1] / (double)HW - m * m;
+        double sa, sb;
+        plane_sums(sums, p, n_splits, sa, sb);
+        double m = sa / (double)HW;
+        double var = sb / (double)HW - m * m;
         mean = (float)m;
         rstd = 1.f / sqrtf(fmaxf((float)var, 0.f) + eps);
         g = gamma[c];
@@ -103,14 +116,20 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_fwd(const float* __
             rstd_out[p] = rstd;
         }
     }
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Hp * Wp) return;
-    int ph = i / Wp, pw = i - ph * Wp;
-    int sh = reflect_src(ph - pad, H), sw = reflect_src(pw - pad, W);
-    float v = (x[p * HW + sh * W + sw] - mean) * rstd * g + b;
-    if (res) v += res[n * rs_n + c * rs_c + sh * rs_h + sw * rs_w];
-    yp[p * (int64_t)Hp * Wp + i] = act_fwd(v, act);
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp;
+    const float* xp = x + p * HW;
+    const float* rp = res ? res + n * rs_n + c * rs_c : nullptr;
+    float* out = yp + p * (int64_t)HWp;
+    int seg = (HWp + gridDim.x - 1) / gridDim.x;
+    int lo = blockIdx.x * seg, hi = min(lo + seg, HWp);
+#pragma unroll 4
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        int ph = i / Wp, pw = i - ph * Wp;
+        int sh = reflect_src(ph - pad, H), sw = reflect_src(pw - pad, W);
+        float v = (xp[sh * W + sw] - mean) * rstd * g + b;
+        if (rp) v += rp[sh * rs_h + sw * rs_w];
+        out[i] = act_fwd(v, act);
+    }
 }
 
 // ---- backward, pass 1: fold the padded gradient, activation derivative -> d_pre (written to dx and d_res), and the two
@@ -123,55 +142,88 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd1(const float* _
                                                                   double* __restrict__ sums) {
     const int64_t p = blockIdx.y;
     const int HW = H * W, Hp = H + 2 * pad, Wp = W + 2 * pad;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* gp = dyp ? dyp + p * (int64_t)Hp * Wp : nullptr;
+    const float* ep = d_extra ? d_extra + p * HW : nullptr;
+    const float* yq = yp + p * (int64_t)Hp * Wp;
+    const float* xq = has_norm ? x + p * HW : nullptr;
+    float* dxp = dx + p * HW;
+    float* drp = d_res ? d_res + p * HW : nullptr;
+    const float mean = has_norm ? mean_in[p] : 0.f, rstd = has_norm ? rstd_in[p] : 1.f;
+    int seg = (HW + gridDim.x - 1) / gridDim.x;
+    int lo = blockIdx.x * seg, hi = min(lo + seg, HW);
     double s1 = 0.0, s2 = 0.0;
-    if (i < HW) {
+#pragma unroll 2
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         int h = i / W, w = i - h * W;
-        float d = d_extra ? d_extra[p * HW + i] : 0.f;
-        if (dyp) {
-            const float* gp = dyp + p * (int64_t)Hp * Wp;
-            int rows[3], cols[3], nr = 0, nc = 0;      // rows / columns of the padded gradient that mirror onto (h, w)
-            rows[nr++] = h + pad;
-            if (h >= 1 && h <= pad) rows[nr++] = pad - h;
-            if (h <= H - 2 && h >= H - 1 - pad) rows[nr++] = 2 * (H - 1) + pad - h;
-            cols[nc++] = w + pad;
-            if (w >= 1 && w <= pad) cols[nc++] = pad - w;
-            if (w <= W - 2 && w >= W - 1 - pad) cols[nc++] = 2 * (W - 1) + pad - w;
-            for (int a = 0; a < nr; ++a)
-                for (int b = 0; b < nc; ++b) d += gp[rows[a] * Wp + cols[b]];
+        float d = ep ? ep[i] : 0.f;
+        if (gp) {
+            d += gp[(h + pad) * Wp + (w + pad)];
+            // border pixels also collect the padded positions that mirror onto them
+            bool hb = (h >= 1 && h <= pad) || (h <= H - 2 && h >= H - 1 - pad);
+            bool wb = (w >= 1 && w <= pad) || (w <= W - 2 && w >= W - 1 - pad);
+            if (hb || wb) {
+                int rows[3], cols[3], nr = 0, nc = 0;
+                rows[nr++] = h + pad;
+                if (h >= 1 && h <= pad) rows[nr++] = pad - h;
+                if (h <= H - 2 && h >= H - 1 - pad) rows[nr++] = 2 * (H - 1) + pad - h;
+                cols[nc++] = w + pad;
+                if (w >= 1 && w <= pad) cols[nc++] = pad - w;
+                if (w <= W - 2 && w >= W - 1 - pad) cols[nc++] = 2 * (W - 1) + pad - w;
+                for (int a = 0; a < nr; ++a)
+                    for (int b = 0; b < nc; ++b)
+                        if (a + b > 0) d += gp[rows[a] * Wp + cols[b]];
+            }
         }
-        float y = yp[p * (int64_t)Hp * Wp + (h + pad) * Wp + (w + pad)];
+        float y = yq[(h + pad) * Wp + (w + pad)];
         float dpre = d * act_grad_from_out(y, act);
-        if (d_res) d_res[p * HW + i] = dpre;
-        dx[p * HW + i] = dpre;
+        if (drp) drp[i] = dpre;
+        dxp[i] = dpre;
         if (has_norm) {
-            float xh = (x[p * HW + i] - mean_in[p]) * rstd_in[p];
-            s1 = (double)dpre;
-            s2 = (double)dpre * xh;
+            float xh = (xq[i] - mean) * rstd;
+            s1 += (double)dpre;
+            s2 += (double)dpre * xh;
         }
     }
-    if (has_norm) block_atomic_sums(s1, s2, sums + p * 2);
+    if (has_norm) block_store_sums(s1, s2, sums + (p * NF_MAX_SPLITS + blockIdx.x) * 2);
 }
 
 // ---- backward, pass 2: dx = gamma rstd (d_pre - mean(d_pre) - xhat mean(d_pre xhat)), in place on dx
 __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd2(const float* __restrict__ x, int C, int HW,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                                   const float* __restrict__ rstd_in, const double* __restrict__ sums,
-                                                                  float* __restrict__ dx) {
+                                                                  int n_splits, float* __restrict__ dx) {
     const int64_t p = blockIdx.y;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= HW) return;
     const int c = (int)(p % C);
-    float mean = mean_in[p], rstd = rstd_in[p];
-    float m1 = (float)(sums[p * 2] / (double)HW), m2 = (float)(sums[p * 2 + 1] / (double)HW);
-    float xh = (x[p * HW + i] - mean) * rstd;
-    dx[p * HW + i] = gamma[c] * rstd * (dx[p * HW + i] - m1 - xh * m2);
+    const float mean = mean_in[p], rstd = rstd_in[p];
+    double sa, sb;
+    plane_sums(sums, p, n_splits, sa, sb);
+    const float m1 = (float)(sa / (double)HW), m2 = (float)(sb / (double)HW);
+    const float gr = gamma[c] * rstd;
+    const float* xq = x + p * HW;
+    float* dxp = dx + p * HW;
+    int seg = (HW + gridDim.x - 1) / gridDim.x;
+    int lo = blockIdx.x * seg, hi = min(lo + seg, HW);
+#pragma unroll 4
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        float xh = (xq[i] - mean) * rstd;
+        dxp[i] = gr * (dxp[i] - m1 - xh * m2);
+    }
+}
+
+// element-wise passes: ~8192 workgroups of 256 threads over the chip, each streaming >= 1024 elements of one plane
+static unsigned nf_apply_splits(int planes, int n) {
+    int splits = 8192 / planes;
+    int cap = n / 1024;
+    if (splits > cap) splits = cap;
+    if (splits > NF_MAX_SPLITS) splits = NF_MAX_SPLITS;
+    return (unsigned)(splits < 1 ? 1 : splits);
 }
 
 static unsigned nf_stat_splits(int planes, int HW) {
     int splits = 2048 / planes;
     int cap = HW / 4096;
     if (splits > cap) splits = cap;
+    if (splits > NF_MAX_SPLITS) splits = NF_MAX_SPLITS;
     return (unsigned)(splits < 1 ? 1 : splits);
 }
 
@@ -182,18 +234,16 @@ extern "C" int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W,
                "nf_in_act_pad_fwd: bad arguments (N %d C %d H %d W %d pad %d act %d)", n_img, C, H, W, pad, act);
     hipStream_t st = (hipStream_t)stream;
     const int planes = n_img * C, HW = H * W, HWp = (H + 2 * pad) * (W + 2 * pad);
+    unsigned stat_splits = 1;
     if (gamma) {
-        NF_REQUIRE(scratch != nullptr, "nf_in_act_pad_fwd: scratch (16 bytes per plane) required with normalisation");
-        if (hipMemsetAsync(scratch, 0, (size_t)planes * 2 * sizeof(double), st) != hipSuccess) {
-            nf_set_error("nf_in_act_pad_fwd: memset failed");
-            return 2;
-        }
-        hipLaunchKernelGGL(k_in_stats, dim3(nf_stat_splits(planes, HW), (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, HW,
-                           (double*)scratch);
+        NF_REQUIRE(scratch != nullptr, "nf_in_act_pad_fwd: scratch (512 bytes per plane) required with normalisation");
+        stat_splits = nf_stat_splits(planes, HW);
+        hipLaunchKernelGGL(k_in_stats, dim3(stat_splits, (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, HW, (double*)scratch);
         NF_LAUNCH_CHECK("nf_in_act_pad_fwd (stats)");
     }
-    hipLaunchKernelGGL(k_in_act_pad_fwd, dim3(nf_blocks(HWp, NF_CNN_BLOCK), (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, C, H, W,
-                       gamma, beta, eps, (const double*)scratch, res, rs_n, rs_c, rs_h, rs_w, act, pad, y_padded, mean, rstd);
+    hipLaunchKernelGGL(k_in_act_pad_fwd, dim3(nf_apply_splits(planes, HWp), (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, C, H, W,
+                       gamma, beta, eps, (const double*)scratch, (int)stat_splits, res, rs_n, rs_c, rs_h, rs_w, act, pad, y_padded, mean,
+                       rstd);
     NF_LAUNCH_CHECK("nf_in_act_pad_fwd");
     return 0;
 }
@@ -207,19 +257,15 @@ extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, c
     hipStream_t st = (hipStream_t)stream;
     const int planes = n_img * C, HW = H * W;
     if (gamma) {
-        NF_REQUIRE(scratch != nullptr, "nf_in_act_pad_bwd: scratch (16 bytes per plane) required with normalisation");
-        if (hipMemsetAsync(scratch, 0, (size_t)planes * 2 * sizeof(double), st) != hipSuccess) {
-            nf_set_error("nf_in_act_pad_bwd: memset failed");
-            return 2;
-        }
+        NF_REQUIRE(scratch != nullptr, "nf_in_act_pad_bwd: scratch (512 bytes per plane) required with normalisation");
     }
-    dim3 grid(nf_blocks(HW, NF_CNN_BLOCK), (unsigned)planes);
+    dim3 grid(nf_apply_splits(planes, HW), (unsigned)planes);
     hipLaunchKernelGGL(k_in_act_pad_bwd1, grid, dim3(NF_CNN_BLOCK), 0, st, dy_padded, d_extra, y_padded, x, H, W, mean, rstd,
                        gamma ? 1 : 0, act, pad, d_res, dx, (double*)scratch);
     NF_LAUNCH_CHECK("nf_in_act_pad_bwd (fold)");
     if (gamma) {
         hipLaunchKernelGGL(k_in_act_pad_bwd2, grid, dim3(NF_CNN_BLOCK), 0, st, x, C, HW, gamma, mean, rstd, (const double*)scratch,
-                           dx);
+                           (int)grid.x, dx);
         NF_LAUNCH_CHECK("nf_in_act_pad_bwd (norm)");
     }
     return 0;

@@ -340,7 +340,7 @@ def in_act_pad_fwd(x, gamma, beta, res, act, pad, eps=1e-5):
     if gamma is not None:
         mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
         rstd = torch.empty(N * C, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(N * C * 2, dtype=torch.float64, device=x.device)
+        scratch = torch.empty(N * C * 64, dtype=torch.float64, device=x.device)
     rs = (0, 0, 0, 0)
     if res is not None:
         _f32(res, 'res')
@@ -364,7 +364,7 @@ def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res)
         d_extra = _c(d_extra, 'd_extra')
     dx = torch.empty(N, C, H, W, dtype=torch.float32, device=yp.device)
     d_res = torch.empty_like(dx) if want_d_res else None
-    scratch = torch.empty(N * C * 2, dtype=torch.float64, device=yp.device) if gamma is not None else None
+    scratch = torch.empty(N * C * 64, dtype=torch.float64, device=yp.device) if gamma is not None else None
     with prof.launch('nf_in_act_pad_bwd', yp, n=dx.numel()):
         _lib.check(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(mean),
                                                 _ptr(rstd), int(act), int(pad), _ptr(d_res), _ptr(dx), _ptr(scratch), _stream(yp)),
