@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Golden vectors of the GNT flavour (reference gnt/ package imported from /root/reference, eval mode).  Build container only.
+    python tests/golden/make_golden_gnt.py
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _refimport  # noqa: E402
+
+_refimport.install('gnt')
+
+from gnt.projection import Projector  # noqa: E402
+from gnt.render_ray import render_rays  # noqa: E402
+from gnt.transformer_network import GNT  # noqa: E402
+import gnt.sample_ray as ref_sample_ray  # noqa: E402
+
+from nerfool_amd.synthetic import make_scene, smooth_featmaps  # noqa: E402
+from oracle.gnt_ref import random_gnt_params  # noqa: E402
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.array(t)
+
+
+def case(name, H, W, V, R, S, depth, seed, tilt=0.0):
+    torch.manual_seed(seed)
+    data = make_scene(H, W, V, seed=seed, tilt=tilt)
+    Hf, Wf = max(6, H // 4), max(8, W // 4)
+    fm = smooth_featmaps(V, 32, Hf, Wf, seed=seed).requires_grad_(True)
+    params = random_gnt_params(depth, seed=60 + seed)
+    net = GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=False)
+    net.load_state_dict(params, strict=True)
+    net.eval()
+    model = SimpleNamespace(net_coarse=net, net_fine=None)
+    ref_sample_ray.rng.seed(234)
+    sampler = ref_sample_ray.RaySamplerSingleImage(data, 'cpu')
+    batch = sampler.random_sample(R, sample_mode='uniform', center_ratio=0.8)
+    ret = render_rays(batch, model, (fm, fm), Projector(device='cpu'), S, inv_uniform=True, N_importance=0, det=True,
+                      ret_alpha=False, single_net=True)
+    rgb = ret['outputs_coarse']['rgb']
+    loss = torch.mean((rgb - batch['rgb']) ** 2)
+    grad, = torch.autograd.grad(loss, fm)
+    out = {'cfg': np.array([H, W, V, R, S, depth, Hf, Wf], dtype=np.int64)}
+    for k in ('rgb', 'camera', 'src_rgbs', 'src_cameras', 'depth_range'):
+        out['in/' + k] = npy(data[k])
+    out['in/featmap'] = npy(fm)
+    out['in/ray_o'] = npy(batch['ray_o'])
+    out['in/ray_d'] = npy(batch['ray_d'])
+    out['in/gt_rgb'] = npy(batch['rgb'])
+    for k, v in params.items():
+        out['net/' + k] = npy(v)
+    out['rgb'] = npy(rgb)
+    out['loss'] = npy(loss)
+    out['grad/featmap'] = npy(grad)
+    # network-level capture for the kernel tests
+    from gnt.render_ray import sample_along_camera_ray
+    pts, z = sample_along_camera_ray(batch['ray_o'], batch['ray_d'], batch['depth_range'], S, inv_uniform=True, det=True)
+    rgb_feat, ray_diff, mask = Projector(device='cpu').compute(pts, batch['camera'], batch['src_rgbs'], batch['src_cameras'],
+                                                              featmaps=fm)
+    out['net_in/rgb_feat'] = npy(rgb_feat)
+    out['net_in/ray_diff'] = npy(ray_diff)
+    out['net_in/mask'] = npy(mask)
+    out['net_in/pts'] = npy(pts)
+    print('%-24s loss %.6f  rgb range [%.3f, %.3f]  valid %.3f' % (name, float(loss), float(rgb.min()), float(rgb.max()),
+                                                                  float(mask.mean())))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('   %.1f KB' % (os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024.))
+
+
+if __name__ == '__main__':
+    case('gnt_tiny_d2_v4', 32, 48, 4, 12, 8, 2, seed=0, tilt=0.4)
+    case('gnt_tiny_d3_v5', 32, 48, 5, 10, 12, 3, seed=1, tilt=0.3)
