@@ -166,6 +166,22 @@ int nf_pgd_sign_step(float* delta, const float* grad, const float* src, int64_t 
                      float lower, float upper, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * a15  GNT.forward (ret_alpha = False, eval mode)      ref: gnt/transformer_network.py:270-309 (+ :55-89, :93-113,
+ * :121-171, :175-202).  Parameters as one blob whose layout nf_gnt_blob_entry enumerates (HOST; an empty name marks a
+ * slot without parameters, e.g. q_fcs on odd layers).  rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V],
+ * pts [R,S,3], ray_d [R,3] -> rgb [R,3].  save != 0 keeps all activations in `workspace`
+ * (nf_gnt_workspace_floats(R,S,V,depth,1) floats) for nf_gnt_bwd: d_rgb [R,3] -> d_rgb_feat [R,S,V,35].
+ * ---------------------------------------------------------------------------------------------------------------- */
+int64_t nf_gnt_blob_floats(int depth);
+int nf_gnt_blob_entry(int depth, int idx, char* name, int name_cap, int64_t* offset, int* rows, int* cols, int* transposed);
+int64_t nf_gnt_workspace_floats(int64_t n_rays, int n_samples, int n_views, int depth, int save);
+int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+               const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
+               float* workspace, nf_stream_t stream);
+int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
+               int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * a14 (glue only)  ResUNet: InstanceNorm + affine + residual + ReLU/ELU + reflect padding fused into one pass over a
  * convolution output, producing the pre-padded input of the next convolution.   ref: ibrnet/feature_network.py:38-78,
  * :127-140 (padding_mode='reflect', InstanceNorm2d(affine, no running stats)).

@@ -1,0 +1,769 @@
+// GNT per-ray network (a15): view transformers (subtraction attention over the V source views) interleaved with ray
+// transformers (4-head attention over the S samples), forward and backward w.r.t. rgb_feat.
+// ref: gnt/transformer_network.py:270-309 (GNT.forward, ret_alpha = False, eval mode), :55-89, :93-113, :121-171, :175-202.
+// The backward follows oracle/gnt_manual_bwd.py.
+//
+// Shape-generic kernels in the style of nf_ibrnet.hip: one workgroup per ray, one thread per sample, the thread walks the
+// V views serially; activations stream through a per-ray global workspace [slot][view][sample] / [slot][sample] (sample
+// fastest => coalesced), weights are read with wave-uniform addresses.  With SAVE the forward keeps every activation the
+// backward needs (one slot set per layer), otherwise one slot set is recycled.
+#include "nf_dense.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#define GNT_C 64
+#define GNT_MAX_S 1024
+
+// ---------------------------------------------------------------------------------------------------------------
+// parameter blob: [stem | layer 0 | layer 1 | ... | final]; every Linear as Wt [in][out], W [out][in], bias
+// ---------------------------------------------------------------------------------------------------------------
+struct GntLin { int in, out, bias; const char* key; };
+
+enum { GV_Q, GV_K, GV_V, GV_POS0, GV_POS2, GV_ATT0, GV_ATT2, GV_OUT, GV_FF1, GV_FF2, GQ_0, GQ_2, GR_Q, GR_K, GR_V, GR_OUT, GR_FF1,
+       GR_FF2, G_NLIN };
+
+static constexpr GntLin GNT_LAYER[G_NLIN] = {
+    {64, 64, 0, "view_crosstrans.%d.attn.q_fc"},   {64, 64, 0, "view_crosstrans.%d.attn.k_fc"},
+    {64, 64, 0, "view_crosstrans.%d.attn.v_fc"},   {4, 8, 1, "view_crosstrans.%d.attn.pos_fc.0"},
+    {8, 64, 1, "view_crosstrans.%d.attn.pos_fc.2"}, {64, 8, 1, "view_crosstrans.%d.attn.attn_fc.0"},
+    {8, 64, 1, "view_crosstrans.%d.attn.attn_fc.2"}, {64, 64, 1, "view_crosstrans.%d.attn.out_fc"},
+    {64, 256, 1, "view_crosstrans.%d.ff.fc1"},     {256, 64, 1, "view_crosstrans.%d.ff.fc2"},
+    {190, 64, 1, "q_fcs.%d.0"},                    {64, 64, 1, "q_fcs.%d.2"},
+    {64, 64, 0, "view_selftrans.%d.attn.q_fc"},    {64, 64, 0, "view_selftrans.%d.attn.k_fc"},
+    {64, 64, 0, "view_selftrans.%d.attn.v_fc"},    {64, 64, 1, "view_selftrans.%d.attn.out_fc"},
+    {64, 256, 1, "view_selftrans.%d.ff.fc1"},      {256, 64, 1, "view_selftrans.%d.ff.fc2"}};
+static constexpr const char* GNT_LN_KEYS[4] = {"view_crosstrans.%d.attn_norm", "view_crosstrans.%d.ff_norm",
+                                               "view_selftrans.%d.attn_norm", "view_selftrans.%d.ff_norm"};
+static constexpr GntLin GNT_STEM[2] = {{35, 64, 1, "rgbfeat_fc.0"}, {64, 64, 1, "rgbfeat_fc.2"}};
+
+NF_HD constexpr int gnt_lin_size(const GntLin& l) { return 2 * l.in * l.out + (l.bias ? l.out : 0); }
+NF_HD constexpr int gnt_lin_off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += gnt_lin_size(GNT_LAYER[i]);
+    return o;
+}
+NF_HD constexpr int gnt_wt(int l) { return gnt_lin_off(l); }
+NF_HD constexpr int gnt_w(int l) { return gnt_lin_off(l) + GNT_LAYER[l].in * GNT_LAYER[l].out; }
+NF_HD constexpr int gnt_b(int l) { return gnt_lin_off(l) + 2 * GNT_LAYER[l].in * GNT_LAYER[l].out; }
+static constexpr int GNT_LN_OFF = gnt_lin_off(G_NLIN);          // 4 x (weight 64, bias 64)
+static constexpr int GNT_LAYER_FLOATS = GNT_LN_OFF + 4 * 128;
+static constexpr int GNT_STEM1 = gnt_lin_size(GNT_STEM[0]);
+static constexpr int GNT_STEM_FLOATS = GNT_STEM1 + gnt_lin_size(GNT_STEM[1]);
+NF_HD constexpr int gnt_ln_w(int j) { return GNT_LN_OFF + j * 128; }
+NF_HD constexpr int gnt_ln_b(int j) { return GNT_LN_OFF + j * 128 + 64; }
+// final block: norm weight 64, bias 64, rgb_fc Wt [64][3], W [3][64], bias 3
+static constexpr int GNT_FINAL_FLOATS = 128 + 192 + 192 + 3 + 1;
+NF_HD constexpr int64_t gnt_layer_base(int i) { return (int64_t)GNT_STEM_FLOATS + (int64_t)i * GNT_LAYER_FLOATS; }
+
+extern "C" int64_t nf_gnt_blob_floats(int depth) { return GNT_STEM_FLOATS + (int64_t)depth * GNT_LAYER_FLOATS + GNT_FINAL_FLOATS; }
+
+// idx enumerates (state-dict key, offset, rows, cols, transposed); returns 1 past the end.  Entries of q_fcs on odd layers
+// are reported with an empty name (nn.Identity in the reference: nothing to pack).
+extern "C" int nf_gnt_blob_entry(int depth, int idx, char* name, int name_cap, int64_t* offset, int* rows, int* cols,
+                                 int* transposed) {
+    char key[96] = "";
+    int64_t off = 0;
+    int r = 1, c = 1, tr = 0;
+    const int per_lin = 3, stem_n = 2 * per_lin, layer_n = G_NLIN * per_lin + 8;
+    if (idx < 0) return 1;
+    if (idx < stem_n) {
+        const GntLin& l = GNT_STEM[idx / 3];
+        int part = idx % 3;
+        int64_t base = idx / 3 == 0 ? 0 : GNT_STEM1;
+        snprintf(key, sizeof(key), "%s.%s", l.key, part == 2 ? "bias" : "weight");
+        if (part == 2) { off = base + 2 * l.in * l.out; r = 1; c = l.out; }
+        else { off = base + (part == 0 ? 0 : l.in * l.out); r = l.out; c = l.in; tr = part == 0; }
+    } else if (idx < stem_n + depth * layer_n) {
+        int li = (idx - stem_n) / layer_n, j = (idx - stem_n) % layer_n;
+        int64_t base = gnt_layer_base(li);
+        if (j < G_NLIN * per_lin) {
+            int l = j / 3, part = j % 3;
+            const GntLin& L = GNT_LAYER[l];
+            char fmt[96];
+            snprintf(fmt, sizeof(fmt), "%s.%s", L.key, part == 2 ? "bias" : "weight");
+            bool skip = (part == 2 && !L.bias) || ((l == GQ_0 || l == GQ_2) && (li % 2 == 1));
+            if (!skip) snprintf(key, sizeof(key), fmt, li);
+            if (part == 2) { off = base + gnt_b(l); r = 1; c = L.out; }
+            else { off = base + (part == 0 ? gnt_wt(l) : gnt_w(l)); r = L.out; c = L.in; tr = part == 0; }
+        } else {
+            int k = j - G_NLIN * per_lin;      // 0..7: 4 LayerNorms x (weight, bias)
+            char fmt[96];
+            snprintf(fmt, sizeof(fmt), "%s.%s", GNT_LN_KEYS[k / 2], k % 2 == 0 ? "weight" : "bias");
+            snprintf(key, sizeof(key), fmt, li);
+            off = base + (k % 2 == 0 ? gnt_ln_w(k / 2) : gnt_ln_b(k / 2)); r = 1; c = 64;
+        }
+    } else {
+        int j = idx - stem_n - depth * layer_n;
+        int64_t base = gnt_layer_base(depth);
+        if (j == 0) { snprintf(key, sizeof(key), "norm.weight"); off = base; c = 64; }
+        else if (j == 1) { snprintf(key, sizeof(key), "norm.bias"); off = base + 64; c = 64; }
+        else if (j == 2) { snprintf(key, sizeof(key), "rgb_fc.weight"); off = base + 128; r = 3; c = 64; tr = 1; }
+        else if (j == 3) { snprintf(key, sizeof(key), "rgb_fc.weight"); off = base + 320; r = 3; c = 64; }
+        else if (j == 4) { snprintf(key, sizeof(key), "rgb_fc.bias"); off = base + 512; c = 3; }
+        else return 1;
+    }
+    if (name && name_cap > 0) { strncpy(name, key, (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = off;
+    if (rows) *rows = r;
+    if (cols) *cols = c;
+    if (transposed) *transposed = tr;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// workspace slots
+// ---------------------------------------------------------------------------------------------------------------
+enum { RW_R1 = 0, RW_X = 64, RW_DX = 128, RW_T = 192, RW_T2 = 256, RW_BASE = 320, RWL_VP = 0, RWL_H = 64, RWL_PROB = 72, RW_LAYER = 136 };
+enum { SW_AMAX = 0, SW_CUR = 64, SW_PE = 128, SW_T = 256, SW_U = 512, SW_QV = 576, SW_XHF = 640, SW_RSTDF = 704, SW_HF = 705,
+       SW_DCUR = 769, SW_DU = 833, SW_SP = 897, SW_DQS = 961, SW_DQ = 1025, SW_DK = 1089, SW_DV = 1153, SW_GO = 1217, SW_DH = 1281,
+       SW_BASE = 1288,
+       SL_XH1 = 0, SL_RSTD1 = 64, SL_XH2 = 65, SL_RSTD2 = 129, SL_F = 130, SL_G = 386, SL_RXH1 = 450, SL_RRSTD1 = 514, SL_QH = 515,
+       SL_KH = 579, SL_VH = 643, SL_ML = 707, SL_OUTA = 715, SL_RXH2 = 779, SL_RRSTD2 = 843, SL_F2 = 844, SW_LAYER = 1104 };
+
+static int64_t gnt_row_floats(int depth, int save) { return RW_BASE + (int64_t)(save ? depth : 1) * RW_LAYER; }
+static int64_t gnt_smp_floats(int depth, int save) { return SW_BASE + (int64_t)(save ? depth : 1) * SW_LAYER; }
+
+#define GNT_RAYS_PER_LAUNCH 128
+
+extern "C" int64_t nf_gnt_workspace_floats(int64_t n_rays, int n_samples, int n_views, int depth, int save) {
+    int64_t rays = save ? n_rays : (n_rays < GNT_RAYS_PER_LAUNCH ? n_rays : GNT_RAYS_PER_LAUNCH);
+    if (rays < 1) rays = 1;
+    return rays * ((int64_t)n_samples * n_views * gnt_row_floats(depth, save) + (int64_t)n_samples * gnt_smp_floats(depth, save));
+}
+
+struct GntCtx {
+    const float* __restrict__ blob;
+    const float* __restrict__ rgb_feat;   // this ray [S,V,35]
+    const float* __restrict__ ray_diff;   // [S,V,4]
+    const float* __restrict__ mask;       // [S,V]
+    float* ws_row;
+    float* ws_smp;
+    int S, V, s, depth, save;
+};
+
+#define ROWP(slot) (c.ws_row + ((size_t)(slot) * c.V + v) * c.S + c.s)
+#define ROWSTRIDE ((size_t)c.V * c.S)
+#define ROW(slot, j) ROWP(slot)[(size_t)(j) * ROWSTRIDE]
+#define SMPP(slot) (c.ws_smp + (size_t)(slot) * c.S + c.s)
+#define SMP(slot, j) SMPP(slot)[(size_t)(j) * c.S]
+
+// LayerNorm of the 64 values at SMPP(src): writes xhat to SMPP(xh_slot) (+ rstd) and the affine output to SMPP(dst)
+__device__ __forceinline__ void gnt_layernorm(const GntCtx& c, int src, const float* __restrict__ w, const float* __restrict__ b,
+                                              float eps, int xh_slot, int rstd_slot, int dst) {
+    float mu = 0.f;
+    for (int j = 0; j < 64; ++j) mu += SMP(src, j);
+    mu = mu / 64.f;
+    float var = 0.f;
+    for (int j = 0; j < 64; ++j) {
+        float d = SMP(src, j) - mu;
+        var += d * d;
+    }
+    float rstd = 1.f / sqrtf(var / 64.f + eps);
+    SMP(rstd_slot, 0) = rstd;
+    for (int j = 0; j < 64; ++j) {
+        float xh = (SMP(src, j) - mu) * rstd;
+        SMP(xh_slot, j) = xh;
+        SMP(dst, j) = xh * w[j] + b[j];
+    }
+}
+
+// dx (added into SMPP(dst)) of LayerNorm given dy at SMPP(dy_slot): dx = rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dy w
+__device__ __forceinline__ void gnt_layernorm_bwd_add(const GntCtx& c, int dy_slot, const float* __restrict__ w, int xh_slot,
+                                                      int rstd_slot, int dst) {
+    float m1 = 0.f, m2 = 0.f;
+    for (int j = 0; j < 64; ++j) {
+        float dxh = SMP(dy_slot, j) * w[j];
+        m1 += dxh;
+        m2 += dxh * SMP(xh_slot, j);
+    }
+    m1 = m1 / 64.f;
+    m2 = m2 / 64.f;
+    float rstd = SMP(rstd_slot, 0);
+    for (int j = 0; j < 64; ++j) {
+        float dxh = SMP(dy_slot, j) * w[j];
+        SMP(dst, j) += rstd * (dxh - m1 - SMP(xh_slot, j) * m2);
+    }
+}
+
+// feed-forward 64 -> 256 -> 64 with residual: input y at SMPP(SW_T) (64), hidden saved at SMPP(f_slot) (256), q1 at SMPP(SW_CUR),
+// result written to SMPP(SW_CUR)
+__device__ __forceinline__ void gnt_ff(const GntCtx& c, const float* __restrict__ L, int l1, int l2, int f_slot) {
+    for (int ch = 0; ch < 4; ++ch) {
+        float f[64];
+        nf_load_bias(L + gnt_b(l1) + ch * 64, f);
+        nf_dense_ws_ld<64>(L + gnt_wt(l1) + ch * 64, 256, 64, SMPP(SW_T), (size_t)c.S, f);
+#pragma unroll
+        for (int n = 0; n < 64; ++n) SMP(f_slot, ch * 64 + n) = fmaxf(f[n], 0.f);
+    }
+    float o[64];
+    nf_load_bias(L + gnt_b(l2), o);
+    nf_dense_ws<64>(L + gnt_wt(l2), 256, SMPP(f_slot), (size_t)c.S, 1.f, o);
+#pragma unroll
+    for (int n = 0; n < 64; ++n) SMP(SW_CUR, n) += o[n];
+}
+
+// backward of gnt_ff + its LayerNorm: SMPP(SW_DCUR) holds d(q2); adds LN-bwd(F1^T((F2^T d) * relu')) into SMPP(SW_DCUR)
+__device__ __forceinline__ void gnt_ff_bwd(const GntCtx& c, const float* __restrict__ L, int l1, int l2, int f_slot, int ln_idx,
+                                           int xh_slot, int rstd_slot) {
+    for (int ch = 0; ch < 4; ++ch) {
+        float df[64];
+#pragma unroll
+        for (int n = 0; n < 64; ++n) df[n] = 0.f;
+        nf_dense_bwd_ws<64>(L + gnt_w(l2) + ch * 64, 64, 256, SMPP(SW_DCUR), (size_t)c.S, df);
+#pragma unroll
+        for (int n = 0; n < 64; ++n) SMP(SW_T, ch * 64 + n) = SMP(f_slot, ch * 64 + n) > 0.f ? df[n] : 0.f;
+    }
+    float dy[64];
+#pragma unroll
+    for (int n = 0; n < 64; ++n) dy[n] = 0.f;
+    nf_dense_bwd_ws<64>(L + gnt_w(l1), 256, 64, SMPP(SW_T), (size_t)c.S, dy);
+#pragma unroll
+    for (int n = 0; n < 64; ++n) SMP(SW_U, n) = dy[n];
+    gnt_layernorm_bwd_add(c, SW_U, L + gnt_ln_w(ln_idx), xh_slot, rstd_slot, SW_DCUR);
+}
+
+__device__ __forceinline__ float gnt_score(const float* __restrict__ base, size_t S, int k, const float (&q)[16]) {
+    float sc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) sc = fmaf(q[d], base[(size_t)d * S + k], sc);
+    return sc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gnt_fwd(const float* __restrict__ blob, const float* __restrict__ rgb_feat,
+                                                 const float* __restrict__ ray_diff, const float* __restrict__ mask,
+                                                 const float* __restrict__ pts, const float* __restrict__ ray_d, int S, int V,
+                                                 int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
+                                                 int64_t row_floats, int64_t smp_floats) {
+    __shared__ float mean_h[64];
+    const int64_t ray = blockIdx.x;
+    GntCtx c;
+    c.blob = blob; c.S = S; c.V = V; c.s = threadIdx.x; c.depth = depth; c.save = save;
+    c.rgb_feat = rgb_feat + ray * S * V * 35;
+    c.ray_diff = ray_diff + ray * S * V * 4;
+    c.mask = mask + ray * S * V;
+    const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;
+    c.ws_row = ws + ray * per_ray;
+    c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
+    const bool active = c.s < S;
+    if (active) {
+        // ---- stem: X_v = W2 relu(W1 rgb_feat_v + b1) + b2 ; q = max over views (first maximum wins, like torch.max)
+        for (int v = 0; v < V; ++v) {
+            const float* rf = c.rgb_feat + ((size_t)c.s * V + v) * 35;
+            float r1[64];
+            nf_load_bias(blob + 2 * 35 * 64, r1);
+            nf_dense_ws<64>(blob, 35, rf, 1, 1.f, r1);
+#pragma unroll
+            for (int n = 0; n < 64; ++n) ROW(RW_R1, n) = fmaxf(r1[n], 0.f);
+            float x[64];
+            nf_load_bias(blob + GNT_STEM1 + 2 * 64 * 64, x);
+            nf_dense_ws<64>(blob + GNT_STEM1, 64, ROWP(RW_R1), ROWSTRIDE, 1.f, x);
+#pragma unroll
+            for (int n = 0; n < 64; ++n) {
+                ROW(RW_X, n) = x[n];
+                if (v == 0 || x[n] > SMP(SW_CUR, n)) {
+                    SMP(SW_CUR, n) = x[n];
+                    SMP(SW_AMAX, n) = (float)v;
+                }
+            }
+        }
+        // ---- positional encodings of the sample position and of the unit view direction (Embedder, 3 -> 63 each)
+        {
+            const float* p3 = pts + (ray * S + c.s) * 3;
+            const float* d3 = ray_d + ray * 3;
+            float dn = sqrtf(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+            for (int part = 0; part < 2; ++part) {
+                float x[3];
+                for (int a = 0; a < 3; ++a) x[a] = part == 0 ? p3[a] : d3[a] / dn;
+                for (int a = 0; a < 3; ++a) SMP(SW_PE, part * 63 + a) = x[a];
+                float freq = 1.f;
+                for (int k = 0; k < 10; ++k) {
+                    for (int a = 0; a < 3; ++a) {
+                        SMP(SW_PE, part * 63 + 3 + k * 6 + a) = sinf(x[a] * freq);
+                        SMP(SW_PE, part * 63 + 3 + k * 6 + 3 + a) = cosf(x[a] * freq);
+                    }
+                    freq *= 2.f;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < depth; ++i) {
+        const float* L = blob + gnt_layer_base(i);
+        const int ls = SW_BASE + (save ? i : 0) * SW_LAYER;
+        const int lr = RW_BASE + (save ? i : 0) * RW_LAYER;
+        if (active) {
+            // ================= view transformer =================
+            gnt_layernorm(c, SW_CUR, L + gnt_ln_w(0), L + gnt_ln_b(0), 1e-6f, ls + SL_XH1, ls + SL_RSTD1, SW_T);
+            {
+                float Q[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) Q[n] = 0.f;
+                nf_dense_ws<64>(L + gnt_wt(GV_Q), 64, SMPP(SW_T), (size_t)c.S, 1.f, Q);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_QV, n) = Q[n];
+            }
+            float m[64];
+#pragma unroll
+            for (int n = 0; n < 64; ++n) m[n] = -3.0e38f;
+            for (int v = 0; v < V; ++v) {
+                const float* rd = c.ray_diff + ((size_t)c.s * V + v) * 4;
+                const float mk = c.mask[(size_t)c.s * V + v];
+                {
+                    float K[64];
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) K[n] = 0.f;
+                    nf_dense_ws<64>(L + gnt_wt(GV_K), 64, ROWP(RW_X), ROWSTRIDE, 1.f, K);
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) ROW(RW_T, n) = K[n];
+                }
+                float pos[64];
+                {
+                    float h0[8];
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) {
+                        float t = L[gnt_b(GV_POS0) + n];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t = fmaf(L[gnt_wt(GV_POS0) + k * 8 + n], rd[k], t);
+                        h0[n] = fmaxf(t, 0.f);
+                    }
+                    nf_load_bias(L + gnt_b(GV_POS2), pos);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                        for (int n = 0; n < 64; ++n) pos[n] = fmaf(L[gnt_wt(GV_POS2) + k * 64 + n], h0[k], pos[n]);
+                    }
+                }
+                {
+                    float Vv[64];
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) Vv[n] = 0.f;
+                    nf_dense_ws<64>(L + gnt_wt(GV_V), 64, ROWP(RW_T), ROWSTRIDE, 1.f, Vv);
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) {
+                        ROW(lr + RWL_VP, n) = Vv[n] + pos[n];
+                        ROW(RW_T2, n) = ROW(RW_T, n) - SMP(SW_QV, n) + pos[n];      // k - q + pos
+                    }
+                }
+                float h[8];
+                nf_load_bias(L + gnt_b(GV_ATT0), h);
+                nf_dense_ws<8>(L + gnt_wt(GV_ATT0), 64, ROWP(RW_T2), ROWSTRIDE, 1.f, h);
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    h[n] = fmaxf(h[n], 0.f);
+                    ROW(lr + RWL_H, n) = h[n];
+                }
+                float lg[64];
+                nf_load_bias(L + gnt_b(GV_ATT2), lg);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) lg[n] = fmaf(L[gnt_wt(GV_ATT2) + k * 64 + n], h[k], lg[n]);
+                }
+#pragma unroll
+                for (int n = 0; n < 64; ++n) {
+                    float t = mk == 0.f ? -1e9f : lg[n];
+                    ROW(lr + RWL_PROB, n) = t;
+                    m[n] = fmaxf(m[n], t);
+                }
+            }
+            {
+                float sum[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) sum[n] = 0.f;
+                for (int v = 0; v < V; ++v) {
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) {
+                        float e = expf(ROW(lr + RWL_PROB, n) - m[n]);
+                        ROW(lr + RWL_PROB, n) = e;
+                        sum[n] += e;
+                    }
+                }
+                float u[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) u[n] = 0.f;
+                for (int v = 0; v < V; ++v) {
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) {
+                        float pr = ROW(lr + RWL_PROB, n) / sum[n];
+                        ROW(lr + RWL_PROB, n) = pr;
+                        u[n] = fmaf(ROW(lr + RWL_VP, n), pr, u[n]);
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_U, n) = u[n];
+            }
+            {
+                float o[64];
+                nf_load_bias(L + gnt_b(GV_OUT), o);
+                nf_dense_ws<64>(L + gnt_wt(GV_OUT), 64, SMPP(SW_U), (size_t)c.S, 1.f, o);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_CUR, n) += o[n];
+            }
+            gnt_layernorm(c, SW_CUR, L + gnt_ln_w(1), L + gnt_ln_b(1), 1e-6f, ls + SL_XH2, ls + SL_RSTD2, SW_T);
+            gnt_ff(c, L, GV_FF1, GV_FF2, ls + SL_F);
+            // ================= positional MLP on even layers =================
+            if ((i & 1) == 0) {
+                float g[64];
+                nf_load_bias(L + gnt_b(GQ_0), g);
+                nf_dense_ws<64>(L + gnt_wt(GQ_0), 64, SMPP(SW_CUR), (size_t)c.S, 1.f, g);
+                nf_dense_ws<64>(L + gnt_wt(GQ_0) + 64 * 64, 126, SMPP(SW_PE), (size_t)c.S, 1.f, g);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(ls + SL_G, n) = fmaxf(g[n], 0.f);
+                float q3[64];
+                nf_load_bias(L + gnt_b(GQ_2), q3);
+                nf_dense_ws<64>(L + gnt_wt(GQ_2), 64, SMPP(ls + SL_G), (size_t)c.S, 1.f, q3);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_CUR, n) = q3[n];
+            }
+            // ================= ray transformer: projections =================
+            gnt_layernorm(c, SW_CUR, L + gnt_ln_w(2), L + gnt_ln_b(2), 1e-6f, ls + SL_RXH1, ls + SL_RRSTD1, SW_T);
+            for (int which = 0; which < 3; ++which) {
+                float o[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) o[n] = 0.f;
+                nf_dense_ws<64>(L + gnt_wt(GR_Q + which), 64, SMPP(SW_T), (size_t)c.S, 1.f, o);
+                const int slot = ls + (which == 0 ? SL_QH : (which == 1 ? SL_KH : SL_VH));
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(slot, n) = o[n];
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // ================= ray transformer: attention over the S samples, out_fc, FF =================
+            for (int hd = 0; hd < 4; ++hd) {
+                float q[16];
+#pragma unroll
+                for (int d = 0; d < 16; ++d) q[d] = SMP(ls + SL_QH, hd * 16 + d) * 0.25f;     // 1 / sqrt(16)
+                const float* Kb = c.ws_smp + (size_t)(ls + SL_KH + hd * 16) * S;
+                const float* Vb = c.ws_smp + (size_t)(ls + SL_VH + hd * 16) * S;
+                float mx = -3.0e38f;
+                for (int k = 0; k < S; ++k) mx = fmaxf(mx, gnt_score(Kb, (size_t)S, k, q));
+                float l = 0.f, acc[16];
+#pragma unroll
+                for (int d = 0; d < 16; ++d) acc[d] = 0.f;
+                for (int k = 0; k < S; ++k) {
+                    float p = expf(gnt_score(Kb, (size_t)S, k, q) - mx);
+                    l += p;
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) acc[d] = fmaf(p, Vb[(size_t)d * S + k], acc[d]);
+                }
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    float o = acc[d] / l;
+                    SMP(SW_U, hd * 16 + d) = o;
+                    SMP(ls + SL_OUTA, hd * 16 + d) = o;
+                }
+                SMP(ls + SL_ML, hd) = mx;
+                SMP(ls + SL_ML, 4 + hd) = l;
+            }
+            {
+                float o[64];
+                nf_load_bias(L + gnt_b(GR_OUT), o);
+                nf_dense_ws<64>(L + gnt_wt(GR_OUT), 64, SMPP(SW_U), (size_t)c.S, 1.f, o);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_CUR, n) += o[n];
+            }
+            gnt_layernorm(c, SW_CUR, L + gnt_ln_w(3), L + gnt_ln_b(3), 1e-6f, ls + SL_RXH2, ls + SL_RRSTD2, SW_T);
+            gnt_ff(c, L, GR_FF1, GR_FF2, ls + SL_F2);
+        }
+        __syncthreads();
+    }
+    // ---- final LayerNorm (eps 1e-5), mean over the samples, rgb_fc
+    const float* Fp = blob + gnt_layer_base(depth);
+    if (active) gnt_layernorm(c, SW_CUR, Fp, Fp + 64, 1e-5f, SW_XHF, SW_RSTDF, SW_HF);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        const float* col = c.ws_smp + (size_t)(SW_HF + threadIdx.x) * S;
+        for (int k = 0; k < S; ++k) t += col[k];
+        mean_h[threadIdx.x] = t / (float)S;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = Fp[512 + threadIdx.x];
+        for (int j = 0; j < 64; ++j) t = fmaf(Fp[128 + j * 3 + threadIdx.x], mean_h[j], t);
+        rgb_out[ray * 3 + threadIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward (reads the activations saved by the forward with save = 1)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gnt_bwd(const float* __restrict__ blob, const float* __restrict__ ray_diff,
+                                                 const float* __restrict__ mask, const float* __restrict__ d_rgb, int S, int V,
+                                                 int depth, float* __restrict__ d_rgb_feat, float* __restrict__ ws,
+                                                 int64_t row_floats, int64_t smp_floats) {
+    const int64_t ray = blockIdx.x;
+    GntCtx c;
+    c.blob = blob; c.S = S; c.V = V; c.s = threadIdx.x; c.depth = depth; c.save = 1;
+    c.rgb_feat = nullptr;
+    c.ray_diff = ray_diff + ray * S * V * 4;
+    c.mask = mask + ray * S * V;
+    const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;
+    c.ws_row = ws + ray * per_ray;
+    c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
+    const bool active = c.s < S;
+    const float* Fp = blob + gnt_layer_base(depth);
+    if (active) {
+        // ---- rgb_fc, mean over samples, final LayerNorm
+        const float* g = d_rgb + ray * 3;
+        for (int j = 0; j < 64; ++j) {
+            float dm = Fp[320 + j] * g[0] + Fp[320 + 64 + j] * g[1] + Fp[320 + 128 + j] * g[2];
+            SMP(SW_U, j) = dm / (float)S;
+            SMP(SW_DCUR, j) = 0.f;
+        }
+        gnt_layernorm_bwd_add(c, SW_U, Fp, SW_XHF, SW_RSTDF, SW_DCUR);
+        for (int v = 0; v < V; ++v)
+            for (int n = 0; n < 64; ++n) ROW(RW_DX, n) = 0.f;
+    }
+    for (int i = depth - 1; i >= 0; --i) {
+        const float* L = blob + gnt_layer_base(i);
+        const int ls = SW_BASE + i * SW_LAYER;
+        const int lr = RW_BASE + i * RW_LAYER;
+        if (active) {
+            // ================= ray transformer backward, per-sample part =================
+            gnt_ff_bwd(c, L, GR_FF1, GR_FF2, ls + SL_F2, 3, ls + SL_RXH2, ls + SL_RRSTD2);    // SW_DCUR = d q1
+            float d_out[64];
+#pragma unroll
+            for (int n = 0; n < 64; ++n) d_out[n] = 0.f;
+            nf_dense_bwd_ws<64>(L + gnt_w(GR_OUT), 64, 64, SMPP(SW_DCUR), (size_t)c.S, d_out);
+#pragma unroll
+            for (int hd = 0; hd < 4; ++hd) {
+                float D = 0.f;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    SMP(SW_GO, hd * 16 + d) = d_out[hd * 16 + d];
+                    D = fmaf(d_out[hd * 16 + d], SMP(ls + SL_OUTA, hd * 16 + d), D);
+                }
+                SMP(SW_DH, hd) = D;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // ================= attention backward: dQ (as query), dK / dV (as key) =================
+            for (int hd = 0; hd < 4; ++hd) {
+                const float* Qb = c.ws_smp + (size_t)(ls + SL_QH + hd * 16) * S;
+                const float* Kb = c.ws_smp + (size_t)(ls + SL_KH + hd * 16) * S;
+                const float* Vb = c.ws_smp + (size_t)(ls + SL_VH + hd * 16) * S;
+                const float* Gb = c.ws_smp + (size_t)(SW_GO + hd * 16) * S;
+                const float* Mb = c.ws_smp + (size_t)(ls + SL_ML + hd) * S;
+                const float* Lb = c.ws_smp + (size_t)(ls + SL_ML + 4 + hd) * S;
+                const float* Db = c.ws_smp + (size_t)(SW_DH + hd) * S;
+                {
+                    float q[16], go[16], dq[16];
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) {
+                        q[d] = Qb[(size_t)d * S + c.s] * 0.25f;
+                        go[d] = Gb[(size_t)d * S + c.s];
+                        dq[d] = 0.f;
+                    }
+                    float mx = Mb[c.s], rl = 1.f / Lb[c.s], D = Db[c.s];
+                    for (int k = 0; k < S; ++k) {
+                        float p = expf(gnt_score(Kb, (size_t)S, k, q) - mx) * rl;
+                        float dA = gnt_score(Vb, (size_t)S, k, go);
+                        float dS = p * (dA - D);
+#pragma unroll
+                        for (int d = 0; d < 16; ++d) dq[d] = fmaf(dS, Kb[(size_t)d * S + k], dq[d]);
+                    }
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) SMP(SW_DQ, hd * 16 + d) = dq[d] * 0.25f;
+                }
+                {
+                    float kk[16], vv[16], dk[16], dv[16];
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) {
+                        kk[d] = Kb[(size_t)d * S + c.s];
+                        vv[d] = Vb[(size_t)d * S + c.s];
+                        dk[d] = dv[d] = 0.f;
+                    }
+                    for (int qi = 0; qi < S; ++qi) {
+                        float sc = 0.f, dA = 0.f;
+#pragma unroll
+                        for (int d = 0; d < 16; ++d) {
+                            sc = fmaf(Qb[(size_t)d * S + qi] * 0.25f, kk[d], sc);
+                            dA = fmaf(Gb[(size_t)d * S + qi], vv[d], dA);
+                        }
+                        float p = expf(sc - Mb[qi]) / Lb[qi];
+                        float dS = p * (dA - Db[qi]);
+#pragma unroll
+                        for (int d = 0; d < 16; ++d) {
+                            dv[d] = fmaf(p, Gb[(size_t)d * S + qi], dv[d]);
+                            dk[d] = fmaf(dS, Qb[(size_t)d * S + qi] * 0.25f, dk[d]);
+                        }
+                    }
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) {
+                        SMP(SW_DK, hd * 16 + d) = dk[d];
+                        SMP(SW_DV, hd * 16 + d) = dv[d];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (active) {
+            {
+                float dx[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) dx[n] = 0.f;
+                nf_dense_bwd_ws<64>(L + gnt_w(GR_Q), 64, 64, SMPP(SW_DQ), (size_t)c.S, dx);
+                nf_dense_bwd_ws<64>(L + gnt_w(GR_K), 64, 64, SMPP(SW_DK), (size_t)c.S, dx);
+                nf_dense_bwd_ws<64>(L + gnt_w(GR_V), 64, 64, SMPP(SW_DV), (size_t)c.S, dx);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_U, n) = dx[n];
+            }
+            gnt_layernorm_bwd_add(c, SW_U, L + gnt_ln_w(2), ls + SL_RXH1, ls + SL_RRSTD1, SW_DCUR);
+            // ================= positional MLP backward (even layers) =================
+            if ((i & 1) == 0) {
+                float dg[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) dg[n] = 0.f;
+                nf_dense_bwd_ws<64>(L + gnt_w(GQ_2), 64, 64, SMPP(SW_DCUR), (size_t)c.S, dg);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_T, n) = SMP(ls + SL_G, n) > 0.f ? dg[n] : 0.f;
+                float dq[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) dq[n] = 0.f;
+                nf_dense_bwd_ws<64>(L + gnt_w(GQ_0), 64, 190, SMPP(SW_T), (size_t)c.S, dq);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_DCUR, n) = dq[n];
+            }
+            // ================= view transformer backward =================
+            gnt_ff_bwd(c, L, GV_FF1, GV_FF2, ls + SL_F, 1, ls + SL_XH2, ls + SL_RSTD2);      // SW_DCUR = d q1
+            {
+                float du[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) du[n] = 0.f;
+                nf_dense_bwd_ws<64>(L + gnt_w(GV_OUT), 64, 64, SMPP(SW_DCUR), (size_t)c.S, du);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) {
+                    SMP(SW_DU, n) = du[n];
+                    SMP(SW_DQS, n) = 0.f;
+                }
+                float sp[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) sp[n] = 0.f;
+                for (int v = 0; v < V; ++v) {
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) sp[n] = fmaf(ROW(lr + RWL_PROB, n) * ROW(lr + RWL_VP, n), du[n], sp[n]);
+                }
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_SP, n) = sp[n];
+            }
+            for (int v = 0; v < V; ++v) {
+                const float mk = c.mask[(size_t)c.s * V + v];
+                float dl[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) {
+                    float pr = ROW(lr + RWL_PROB, n), du = SMP(SW_DU, n);
+                    dl[n] = mk == 0.f ? 0.f : pr * (ROW(lr + RWL_VP, n) * du - SMP(SW_SP, n));
+                    ROW(RW_T, n) = pr * du;                                   // d Vv
+                }
+                float dh[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int n = 0; n < 64; ++n) t = fmaf(L[gnt_w(GV_ATT2) + n * 8 + j], dl[n], t);
+                    dh[j] = ROW(lr + RWL_H, j) > 0.f ? t : 0.f;
+                }
+                float da[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t = fmaf(L[gnt_w(GV_ATT0) + j * 64 + n], dh[j], t);
+                    da[n] = t;
+                    SMP(SW_DQS, n) += t;
+                }
+                nf_dense_bwd_ws<64>(L + gnt_w(GV_V), 64, 64, ROWP(RW_T), ROWSTRIDE, da);      // d K = d a + Wv^T d Vv
+#pragma unroll
+                for (int n = 0; n < 64; ++n) ROW(RW_T2, n) = da[n];
+                float dx[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) dx[n] = 0.f;
+                nf_dense_bwd_ws<64>(L + gnt_w(GV_K), 64, 64, ROWP(RW_T2), ROWSTRIDE, dx);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) ROW(RW_DX, n) += dx[n];
+            }
+            {
+                float dx[64];
+#pragma unroll
+                for (int n = 0; n < 64; ++n) {
+                    dx[n] = 0.f;
+                    SMP(SW_T, n) = -SMP(SW_DQS, n);                           // d Q = - sum_v d a_v
+                }
+                nf_dense_bwd_ws<64>(L + gnt_w(GV_Q), 64, 64, SMPP(SW_T), (size_t)c.S, dx);
+#pragma unroll
+                for (int n = 0; n < 64; ++n) SMP(SW_U, n) = dx[n];
+            }
+            gnt_layernorm_bwd_add(c, SW_U, L + gnt_ln_w(0), ls + SL_XH1, ls + SL_RSTD1, SW_DCUR);
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    // ---- q0 = max over views routes its gradient to the arg-max view; then the stem
+    for (int n = 0; n < 64; ++n) {
+        int v = (int)SMP(SW_AMAX, n);
+        ROW(RW_DX, n) += SMP(SW_DCUR, n);
+    }
+    for (int v = 0; v < V; ++v) {
+        float dr[64];
+#pragma unroll
+        for (int n = 0; n < 64; ++n) dr[n] = 0.f;
+        nf_dense_bwd_ws<64>(blob + GNT_STEM1 + 64 * 64, 64, 64, ROWP(RW_DX), ROWSTRIDE, dr);
+#pragma unroll
+        for (int n = 0; n < 64; ++n) ROW(RW_T, n) = ROW(RW_R1, n) > 0.f ? dr[n] : 0.f;
+        float df[35];
+#pragma unroll
+        for (int n = 0; n < 35; ++n) df[n] = 0.f;
+        nf_dense_bwd_ws<35>(blob + 35 * 64, 64, 35, ROWP(RW_T), ROWSTRIDE, df);
+        float* o = d_rgb_feat + ((ray * S + c.s) * V + v) * 35;
+#pragma unroll
+        for (int n = 0; n < 35; ++n) o[n] = df[n];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+static int gnt_check(const char* who, int64_t R, int S, int V, int depth) {
+    NF_REQUIRE(R >= 0 && S >= 1 && S <= 256 && V >= 1 && V <= 64 && depth >= 1 && depth <= 16,
+               "%s: need 1 <= S <= 256, 1 <= V <= 64, 1 <= depth <= 16 (got R %lld S %d V %d depth %d)", who, (long long)R, S, V, depth);
+    return 0;
+}
+
+/* rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V], pts [R,S,3], ray_d [R,3] -> rgb [R,3].
+ * save != 0 keeps the activations of ALL rays in `workspace` (nf_gnt_workspace_floats(R,S,V,depth,1)) for nf_gnt_bwd. */
+extern "C" int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+                          const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
+                          float* workspace, nf_stream_t stream) {
+    if (gnt_check("nf_gnt_fwd", n_rays, n_samples, n_views, depth)) return 1;
+    const int S = n_samples, V = n_views;
+    const int threads = ((S + 63) / 64) * 64;
+    const int64_t rf = gnt_row_floats(depth, save), sf = gnt_smp_floats(depth, save);
+    const int64_t per_ray = (int64_t)S * V * rf + (int64_t)S * sf;
+    const int64_t step = save ? n_rays : GNT_RAYS_PER_LAUNCH;
+    for (int64_t r0 = 0; r0 < n_rays; r0 += step) {
+        int64_t nr = n_rays - r0 < step ? n_rays - r0 : step;
+        hipLaunchKernelGGL(k_gnt_fwd, dim3((unsigned)nr), dim3(threads), 0, (hipStream_t)stream, blob, rgb_feat + r0 * S * V * 35,
+                           ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, S, V, depth, save ? 1 : 0,
+                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf);
+        NF_LAUNCH_CHECK("nf_gnt_fwd");
+    }
+    return 0;
+}
+
+/* d_rgb [R,3] -> d_rgb_feat [R,S,V,35]; `workspace` is the buffer a forward with save = 1 filled */
+extern "C" int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays,
+                          int n_samples, int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream) {
+    if (gnt_check("nf_gnt_bwd", n_rays, n_samples, n_views, depth)) return 1;
+    if (n_rays == 0) return 0;
+    const int threads = ((n_samples + 63) / 64) * 64;
+    hipLaunchKernelGGL(k_gnt_bwd, dim3((unsigned)n_rays), dim3(threads), 0, (hipStream_t)stream, blob, ray_diff, mask, d_rgb,
+                       n_samples, n_views, depth, d_rgb_feat, workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1));
+    NF_LAUNCH_CHECK("nf_gnt_bwd");
+    return 0;
+}

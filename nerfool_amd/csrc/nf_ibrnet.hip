@@ -10,6 +10,7 @@
 // ref: ibrnet/mlp_network.py:222-274 (IBRNet.forward), :69-119 (MultiHeadAttention), :23-43 (attention core).
 // The backward follows oracle/ibrnet_manual_bwd.py step by step (d/d rgb_feat only).
 #include "nf_ibrnet.h"
+#include "nf_dense.h"
 
 #include <string.h>
 
@@ -33,36 +34,6 @@ struct IbrCtx {
 #define ROW(slot, j) ROWP(slot)[(size_t)(j) * ROWSTRIDE]
 #define SMPP(slot) (c.ws_smp + (size_t)(slot) * c.S + c.s)
 #define SMP(slot, j) SMPP(slot)[(size_t)(j) * c.S]
-
-// y[n] += sum_k Wt[k][n] * (x[k] * scale), x streamed from the workspace with element stride xstride
-template <int N>
-__device__ __forceinline__ void nf_dense_ws(const float* __restrict__ Wt, int K, const float* x, size_t xstride, float scale,
-                                            float (&y)[N]) {
-    for (int k = 0; k < K; ++k) {
-        float xk = x[(size_t)k * xstride] * scale;
-        const float* wr = Wt + k * N;
-#pragma unroll
-        for (int n = 0; n < N; ++n) y[n] = fmaf(wr[n], xk, y[n]);
-    }
-}
-
-// dx[k] += sum_n W[n][k] * dy[n], dy streamed from the workspace; W rows have leading dimension ldw
-template <int K>
-__device__ __forceinline__ void nf_dense_bwd_ws(const float* __restrict__ W, int N, int ldw, const float* dy, size_t dystride,
-                                                float (&dx)[K]) {
-    for (int n = 0; n < N; ++n) {
-        float g = dy[(size_t)n * dystride];
-        const float* wr = W + n * ldw;
-#pragma unroll
-        for (int k = 0; k < K; ++k) dx[k] = fmaf(wr[k], g, dx[k]);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void nf_load_bias(const float* __restrict__ b, float (&y)[N]) {
-#pragma unroll
-    for (int n = 0; n < N; ++n) y[n] = b[n];
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward, per-sample part (everything except the ray attention).  Stores every activation the backward needs.

@@ -1,0 +1,44 @@
+"""GNTModel container (gnt/model.py:17-123 attribute surface): net_coarse (GNT), net_fine (None with single_net),
+feature_net (ResUNet, single_net => one 32-channel map returned twice), switch_to_eval, start_step, checkpoint loading."""
+import os
+
+import torch
+
+from ..ibrnet.feature_network import ResUNet
+from .transformer_network import GNT
+
+
+class GNTModel(object):
+    def __init__(self, args, load_opt=False, load_scheduler=False, device=None):
+        self.args = args
+        if device is None:
+            device = torch.device('cuda:%d' % getattr(args, 'local_rank', 0))
+        self.device = torch.device(device)
+        if not getattr(args, 'single_net', True):
+            raise NotImplementedError('only single_net = True (the released GNT configurations) is built')
+        self.net_coarse = GNT(args, in_feat_ch=getattr(args, 'coarse_feat_dim', 32), posenc_dim=63, viewenc_dim=63,
+                              ret_alpha=getattr(args, 'ret_alpha', False)).to(self.device)
+        self.net_fine = None
+        self.feature_net = ResUNet(coarse_out_ch=getattr(args, 'coarse_feat_dim', 32), fine_out_ch=getattr(args, 'fine_feat_dim', 32),
+                                   single_net=True).to(self.device)
+        for net in (self.net_coarse, self.feature_net):
+            for p in net.parameters():
+                p.requires_grad_(False)
+        self.start_step = 0
+        ckpt = getattr(args, 'ckpt_path', None)
+        if ckpt and os.path.isfile(ckpt) and not getattr(args, 'no_reload', False):
+            to_load = torch.load(ckpt, map_location=self.device)
+            self.net_coarse.load_state_dict(to_load['net_coarse'])
+            self.feature_net.load_state_dict(to_load['feature_net'])
+            try:
+                self.start_step = int(ckpt[-10:-4])
+            except ValueError:
+                self.start_step = 0
+
+    def switch_to_eval(self):
+        self.net_coarse.eval()
+        self.feature_net.eval()
+
+    def switch_to_train(self):
+        self.net_coarse.train()
+        self.feature_net.train()

@@ -1,0 +1,101 @@
+"""GNT as an nn.Module whose forward and backward are HIP kernels.  The module tree reproduces the parameter names of
+gnt/transformer_network.py:205-268 (rgbfeat_fc, view_crosstrans.N.{attn_norm, ff_norm, ff.fc1/fc2, attn.{q_fc,k_fc,v_fc,
+pos_fc.0/2, attn_fc.0/2, out_fc}}, view_selftrans.N.{...}, q_fcs.N.0/2 on even N, norm, rgb_fc) so that the public GNT
+checkpoints load by key.  Eval-mode semantics (Dropout = identity); the parameters are constants of the attack."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class _FF(nn.Module):
+    def __init__(self, dim, hid):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hid)
+        self.fc2 = nn.Linear(hid, dim)
+
+
+class _ViewAttnParams(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.q_fc = nn.Linear(dim, dim, bias=False)
+        self.k_fc = nn.Linear(dim, dim, bias=False)
+        self.v_fc = nn.Linear(dim, dim, bias=False)
+        self.pos_fc = nn.Sequential(nn.Linear(4, dim // 8), nn.ReLU(), nn.Linear(dim // 8, dim))
+        self.attn_fc = nn.Sequential(nn.Linear(dim, dim // 8), nn.ReLU(), nn.Linear(dim // 8, dim))
+        self.out_fc = nn.Linear(dim, dim)
+
+
+class _RayAttnParams(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.q_fc = nn.Linear(dim, dim, bias=False)
+        self.k_fc = nn.Linear(dim, dim, bias=False)
+        self.v_fc = nn.Linear(dim, dim, bias=False)
+        self.out_fc = nn.Linear(dim, dim)
+
+
+class _TransformerParams(nn.Module):
+    def __init__(self, dim, attn):
+        super().__init__()
+        self.attn_norm = nn.LayerNorm(dim, eps=1e-6)
+        self.ff_norm = nn.LayerNorm(dim, eps=1e-6)
+        self.ff = _FF(dim, dim * 4)
+        self.attn = attn
+
+
+class _GNTFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, depth):
+        need_grad = rgb_feat.requires_grad
+        rgb, ws = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad)
+        ctx.depth = depth
+        ctx.shape = tuple(rgb_feat.shape[:3])
+        ctx.have_ws = ws is not None
+        if ws is not None:
+            ctx.save_for_backward(ray_diff, mask, blob, ws)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        if not ctx.have_ws:
+            raise RuntimeError('GNT forward ran without saved activations (input did not require grad)')
+        ray_diff, mask, blob, ws = ctx.saved_tensors
+        d_rgb_feat = ops.gnt_bwd(blob, ray_diff, mask, d_rgb, ws, ctx.shape, ctx.depth)
+        return d_rgb_feat, None, None, None, None, None, None
+
+
+class GNT(nn.Module):
+    def __init__(self, args, in_feat_ch=32, posenc_dim=3, viewenc_dim=3, ret_alpha=False):
+        super().__init__()
+        if ret_alpha:
+            raise NotImplementedError('ret_alpha (attention-derived depth) is not built; the released configs use False')
+        if args.netwidth != 64 or in_feat_ch != 32:
+            raise ValueError('the HIP GNT kernels are built for netwidth 64 and 32 feature channels')
+        w = args.netwidth
+        self.trans_depth = args.trans_depth
+        self.rgbfeat_fc = nn.Sequential(nn.Linear(in_feat_ch + 3, w), nn.ReLU(), nn.Linear(w, w))
+        self.view_selftrans = nn.ModuleList([_TransformerParams(w, _RayAttnParams(w)) for _ in range(args.trans_depth)])
+        self.view_crosstrans = nn.ModuleList([_TransformerParams(w, _ViewAttnParams(w)) for _ in range(args.trans_depth)])
+        self.q_fcs = nn.ModuleList([
+            nn.Sequential(nn.Linear(w + posenc_dim + viewenc_dim, w), nn.ReLU(), nn.Linear(w, w)) if i % 2 == 0 else nn.Identity()
+            for i in range(args.trans_depth)])
+        if posenc_dim != 63 or viewenc_dim != 63:
+            raise ValueError('positional encodings of 3 + 3*2*10 = 63 dims are built into the kernels')
+        self.posenc_dim, self.viewenc_dim, self.ret_alpha = posenc_dim, viewenc_dim, ret_alpha
+        self.norm = nn.LayerNorm(w)
+        self.rgb_fc = nn.Linear(w, 3)
+        self._blob = None
+        self._blob_key = None
+
+    def _packed(self, device):
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._blob is None or key != self._blob_key:
+            self._blob = ops.pack_gnt_blob(self.state_dict(), self.trans_depth, device)
+            self._blob_key = key
+        return self._blob
+
+    def forward(self, rgb_feat, ray_diff, mask, pts, ray_d):
+        """rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V,1], pts [R,S,3], ray_d [R,3] -> rgb [R,3]"""
+        blob = self._packed(rgb_feat.device)
+        return _GNTFunction.apply(rgb_feat, ray_diff, mask[..., 0], pts.detach(), ray_d.detach(), blob, self.trans_depth)

@@ -76,13 +76,16 @@ def _join(enc, dec):
 
 
 class ResUNet(nn.Module):
-    def __init__(self, encoder='resnet34', coarse_out_ch=32, fine_out_ch=32, norm_layer=None, coarse_only=False):
+    def __init__(self, encoder='resnet34', coarse_out_ch=32, fine_out_ch=32, norm_layer=None, coarse_only=False,
+                 single_net=False):
         super().__init__()
         if encoder != 'resnet34':
             raise ValueError('only the resnet34 encoder of the released IBRNet checkpoints is supported')
-        self.coarse_only = coarse_only
+        # single_net (GNT flavour, gnt/feature_network.py:195-199,314-316): one map of coarse_out_ch channels returned twice
+        self.single_net = single_net
+        self.coarse_only = coarse_only or single_net
         self.coarse_out_ch = coarse_out_ch
-        self.fine_out_ch = 0 if coarse_only else fine_out_ch
+        self.fine_out_ch = 0 if self.coarse_only else fine_out_ch
         out_ch = self.coarse_out_ch + self.fine_out_ch
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False, padding_mode='reflect')
         self.bn1 = _inorm(64)
@@ -95,8 +98,12 @@ class ResUNet(nn.Module):
 
     def forward(self, x):
         frozen = not any(p.requires_grad for p in self.parameters())
-        if CNN_PATH == 'fused' and frozen and not self.coarse_only and (x.is_cuda or ops._lib.emulated()):
+        if CNN_PATH == 'fused' and frozen and (x.is_cuda or ops._lib.emulated()):
             out = _FusedResUNet.apply(x, self)
+            if self.single_net:
+                return out, out
+            if self.coarse_only:
+                return out, None
             return out[:, :self.coarse_out_ch], out[:, -self.fine_out_ch:]
         x = F.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x)
@@ -105,6 +112,8 @@ class ResUNet(nn.Module):
         y = self.iconv3(_join(x2, self.upconv3(x3)))
         y = self.iconv2(_join(x1, self.upconv2(y)))
         out = self.out_conv(y).contiguous(memory_format=torch.channels_last)
+        if self.single_net:
+            return out, out
         if self.coarse_only:
             return out, None
         return out[:, :self.coarse_out_ch], out[:, -self.fine_out_ch:]

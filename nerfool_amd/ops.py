@@ -370,3 +370,49 @@ def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res)
                                                 _ptr(rstd), int(act), int(pad), _ptr(d_res), _ptr(dx), _ptr(scratch), _stream(yp)),
                    'nf_in_act_pad_bwd')
     return dx, d_res
+
+
+def pack_gnt_blob(state, depth, device):
+    """reference GNT state-dict (gnt/transformer_network.py module paths) -> flat blob in the kernels' layout"""
+    import ctypes
+    L = _lib.lib()
+    blob = torch.zeros(L.nf_gnt_blob_floats(depth), dtype=torch.float32)
+    name = ctypes.create_string_buffer(128)
+    off, rows, cols, tr = ctypes.c_int64(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    idx = 0
+    while L.nf_gnt_blob_entry(depth, idx, name, 128, ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols),
+                              ctypes.byref(tr)) == 0:
+        key = name.value.decode()
+        idx += 1
+        if not key:
+            continue
+        t = state[key].detach().to('cpu', torch.float32).reshape(rows.value, cols.value)
+        if tr.value:
+            t = t.t()
+        blob[off.value:off.value + rows.value * cols.value] = t.contiguous().reshape(-1)
+    return blob.to(device)
+
+
+def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save):
+    rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
+    pts, ray_d = _c(pts, 'pts'), _c(ray_d, 'ray_d')
+    R, S, V, F = rgb_feat.shape
+    if F != 35:
+        raise ValueError('GNT expects 3+32 channels per view (got %d)' % F)
+    L = _lib.lib()
+    ws = torch.empty(L.nf_gnt_workspace_floats(R, S, V, depth, int(bool(save))), dtype=torch.float32, device=rgb_feat.device)
+    rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
+    with prof.launch('nf_gnt_fwd', rgb, R=R, S=S, V=V, depth=depth):
+        _lib.check(L.nf_gnt_fwd(_ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V, depth,
+                                int(bool(save)), _ptr(rgb), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd')
+    return rgb, (ws if save else None)
+
+
+def gnt_bwd(blob, ray_diff, mask, d_rgb, ws, shape, depth):
+    R, S, V = shape
+    ray_diff, mask, d_rgb = _c(ray_diff, 'ray_diff'), _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
+    d_rgb_feat = torch.empty(R, S, V, 35, dtype=torch.float32, device=d_rgb.device)
+    with prof.launch('nf_gnt_bwd', d_rgb, R=R, S=S, V=V, depth=depth):
+        _lib.check(_lib.lib().nf_gnt_bwd(_ptr(blob), _ptr(ray_diff), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat),
+                                         _ptr(ws), _stream(d_rgb)), 'nf_gnt_bwd')
+    return d_rgb_feat

@@ -387,3 +387,56 @@ def check_fused_resunet(dev, size=(96, 128)):
         err = float((a - b).norm() / a.norm())
         assert err < (5e-3 if i == 2 else 1e-4), 'fused ResUNet %s: relative L2 error %.3e' % (name, err)
     assert res['fused'][0].stride(1) == 1, 'feature maps must come out channels-last'
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GNT flavour
+# ------------------------------------------------------------------------------------------------------------------
+def make_gnt(g, depth, dev):
+    from nerfool_amd.gnt.transformer_network import GNT
+    net = GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63)
+    net.load_state_dict(g.params('net'), strict=True)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    return net.to(dev).eval()
+
+
+def check_gnt(case, dev):
+    """GNT network forward + backward (d/d rgb_feat) and the GNT render_rays + unmasked MSE + gradient to the feature map
+    against the reference's capture."""
+    from nerfool_amd.gnt.criterion import Criterion as GntCriterion
+    from nerfool_amd.gnt.render_ray import render_rays as gnt_render_rays
+    from oracle import gnt_ref as gr
+    g = Golden(case)
+    H, W, V, R, S, depth, Hf, Wf = [int(x) for x in g.np('cfg')]
+    net = make_gnt(g, depth, dev)
+    ins = [g.t('net_in/' + k, dev) for k in ('rgb_feat', 'ray_diff', 'mask', 'pts')] + [g.t('in/ray_d', dev)]
+    with torch.no_grad():
+        rgb = net(*ins)
+    ref_rgb = g.np('rgb')
+    assert_close(rgb, ref_rgb, 1e-3, 1e-3 * float(np.abs(ref_rgb).max()), 'GNT rgb (no-grad path)')
+    # backward w.r.t. rgb_feat against autograd of the oracle
+    p = g.params('net')
+    x_cpu = g.t('net_in/rgb_feat').requires_grad_(True)
+    o = gr.gnt_forward(p, x_cpu, g.t('net_in/ray_diff'), g.t('net_in/mask'), g.t('net_in/pts'), g.t('in/ray_d'), depth)
+    d_rgb = torch.randn(o.shape, generator=torch.Generator().manual_seed(4))
+    ref_grad, = torch.autograd.grad(o, x_cpu, d_rgb)
+    x = ins[0].clone().requires_grad_(True)
+    out = net(x, *ins[1:])
+    assert_close(out, ref_rgb, 1e-3, 1e-3 * float(np.abs(ref_rgb).max()), 'GNT rgb (saving path)')
+    mine, = torch.autograd.grad(out, x, d_rgb.to(dev))
+    assert_close(mine, ref_grad, 5e-3, 1e-3 * float(ref_grad.abs().max()), 'GNT d rgb / d rgb_feat', frac_ok=1e-3)
+    # renderer + loss + gradient to the feature map
+    fm = g.t('in/featmap', dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rb = {'ray_o': g.t('in/ray_o', dev), 'ray_d': g.t('in/ray_d', dev), 'rgb': g.t('in/gt_rgb', dev),
+          'camera': g.t('in/camera', dev), 'depth_range': g.t('in/depth_range', dev), 'src_rgbs': g.t('in/src_rgbs', dev),
+          'src_cameras': g.t('in/src_cameras', dev)}
+    ret = gnt_render_rays(rb, SimpleNamespace(net_coarse=net, net_fine=None), (fm, fm), Projector(dev), S, inv_uniform=True,
+                          det=True)
+    assert ret['outputs_fine'] is None and ret['outputs_coarse']['weights'] is None
+    assert_close(ret['outputs_coarse']['rgb'], ref_rgb, 1e-3, 1e-3 * float(np.abs(ref_rgb).max()), 'GNT render_rays rgb')
+    loss, _ = GntCriterion()(ret['outputs_coarse'], rb)
+    assert_close(loss, g.np('loss'), 1e-3, 1e-6, 'GNT loss')
+    grad, = torch.autograd.grad(loss, fm)
+    gref = g.np('grad/featmap')
+    assert_close(grad, gref, 1e-2, 2e-3 * float(np.abs(gref).max()), 'GNT d loss / d featmap', frac_ok=2e-3)

@@ -69,6 +69,11 @@ def test_hybrid_and_sample_pdf():
     pc.check_hybrid_and_sample_pdf('cuda')
 
 
+@pytest.mark.parametrize('case', ['gnt_tiny_d2_v4', 'gnt_tiny_d3_v5'])
+def test_gnt(case):
+    pc.check_gnt(case, 'cuda')
+
+
 def test_render_single_image():
     pc.check_render_single_image('cuda')
 

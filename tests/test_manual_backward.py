@@ -25,3 +25,21 @@ def test_manual_backward_matches_autograd(case):
     assert_close(raw2, raw, 1e-5, 1e-6, 'forward_saved')
     mine = mb.backward_rgb_feat(p, sv, d_raw)
     assert_close(mine, ref, 1e-3, 1e-5 * float(ref.abs().max()), 'manual d rgb_feat')
+
+
+@pytest.mark.parametrize('case', ['gnt_tiny_d2_v4', 'gnt_tiny_d3_v5'])
+def test_gnt_manual_backward_matches_autograd(case):
+    from oracle import gnt_manual_bwd as gmb
+    from oracle import gnt_ref as gr
+    g = Golden(case)
+    depth = int(g.np('cfg')[5])
+    p = g.params('net')
+    rgb_feat = g.t('net_in/rgb_feat').requires_grad_(True)
+    args = (g.t('net_in/ray_diff'), g.t('net_in/mask'), g.t('net_in/pts'), g.t('in/ray_d'))
+    rgb = gr.gnt_forward(p, rgb_feat, *args, depth)
+    d_rgb = torch.randn(rgb.shape, generator=torch.Generator().manual_seed(4))
+    ref, = torch.autograd.grad(rgb, rgb_feat, d_rgb)
+    rgb2, sv = gmb.forward_saved(p, rgb_feat.detach(), *args, depth)
+    assert_close(rgb2, rgb, 1e-5, 1e-6, 'GNT forward_saved')
+    mine = gmb.backward_rgb_feat(p, sv, args[1], d_rgb, depth)
+    assert_close(mine, ref, 1e-3, 1e-5 * float(ref.abs().max()), 'GNT manual d rgb_feat')
