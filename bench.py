@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--samples', type=int, default=64)
     ap.add_argument('--importance', type=int, default=64)
     ap.add_argument('--render-chunks', type=int, default=4, help='4096-ray chunks for the render-throughput leg (0 = skip)')
+    ap.add_argument('--model', choices=('ibrnet', 'gnt'), default='ibrnet',
+                    help="'gnt' = BASELINE config 4 (GNT depth 8, 800x800, 10 views, 64 samples) -- not the headline line")
+    ap.add_argument('--depth', type=int, default=8, help='GNT trans_depth')
     ap.add_argument('--cpu-iters', type=int, default=2, help='timed CPU-oracle PGD iterations for cpu_baseline (0 = skip)')
     return ap.parse_args()
 
@@ -63,11 +66,18 @@ def build_problem(a, dev):
                            lr_step_size=100, lr_gamma=1.0, adv_iters=1000, local_rank=0, coarse_only=False, ckpt_path=None,
                            sample_mode='uniform', center_ratio=0.8, chunk_size=4096)
     torch.manual_seed(0)
-    data = make_scene(a.height, a.width, a.views, seed=0)
-    model = IBRNetModel(args, device=dev)
-    with torch.no_grad():
-        for net in (model.net_coarse, model.net_fine):
-            net.out_geometry_fc[2].bias += 1.0      # random-init weights: keep sigma / alpha / T non-trivial
+    if a.model == 'gnt':
+        from nerfool_amd.gnt.model import GNTModel
+        args.netwidth, args.trans_depth, args.single_net, args.ret_alpha = 64, a.depth, True, False
+        args.N_importance = 0
+        data = make_scene(a.height, a.width, a.views, seed=0, blender=True)
+        model = GNTModel(args, device=dev)
+    else:
+        data = make_scene(a.height, a.width, a.views, seed=0)
+        model = IBRNetModel(args, device=dev)
+        with torch.no_grad():
+            for net in (model.net_coarse, model.net_fine):
+                net.out_geometry_fc[2].bias += 1.0      # random-init weights: keep sigma / alpha / T non-trivial
     model.switch_to_eval()
     sampler = RaySamplerSingleImage(data, dev)
     src_ray_batch = sampler.get_all()
@@ -107,6 +117,10 @@ def cpu_baseline(a, args, data, model):
 
 def main():
     a = parse()
+    if a.model == 'gnt':          # config 4 defaults unless the user overrode the sizes
+        if (a.height, a.width, a.views) == (756, 1008, 4):
+            a.height, a.width, a.views = 800, 800, 10
+        a.importance, a.render_chunks, a.cpu_iters = 0, 0, 0
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -190,6 +204,10 @@ def main():
             elif name == 'nf_project_gather_bwd':
                 b = meta['n_pts'] * meta['V'] * ((3 + meta['C']) * 4 + 4 * meta['C'] * 4)
                 per_launch.append(('hbm', b / (ms * 1e-3) / 1e9))
+            elif name in ('nf_gnt_fwd', 'nf_gnt_bwd'):
+                fl = 2.0 * meta['R'] * meta['S'] * (meta['V'] * (6336 + meta['depth'] * 9760)
+                                                    + meta['depth'] * 98304 + ((meta['depth'] + 1) // 2) * 16256)
+                per_launch.append(('mfma', fl / (ms * 1e-3) / 1e12))
             elif name == 'nf_pgd_adam_step':
                 per_launch.append(('hbm', meta['n'] * 32 / (ms * 1e-3) / 1e9))
         if per_launch:
@@ -208,15 +226,18 @@ def main():
 
     rays_per_step = a.n_rand * world
     out = {
-        'metric': 'rays/s through the IBRNet PGD attack step (render fwd+bwd + CNN fwd+bwd + delta update), 4 src views',
+        'metric': 'rays/s through the %s PGD attack step (render fwd+bwd + CNN fwd+bwd + delta update), %d src views'
+                  % ('IBRNet' if a.model == 'ibrnet' else 'GNT', a.views),
         'value': rays_per_step * a.steps / elapsed,
         'unit': 'rays/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': 1e3 * elapsed / a.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE config 2: IBRNet view-specific attack, LLFF-fern-shaped synthetic scene %dx%d, %d source '
-                               'views, %d+%d samples/ray, N_rand=%d rays per rank per step, Adam lr 1e-3, eps 8/255'
-                               % (a.height, a.width, V, Sc, a.importance, a.n_rand),
+        'config': {'workload': ('BASELINE config 2: IBRNet view-specific attack, LLFF-fern-shaped synthetic scene %dx%d, %d source '
+                                'views, %d+%d samples/ray, N_rand=%d rays per rank per step, Adam lr 1e-3, eps 8/255'
+                                % (a.height, a.width, V, Sc, a.importance, a.n_rand)) if a.model == 'ibrnet' else
+                               ('BASELINE config 4: GNT depth %d view-specific attack, synthetic scene %dx%d, %d source views, %d '
+                                'samples/ray, N_rand=%d rays per rank per step' % (a.depth, a.height, a.width, V, Sc, a.n_rand)),
                    'rays_per_step_all_ranks': rays_per_step, 'parallelism': 'ray-sharded dp%d' % world},
         'roofline': roofline,
         'cpu_baseline': None,

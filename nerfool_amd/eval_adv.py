@@ -44,8 +44,13 @@ def init_adv_perturb(args, src_ray_batch, epsilon, upper_limit, lower_limit):
     return delta
 
 
+def _is_gnt(model):
+    from .gnt.transformer_network import GNT
+    return isinstance(getattr(model, 'net_coarse', None), GNT)
+
+
 def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, return_loss=True, select_inds=None,
-                         shard=None):
+                         shard=None, criterion=None):
     """One loss evaluation of the attack (eval_adv.py:258-310,512-519): draw N_rand rays of the target view `data`,
     features from the PERTURBED source images, colours from the CLEAN ones, masked MSE on coarse + fine.
 
@@ -63,16 +68,25 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
             select_inds = select_inds[shard.rank::shard.world]
     train_ray_batch = sampler.select(select_inds)
     featmaps = model.feature_net((src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
-    ret = render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
-                      N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
-                      det=getattr(args, 'det', True), white_bkgd=args.white_bkgd, args=args, src_ray_batch=src_ray_batch)
+    if _is_gnt(model):      # eval/gnt/eval_adv.py:319-333: GNT renderer, criterion passed in (unmasked MSE)
+        from .gnt.criterion import Criterion as GntCriterion
+        from .gnt.render_ray import render_rays as gnt_render_rays
+        crit = criterion if criterion is not None else GntCriterion()
+        ret = gnt_render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
+                              N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
+                              det=getattr(args, 'det', True), white_bkgd=args.white_bkgd,
+                              ret_alpha=getattr(args, 'ret_alpha', False), args=args, src_ray_batch=src_ray_batch)
+    else:
+        crit = criterion if criterion is not None else globals()['criterion']
+        ret = render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
+                          N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
+                          det=getattr(args, 'det', True), white_bkgd=args.white_bkgd, args=args, src_ray_batch=src_ray_batch)
     counts = None
     if shard is not None:
         counts = shard.global_mask_counts(ret)
-    loss_rgb, _ = criterion(ret['outputs_coarse'], train_ray_batch, None,
-                            None if counts is None else counts[0:1])
+    loss_rgb, _ = crit(ret['outputs_coarse'], train_ray_batch, None, None if counts is None else counts[0:1])
     if ret['outputs_fine'] is not None:
-        fine_loss, _ = criterion(ret['outputs_fine'], train_ray_batch, None, None if counts is None else counts[1:2])
+        fine_loss, _ = crit(ret['outputs_fine'], train_ray_batch, None, None if counts is None else counts[1:2])
         loss_rgb = loss_rgb + fine_loss
     total_loss = {'rgb': loss_rgb}
     loss = loss_rgb
@@ -95,8 +109,12 @@ class RayShard:
         self.world = dist.get_world_size(group)
 
     def global_mask_counts(self, ret):
-        c = ret['outputs_coarse']['mask'].sum(dtype=torch.float32).reshape(1)
-        f = ret['outputs_fine']['mask'].sum(dtype=torch.float32).reshape(1) if ret['outputs_fine'] is not None else c
+        def count(o):       # masked MSE counts the valid rays, the unmasked one (GNT) every ray
+            if 'mask' in o and o['mask'] is not None:
+                return o['mask'].sum(dtype=torch.float32).reshape(1)
+            return torch.full((1,), float(o['rgb'].shape[0]), dtype=torch.float32, device=o['rgb'].device)
+        c = count(ret['outputs_coarse'])
+        f = count(ret['outputs_fine']) if ret['outputs_fine'] is not None else c
         counts = torch.cat([c, f])
         self.dist.all_reduce(counts, op=self.dist.ReduceOp.SUM, group=self.group)
         return counts

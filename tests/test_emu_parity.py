@@ -82,6 +82,10 @@ def test_gnt(case):
     pc.check_gnt(case, 'cpu')
 
 
+def test_gnt_attack_step():
+    pc.check_gnt_attack_step('cpu')
+
+
 def test_render_single_image():
     pc.check_render_single_image('cpu', rows=4)
 

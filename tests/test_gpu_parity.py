@@ -74,6 +74,10 @@ def test_gnt(case):
     pc.check_gnt(case, 'cuda')
 
 
+def test_gnt_attack_step():
+    pc.check_gnt_attack_step('cuda')
+
+
 def test_render_single_image():
     pc.check_render_single_image('cuda')
 
