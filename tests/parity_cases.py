@@ -437,6 +437,13 @@ def check_gnt(case, dev):
     assert_close(ret['outputs_coarse']['rgb'], ref_rgb, 1e-3, 1e-3 * float(np.abs(ref_rgb).max()), 'GNT render_rays rgb')
     loss, _ = GntCriterion()(ret['outputs_coarse'], rb)
     assert_close(loss, g.np('loss'), 1e-3, 1e-6, 'GNT loss')
+    # chunked full-"image" render of the same rays (a 1 x R strip): same colours, host tensors, None entries preserved
+    from nerfool_amd.gnt.render_image import render_single_image as gnt_render_image
+    img = gnt_render_image(SimpleNamespace(H=1, W=R), rb, SimpleNamespace(net_coarse=net, net_fine=None), Projector(dev), 5, S,
+                           inv_uniform=True, det=True, featmaps=(fm.detach(), fm.detach()), single_net=True)
+    assert img['outputs_fine'] is None and img['outputs_coarse']['weights'] is None
+    assert img['outputs_coarse']['rgb'].device.type == 'cpu'
+    assert_close(img['outputs_coarse']['rgb'], ref_rgb, 1e-3, 1e-3 * float(np.abs(ref_rgb).max()), 'GNT render_single_image rgb')
     grad, = torch.autograd.grad(loss, fm)
     gref = g.np('grad/featmap')
     assert_close(grad, gref, 1e-2, 2e-3 * float(np.abs(gref).max()), 'GNT d loss / d featmap', frac_ok=2e-3)
