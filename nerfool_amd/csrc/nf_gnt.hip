@@ -3,10 +3,12 @@
 // ref: gnt/transformer_network.py:270-309 (GNT.forward, ret_alpha = False, eval mode), :55-89, :93-113, :121-171, :175-202.
 // The backward follows oracle/gnt_manual_bwd.py.
 //
-// Shape-generic kernels in the style of nf_ibrnet.hip: one workgroup per ray, one thread per sample, the thread walks the
-// V views serially; activations stream through a per-ray global workspace [slot][view][sample] / [slot][sample] (sample
-// fastest => coalesced), weights are read with wave-uniform addresses.  With SAVE the forward keeps every activation the
-// backward needs (one slot set per layer), otherwise one slot set is recycled.
+// Shape-generic kernels (any V, S <= 256, any depth): one workgroup per ray, FOUR lanes per sample -- each lane owns a
+// 16-channel slice of every 64-wide vector and one of the four attention heads -- and walks the V views serially.
+// Vectors are exchanged through a per-ray global workspace [slot][view][sample] / [slot][sample] (sample fastest =>
+// coalesced; L2-resident), so every stage ends with a workgroup barrier; weights are read with wave-uniform addresses
+// (scalar loads).  With `save` the forward keeps every activation the backward needs (one slot set per layer), otherwise
+// one slot set is recycled.
 #include "nf_dense.h"
 
 #include <stdio.h>
@@ -114,7 +116,7 @@ extern "C" int nf_gnt_blob_entry(int depth, int idx, char* name, int name_cap, i
 // ---------------------------------------------------------------------------------------------------------------
 // workspace slots
 // ---------------------------------------------------------------------------------------------------------------
-enum { RW_R1 = 0, RW_X = 64, RW_DX = 128, RW_T = 192, RW_T2 = 256, RW_BASE = 320, RWL_VP = 0, RWL_H = 64, RWL_PROB = 72, RW_LAYER = 136 };
+enum { RW_R1 = 0, RW_X = 64, RW_DX = 128, RW_T = 192, RW_T2 = 256, RW_T3 = 320, RW_R1H = 384, RW_BASE = 392, RWL_VP = 0, RWL_H = 64, RWL_PROB = 72, RW_LAYER = 136 };
 enum { SW_AMAX = 0, SW_CUR = 64, SW_PE = 128, SW_T = 256, SW_U = 512, SW_QV = 576, SW_XHF = 640, SW_RSTDF = 704, SW_HF = 705,
        SW_DCUR = 769, SW_DU = 833, SW_SP = 897, SW_DQS = 961, SW_DQ = 1025, SW_DK = 1089, SW_DV = 1153, SW_GO = 1217, SW_DH = 1281,
        SW_BASE = 1288,
@@ -139,8 +141,14 @@ struct GntCtx {
     const float* __restrict__ mask;       // [S,V]
     float* ws_row;
     float* ws_smp;
-    int S, V, s, depth, save;
+    int S, V, s, part, P0;                // sample, lane-part (0..3) and its 16-channel slice offset
 };
+
+// Four lanes cooperate on one sample: each owns a 16-channel slice of every 64-wide vector (and one attention head).
+// Vectors are exchanged through the workspace, so every stage ends with a workgroup barrier; all threads run every stage.
+#define GNT_PARTS 4
+#define STAGE_BEGIN if (act) {
+#define STAGE_END } __syncthreads();
 
 #define ROWP(slot) (c.ws_row + ((size_t)(slot) * c.V + v) * c.S + c.s)
 #define ROWSTRIDE ((size_t)c.V * c.S)
@@ -148,9 +156,24 @@ struct GntCtx {
 #define SMPP(slot) (c.ws_smp + (size_t)(slot) * c.S + c.s)
 #define SMP(slot, j) SMPP(slot)[(size_t)(j) * c.S]
 
-// LayerNorm of the 64 values at SMPP(src): writes xhat to SMPP(xh_slot) (+ rstd) and the affine output to SMPP(dst)
-__device__ __forceinline__ void gnt_layernorm(const GntCtx& c, int src, const float* __restrict__ w, const float* __restrict__ b,
-                                              float eps, int xh_slot, int rstd_slot, int dst) {
+// y[j] (j < 16) = bias[P0 + j] + sum_k Wt[k][col0 + j] x[k]   (Wt has leading dimension ld)
+__device__ __forceinline__ void gnt_slice(const float* __restrict__ Wt, int ld, int col0, const float* __restrict__ bias, int K,
+                                          const float* x, size_t xstride, float (&y)[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) y[j] = bias ? bias[col0 + j] : 0.f;
+    nf_dense_ws_ld<16>(Wt + col0, ld, K, x, xstride, y);
+}
+
+// dx[j] (j < 16) += sum_n W[n][col0 + j] dy[n]   (W native [N][ldw])
+__device__ __forceinline__ void gnt_slice_bwd(const float* __restrict__ W, int N, int ldw, int col0, const float* dy, size_t dystride,
+                                              float (&dx)[16]) {
+    nf_dense_bwd_ws<16>(W + col0, N, ldw, dy, dystride, dx);
+}
+
+// LayerNorm over the 64 channels at SMPP(src): every part recomputes the statistics, writes ITS slice of xhat and of the
+// affine output (dst); part 0 stores rstd.  Needs a barrier before (src complete) and after.
+__device__ __forceinline__ void gnt_ln_slice(const GntCtx& c, int src, const float* __restrict__ w, const float* __restrict__ b,
+                                             float eps, int xh_slot, int rstd_slot, int dst) {
     float mu = 0.f;
     for (int j = 0; j < 64; ++j) mu += SMP(src, j);
     mu = mu / 64.f;
@@ -160,17 +183,17 @@ __device__ __forceinline__ void gnt_layernorm(const GntCtx& c, int src, const fl
         var += d * d;
     }
     float rstd = 1.f / sqrtf(var / 64.f + eps);
-    SMP(rstd_slot, 0) = rstd;
-    for (int j = 0; j < 64; ++j) {
+    if (c.part == 0) SMP(rstd_slot, 0) = rstd;
+    for (int j = c.P0; j < c.P0 + 16; ++j) {
         float xh = (SMP(src, j) - mu) * rstd;
         SMP(xh_slot, j) = xh;
         SMP(dst, j) = xh * w[j] + b[j];
     }
 }
 
-// dx (added into SMPP(dst)) of LayerNorm given dy at SMPP(dy_slot): dx = rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dy w
-__device__ __forceinline__ void gnt_layernorm_bwd_add(const GntCtx& c, int dy_slot, const float* __restrict__ w, int xh_slot,
-                                                      int rstd_slot, int dst) {
+// dst slice += rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dy w; dy at SMPP(dy_slot) must be complete (barrier before)
+__device__ __forceinline__ void gnt_ln_bwd_slice(const GntCtx& c, int dy_slot, const float* __restrict__ w, int xh_slot,
+                                                 int rstd_slot, int dst) {
     float m1 = 0.f, m2 = 0.f;
     for (int j = 0; j < 64; ++j) {
         float dxh = SMP(dy_slot, j) * w[j];
@@ -180,47 +203,10 @@ __device__ __forceinline__ void gnt_layernorm_bwd_add(const GntCtx& c, int dy_sl
     m1 = m1 / 64.f;
     m2 = m2 / 64.f;
     float rstd = SMP(rstd_slot, 0);
-    for (int j = 0; j < 64; ++j) {
+    for (int j = c.P0; j < c.P0 + 16; ++j) {
         float dxh = SMP(dy_slot, j) * w[j];
         SMP(dst, j) += rstd * (dxh - m1 - SMP(xh_slot, j) * m2);
     }
-}
-
-// feed-forward 64 -> 256 -> 64 with residual: input y at SMPP(SW_T) (64), hidden saved at SMPP(f_slot) (256), q1 at SMPP(SW_CUR),
-// result written to SMPP(SW_CUR)
-__device__ __forceinline__ void gnt_ff(const GntCtx& c, const float* __restrict__ L, int l1, int l2, int f_slot) {
-    for (int ch = 0; ch < 4; ++ch) {
-        float f[64];
-        nf_load_bias(L + gnt_b(l1) + ch * 64, f);
-        nf_dense_ws_ld<64>(L + gnt_wt(l1) + ch * 64, 256, 64, SMPP(SW_T), (size_t)c.S, f);
-#pragma unroll
-        for (int n = 0; n < 64; ++n) SMP(f_slot, ch * 64 + n) = fmaxf(f[n], 0.f);
-    }
-    float o[64];
-    nf_load_bias(L + gnt_b(l2), o);
-    nf_dense_ws<64>(L + gnt_wt(l2), 256, SMPP(f_slot), (size_t)c.S, 1.f, o);
-#pragma unroll
-    for (int n = 0; n < 64; ++n) SMP(SW_CUR, n) += o[n];
-}
-
-// backward of gnt_ff + its LayerNorm: SMPP(SW_DCUR) holds d(q2); adds LN-bwd(F1^T((F2^T d) * relu')) into SMPP(SW_DCUR)
-__device__ __forceinline__ void gnt_ff_bwd(const GntCtx& c, const float* __restrict__ L, int l1, int l2, int f_slot, int ln_idx,
-                                           int xh_slot, int rstd_slot) {
-    for (int ch = 0; ch < 4; ++ch) {
-        float df[64];
-#pragma unroll
-        for (int n = 0; n < 64; ++n) df[n] = 0.f;
-        nf_dense_bwd_ws<64>(L + gnt_w(l2) + ch * 64, 64, 256, SMPP(SW_DCUR), (size_t)c.S, df);
-#pragma unroll
-        for (int n = 0; n < 64; ++n) SMP(SW_T, ch * 64 + n) = SMP(f_slot, ch * 64 + n) > 0.f ? df[n] : 0.f;
-    }
-    float dy[64];
-#pragma unroll
-    for (int n = 0; n < 64; ++n) dy[n] = 0.f;
-    nf_dense_bwd_ws<64>(L + gnt_w(l1), 256, 64, SMPP(SW_T), (size_t)c.S, dy);
-#pragma unroll
-    for (int n = 0; n < 64; ++n) SMP(SW_U, n) = dy[n];
-    gnt_layernorm_bwd_add(c, SW_U, L + gnt_ln_w(ln_idx), xh_slot, rstd_slot, SW_DCUR);
 }
 
 __device__ __forceinline__ float gnt_score(const float* __restrict__ base, size_t S, int k, const float (&q)[16]) {
@@ -230,251 +216,253 @@ __device__ __forceinline__ float gnt_score(const float* __restrict__ base, size_
     return sc;
 }
 
+#define GNT_SETUP()                                                                                   \
+    const int64_t ray = blockIdx.x;                                                                   \
+    const int Sp = blockDim.x / GNT_PARTS;                                                            \
+    GntCtx c;                                                                                         \
+    c.blob = blob; c.S = S; c.V = V; c.part = threadIdx.x / Sp; c.s = threadIdx.x - c.part * Sp; c.P0 = c.part * 16; \
+    c.ray_diff = ray_diff + ray * S * V * 4;                                                          \
+    c.mask = mask + ray * S * V;                                                                      \
+    const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;                      \
+    c.ws_row = ws + ray * per_ray;                                                                    \
+    c.ws_smp = c.ws_row + (size_t)S * V * row_floats;                                                \
+    const bool act = c.s < S;                                                                         \
+    const int P0 = c.P0;
+
+// ---- shared stages -------------------------------------------------------------------------------------------------
+// feed-forward 64 -> 256 -> 64 with residual: y at SW_T, hidden saved at f_slot, CUR += FF(y).  Two barriers inside.
+#define GNT_FF(L, l1, l2, f_slot)                                                                              \
+    STAGE_BEGIN                                                                                                \
+    for (int ch = 0; ch < 4; ++ch) {                                                                           \
+        float f[16];                                                                                           \
+        gnt_slice((L) + gnt_wt(l1), 256, ch * 64 + P0, (L) + gnt_b(l1), 64, SMPP(SW_T), (size_t)c.S, f);       \
+        for (int j = 0; j < 16; ++j) SMP(f_slot, ch * 64 + P0 + j) = fmaxf(f[j], 0.f);                         \
+    }                                                                                                          \
+    STAGE_END                                                                                                  \
+    STAGE_BEGIN                                                                                                \
+    float o[16];                                                                                               \
+    gnt_slice((L) + gnt_wt(l2), 64, P0, (L) + gnt_b(l2), 256, SMPP(f_slot), (size_t)c.S, o);                   \
+    for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j];                                                  \
+    STAGE_END
+
+// backward of FF + its LayerNorm: DCUR holds d(q2) on entry, d(q1) on exit
+#define GNT_FF_BWD(L, l1, l2, f_slot, ln_idx, xh_slot, rstd_slot)                                              \
+    STAGE_BEGIN                                                                                                \
+    for (int ch = 0; ch < 4; ++ch) {                                                                           \
+        float df[16];                                                                                          \
+        for (int j = 0; j < 16; ++j) df[j] = 0.f;                                                              \
+        gnt_slice_bwd((L) + gnt_w(l2), 64, 256, ch * 64 + P0, SMPP(SW_DCUR), (size_t)c.S, df);                 \
+        for (int j = 0; j < 16; ++j) SMP(SW_T, ch * 64 + P0 + j) = SMP(f_slot, ch * 64 + P0 + j) > 0.f ? df[j] : 0.f; \
+    }                                                                                                          \
+    STAGE_END                                                                                                  \
+    STAGE_BEGIN                                                                                                \
+    float dy[16];                                                                                              \
+    for (int j = 0; j < 16; ++j) dy[j] = 0.f;                                                                  \
+    gnt_slice_bwd((L) + gnt_w(l1), 256, 64, P0, SMPP(SW_T), (size_t)c.S, dy);                                  \
+    for (int j = 0; j < 16; ++j) SMP(SW_U, P0 + j) = dy[j];                                                    \
+    STAGE_END                                                                                                  \
+    STAGE_BEGIN                                                                                                \
+    gnt_ln_bwd_slice(c, SW_U, (L) + gnt_ln_w(ln_idx), xh_slot, rstd_slot, SW_DCUR);                            \
+    STAGE_END
+
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gnt_fwd(const float* __restrict__ blob, const float* __restrict__ rgb_feat,
-                                                 const float* __restrict__ ray_diff, const float* __restrict__ mask,
-                                                 const float* __restrict__ pts, const float* __restrict__ ray_d, int S, int V,
-                                                 int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
-                                                 int64_t row_floats, int64_t smp_floats) {
+__global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob, const float* __restrict__ rgb_feat_all,
+                                                  const float* __restrict__ ray_diff, const float* __restrict__ mask,
+                                                  const float* __restrict__ pts, const float* __restrict__ ray_d, int S, int V,
+                                                  int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
+                                                  int64_t row_floats, int64_t smp_floats) {
     __shared__ float mean_h[64];
-    const int64_t ray = blockIdx.x;
-    GntCtx c;
-    c.blob = blob; c.S = S; c.V = V; c.s = threadIdx.x; c.depth = depth; c.save = save;
-    c.rgb_feat = rgb_feat + ray * S * V * 35;
-    c.ray_diff = ray_diff + ray * S * V * 4;
-    c.mask = mask + ray * S * V;
-    const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;
-    c.ws_row = ws + ray * per_ray;
-    c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
-    const bool active = c.s < S;
-    if (active) {
-        // ---- stem: X_v = W2 relu(W1 rgb_feat_v + b1) + b2 ; q = max over views (first maximum wins, like torch.max)
-        for (int v = 0; v < V; ++v) {
-            const float* rf = c.rgb_feat + ((size_t)c.s * V + v) * 35;
-            float r1[64];
-            nf_load_bias(blob + 2 * 35 * 64, r1);
-            nf_dense_ws<64>(blob, 35, rf, 1, 1.f, r1);
-#pragma unroll
-            for (int n = 0; n < 64; ++n) ROW(RW_R1, n) = fmaxf(r1[n], 0.f);
-            float x[64];
-            nf_load_bias(blob + GNT_STEM1 + 2 * 64 * 64, x);
-            nf_dense_ws<64>(blob + GNT_STEM1, 64, ROWP(RW_R1), ROWSTRIDE, 1.f, x);
-#pragma unroll
-            for (int n = 0; n < 64; ++n) {
-                ROW(RW_X, n) = x[n];
-                if (v == 0 || x[n] > SMP(SW_CUR, n)) {
-                    SMP(SW_CUR, n) = x[n];
-                    SMP(SW_AMAX, n) = (float)v;
-                }
+    GNT_SETUP()
+    c.rgb_feat = rgb_feat_all + ray * S * V * 35;
+    // ---- stem: X_v = W2 relu(W1 rgb_feat_v + b1) + b2 ; q = max over views (first maximum wins, like torch.max)
+    for (int v = 0; v < V; ++v) {
+        STAGE_BEGIN
+        const float* rf = c.rgb_feat + ((size_t)c.s * V + v) * 35;
+        float r1[16];
+        gnt_slice(blob, 64, P0, blob + 2 * 35 * 64, 35, rf, 1, r1);
+        for (int j = 0; j < 16; ++j) ROW(RW_R1, P0 + j) = fmaxf(r1[j], 0.f);
+        STAGE_END
+        STAGE_BEGIN
+        float x[16];
+        gnt_slice(blob + GNT_STEM1, 64, P0, blob + GNT_STEM1 + 2 * 64 * 64, 64, ROWP(RW_R1), ROWSTRIDE, x);
+        for (int j = 0; j < 16; ++j) {
+            ROW(RW_X, P0 + j) = x[j];
+            if (v == 0 || x[j] > SMP(SW_CUR, P0 + j)) {
+                SMP(SW_CUR, P0 + j) = x[j];
+                SMP(SW_AMAX, P0 + j) = (float)v;
             }
         }
-        // ---- positional encodings of the sample position and of the unit view direction (Embedder, 3 -> 63 each)
-        {
-            const float* p3 = pts + (ray * S + c.s) * 3;
-            const float* d3 = ray_d + ray * 3;
-            float dn = sqrtf(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
-            for (int part = 0; part < 2; ++part) {
-                float x[3];
-                for (int a = 0; a < 3; ++a) x[a] = part == 0 ? p3[a] : d3[a] / dn;
-                for (int a = 0; a < 3; ++a) SMP(SW_PE, part * 63 + a) = x[a];
-                float freq = 1.f;
-                for (int k = 0; k < 10; ++k) {
-                    for (int a = 0; a < 3; ++a) {
-                        SMP(SW_PE, part * 63 + 3 + k * 6 + a) = sinf(x[a] * freq);
-                        SMP(SW_PE, part * 63 + 3 + k * 6 + 3 + a) = cosf(x[a] * freq);
-                    }
-                    freq *= 2.f;
-                }
+        STAGE_END
+    }
+    // ---- positional encodings of the sample position (part 0) and of the unit view direction (part 1): 3 -> 63 each
+    STAGE_BEGIN
+    if (c.part < 2) {
+        const float* p3 = pts + (ray * S + c.s) * 3;
+        const float* d3 = ray_d + ray * 3;
+        float dn = sqrtf(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+        float x[3];
+        for (int a = 0; a < 3; ++a) x[a] = c.part == 0 ? p3[a] : d3[a] / dn;
+        for (int a = 0; a < 3; ++a) SMP(SW_PE, c.part * 63 + a) = x[a];
+        float freq = 1.f;
+        for (int k = 0; k < 10; ++k) {
+            for (int a = 0; a < 3; ++a) {
+                SMP(SW_PE, c.part * 63 + 3 + k * 6 + a) = sinf(x[a] * freq);
+                SMP(SW_PE, c.part * 63 + 3 + k * 6 + 3 + a) = cosf(x[a] * freq);
             }
+            freq *= 2.f;
         }
     }
+    STAGE_END
     for (int i = 0; i < depth; ++i) {
         const float* L = blob + gnt_layer_base(i);
         const int ls = SW_BASE + (save ? i : 0) * SW_LAYER;
         const int lr = RW_BASE + (save ? i : 0) * RW_LAYER;
-        if (active) {
-            // ================= view transformer =================
-            gnt_layernorm(c, SW_CUR, L + gnt_ln_w(0), L + gnt_ln_b(0), 1e-6f, ls + SL_XH1, ls + SL_RSTD1, SW_T);
-            {
-                float Q[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) Q[n] = 0.f;
-                nf_dense_ws<64>(L + gnt_wt(GV_Q), 64, SMPP(SW_T), (size_t)c.S, 1.f, Q);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_QV, n) = Q[n];
+        // ================= view transformer =================
+        STAGE_BEGIN
+        gnt_ln_slice(c, SW_CUR, L + gnt_ln_w(0), L + gnt_ln_b(0), 1e-6f, ls + SL_XH1, ls + SL_RSTD1, SW_T);
+        STAGE_END
+        STAGE_BEGIN
+        float Q[16];
+        gnt_slice(L + gnt_wt(GV_Q), 64, P0, nullptr, 64, SMPP(SW_T), (size_t)c.S, Q);
+        for (int j = 0; j < 16; ++j) SMP(SW_QV, P0 + j) = Q[j];
+        STAGE_END
+        float m[16];
+        for (int j = 0; j < 16; ++j) m[j] = -3.0e38f;
+        for (int v = 0; v < V; ++v) {
+            STAGE_BEGIN
+            float K[16];
+            gnt_slice(L + gnt_wt(GV_K), 64, P0, nullptr, 64, ROWP(RW_X), ROWSTRIDE, K);
+            for (int j = 0; j < 16; ++j) ROW(RW_T, P0 + j) = K[j];
+            STAGE_END
+            STAGE_BEGIN
+            const float* rd = c.ray_diff + ((size_t)c.s * V + v) * 4;
+            float h0[8];
+            for (int n = 0; n < 8; ++n) {
+                float t = L[gnt_b(GV_POS0) + n];
+                for (int k = 0; k < 4; ++k) t = fmaf(L[gnt_wt(GV_POS0) + k * 8 + n], rd[k], t);
+                h0[n] = fmaxf(t, 0.f);
             }
-            float m[64];
-#pragma unroll
-            for (int n = 0; n < 64; ++n) m[n] = -3.0e38f;
-            for (int v = 0; v < V; ++v) {
-                const float* rd = c.ray_diff + ((size_t)c.s * V + v) * 4;
-                const float mk = c.mask[(size_t)c.s * V + v];
-                {
-                    float K[64];
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) K[n] = 0.f;
-                    nf_dense_ws<64>(L + gnt_wt(GV_K), 64, ROWP(RW_X), ROWSTRIDE, 1.f, K);
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) ROW(RW_T, n) = K[n];
-                }
-                float pos[64];
-                {
-                    float h0[8];
-#pragma unroll
-                    for (int n = 0; n < 8; ++n) {
-                        float t = L[gnt_b(GV_POS0) + n];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) t = fmaf(L[gnt_wt(GV_POS0) + k * 8 + n], rd[k], t);
-                        h0[n] = fmaxf(t, 0.f);
-                    }
-                    nf_load_bias(L + gnt_b(GV_POS2), pos);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-#pragma unroll
-                        for (int n = 0; n < 64; ++n) pos[n] = fmaf(L[gnt_wt(GV_POS2) + k * 64 + n], h0[k], pos[n]);
-                    }
-                }
-                {
-                    float Vv[64];
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) Vv[n] = 0.f;
-                    nf_dense_ws<64>(L + gnt_wt(GV_V), 64, ROWP(RW_T), ROWSTRIDE, 1.f, Vv);
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) {
-                        ROW(lr + RWL_VP, n) = Vv[n] + pos[n];
-                        ROW(RW_T2, n) = ROW(RW_T, n) - SMP(SW_QV, n) + pos[n];      // k - q + pos
-                    }
-                }
-                float h[8];
-                nf_load_bias(L + gnt_b(GV_ATT0), h);
-                nf_dense_ws<8>(L + gnt_wt(GV_ATT0), 64, ROWP(RW_T2), ROWSTRIDE, 1.f, h);
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    h[n] = fmaxf(h[n], 0.f);
-                    ROW(lr + RWL_H, n) = h[n];
-                }
-                float lg[64];
-                nf_load_bias(L + gnt_b(GV_ATT2), lg);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) lg[n] = fmaf(L[gnt_wt(GV_ATT2) + k * 64 + n], h[k], lg[n]);
-                }
-#pragma unroll
-                for (int n = 0; n < 64; ++n) {
-                    float t = mk == 0.f ? -1e9f : lg[n];
-                    ROW(lr + RWL_PROB, n) = t;
-                    m[n] = fmaxf(m[n], t);
-                }
+            float Vv[16];
+            gnt_slice(L + gnt_wt(GV_V), 64, P0, nullptr, 64, ROWP(RW_T), ROWSTRIDE, Vv);
+            for (int j = 0; j < 16; ++j) {
+                float pos = L[gnt_b(GV_POS2) + P0 + j];
+                for (int k = 0; k < 8; ++k) pos = fmaf(L[gnt_wt(GV_POS2) + k * 64 + P0 + j], h0[k], pos);
+                ROW(lr + RWL_VP, P0 + j) = Vv[j] + pos;
+                ROW(RW_T2, P0 + j) = ROW(RW_T, P0 + j) - SMP(SW_QV, P0 + j) + pos;      // k - q + pos
             }
-            {
-                float sum[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) sum[n] = 0.f;
-                for (int v = 0; v < V; ++v) {
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) {
-                        float e = expf(ROW(lr + RWL_PROB, n) - m[n]);
-                        ROW(lr + RWL_PROB, n) = e;
-                        sum[n] += e;
-                    }
-                }
-                float u[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) u[n] = 0.f;
-                for (int v = 0; v < V; ++v) {
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) {
-                        float pr = ROW(lr + RWL_PROB, n) / sum[n];
-                        ROW(lr + RWL_PROB, n) = pr;
-                        u[n] = fmaf(ROW(lr + RWL_VP, n), pr, u[n]);
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_U, n) = u[n];
+            STAGE_END
+            STAGE_BEGIN
+            for (int j = 0; j < 2; ++j) {          // 8 hidden units of attn_fc, two per part
+                int n = c.part * 2 + j;
+                float t = L[gnt_b(GV_ATT0) + n];
+                for (int k = 0; k < 64; ++k) t = fmaf(L[gnt_wt(GV_ATT0) + k * 8 + n], ROW(RW_T2, k), t);
+                ROW(lr + RWL_H, n) = fmaxf(t, 0.f);
             }
-            {
-                float o[64];
-                nf_load_bias(L + gnt_b(GV_OUT), o);
-                nf_dense_ws<64>(L + gnt_wt(GV_OUT), 64, SMPP(SW_U), (size_t)c.S, 1.f, o);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_CUR, n) += o[n];
+            STAGE_END
+            STAGE_BEGIN
+            const float mk = c.mask[(size_t)c.s * V + v];
+            for (int j = 0; j < 16; ++j) {
+                float t = L[gnt_b(GV_ATT2) + P0 + j];
+                for (int k = 0; k < 8; ++k) t = fmaf(L[gnt_wt(GV_ATT2) + k * 64 + P0 + j], ROW(lr + RWL_H, k), t);
+                if (mk == 0.f) t = -1e9f;
+                ROW(lr + RWL_PROB, P0 + j) = t;
+                m[j] = fmaxf(m[j], t);
             }
-            gnt_layernorm(c, SW_CUR, L + gnt_ln_w(1), L + gnt_ln_b(1), 1e-6f, ls + SL_XH2, ls + SL_RSTD2, SW_T);
-            gnt_ff(c, L, GV_FF1, GV_FF2, ls + SL_F);
-            // ================= positional MLP on even layers =================
-            if ((i & 1) == 0) {
-                float g[64];
-                nf_load_bias(L + gnt_b(GQ_0), g);
-                nf_dense_ws<64>(L + gnt_wt(GQ_0), 64, SMPP(SW_CUR), (size_t)c.S, 1.f, g);
-                nf_dense_ws<64>(L + gnt_wt(GQ_0) + 64 * 64, 126, SMPP(SW_PE), (size_t)c.S, 1.f, g);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(ls + SL_G, n) = fmaxf(g[n], 0.f);
-                float q3[64];
-                nf_load_bias(L + gnt_b(GQ_2), q3);
-                nf_dense_ws<64>(L + gnt_wt(GQ_2), 64, SMPP(ls + SL_G), (size_t)c.S, 1.f, q3);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_CUR, n) = q3[n];
-            }
-            // ================= ray transformer: projections =================
-            gnt_layernorm(c, SW_CUR, L + gnt_ln_w(2), L + gnt_ln_b(2), 1e-6f, ls + SL_RXH1, ls + SL_RRSTD1, SW_T);
-            for (int which = 0; which < 3; ++which) {
-                float o[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) o[n] = 0.f;
-                nf_dense_ws<64>(L + gnt_wt(GR_Q + which), 64, SMPP(SW_T), (size_t)c.S, 1.f, o);
-                const int slot = ls + (which == 0 ? SL_QH : (which == 1 ? SL_KH : SL_VH));
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(slot, n) = o[n];
-            }
+            STAGE_END
         }
-        __syncthreads();
-        if (active) {
-            // ================= ray transformer: attention over the S samples, out_fc, FF =================
-            for (int hd = 0; hd < 4; ++hd) {
-                float q[16];
-#pragma unroll
-                for (int d = 0; d < 16; ++d) q[d] = SMP(ls + SL_QH, hd * 16 + d) * 0.25f;     // 1 / sqrt(16)
-                const float* Kb = c.ws_smp + (size_t)(ls + SL_KH + hd * 16) * S;
-                const float* Vb = c.ws_smp + (size_t)(ls + SL_VH + hd * 16) * S;
-                float mx = -3.0e38f;
-                for (int k = 0; k < S; ++k) mx = fmaxf(mx, gnt_score(Kb, (size_t)S, k, q));
-                float l = 0.f, acc[16];
-#pragma unroll
-                for (int d = 0; d < 16; ++d) acc[d] = 0.f;
-                for (int k = 0; k < S; ++k) {
-                    float p = expf(gnt_score(Kb, (size_t)S, k, q) - mx);
-                    l += p;
-#pragma unroll
-                    for (int d = 0; d < 16; ++d) acc[d] = fmaf(p, Vb[(size_t)d * S + k], acc[d]);
-                }
-#pragma unroll
-                for (int d = 0; d < 16; ++d) {
-                    float o = acc[d] / l;
-                    SMP(SW_U, hd * 16 + d) = o;
-                    SMP(ls + SL_OUTA, hd * 16 + d) = o;
-                }
-                SMP(ls + SL_ML, hd) = mx;
-                SMP(ls + SL_ML, 4 + hd) = l;
+        STAGE_BEGIN      // softmax over the views (per channel) and the attention-weighted sum, own slice only
+        float sum[16], u[16];
+        for (int j = 0; j < 16; ++j) sum[j] = u[j] = 0.f;
+        for (int v = 0; v < V; ++v)
+            for (int j = 0; j < 16; ++j) {
+                float e = expf(ROW(lr + RWL_PROB, P0 + j) - m[j]);
+                ROW(lr + RWL_PROB, P0 + j) = e;
+                sum[j] += e;
             }
-            {
-                float o[64];
-                nf_load_bias(L + gnt_b(GR_OUT), o);
-                nf_dense_ws<64>(L + gnt_wt(GR_OUT), 64, SMPP(SW_U), (size_t)c.S, 1.f, o);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_CUR, n) += o[n];
+        for (int v = 0; v < V; ++v)
+            for (int j = 0; j < 16; ++j) {
+                float pr = ROW(lr + RWL_PROB, P0 + j) / sum[j];
+                ROW(lr + RWL_PROB, P0 + j) = pr;
+                u[j] = fmaf(ROW(lr + RWL_VP, P0 + j), pr, u[j]);
             }
-            gnt_layernorm(c, SW_CUR, L + gnt_ln_w(3), L + gnt_ln_b(3), 1e-6f, ls + SL_RXH2, ls + SL_RRSTD2, SW_T);
-            gnt_ff(c, L, GR_FF1, GR_FF2, ls + SL_F2);
+        for (int j = 0; j < 16; ++j) SMP(SW_U, P0 + j) = u[j];
+        STAGE_END
+        STAGE_BEGIN
+        float o[16];
+        gnt_slice(L + gnt_wt(GV_OUT), 64, P0, L + gnt_b(GV_OUT), 64, SMPP(SW_U), (size_t)c.S, o);
+        for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j];
+        STAGE_END
+        STAGE_BEGIN
+        gnt_ln_slice(c, SW_CUR, L + gnt_ln_w(1), L + gnt_ln_b(1), 1e-6f, ls + SL_XH2, ls + SL_RSTD2, SW_T);
+        STAGE_END
+        GNT_FF(L, GV_FF1, GV_FF2, ls + SL_F)
+        // ================= positional MLP on even layers =================
+        if ((i & 1) == 0) {
+            STAGE_BEGIN
+            float g[16];
+            gnt_slice(L + gnt_wt(GQ_0), 64, P0, L + gnt_b(GQ_0), 64, SMPP(SW_CUR), (size_t)c.S, g);
+            nf_dense_ws_ld<16>(L + gnt_wt(GQ_0) + 64 * 64 + P0, 64, 126, SMPP(SW_PE), (size_t)c.S, g);
+            for (int j = 0; j < 16; ++j) SMP(ls + SL_G, P0 + j) = fmaxf(g[j], 0.f);
+            STAGE_END
+            STAGE_BEGIN
+            float q3[16];
+            gnt_slice(L + gnt_wt(GQ_2), 64, P0, L + gnt_b(GQ_2), 64, SMPP(ls + SL_G), (size_t)c.S, q3);
+            for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) = q3[j];
+            STAGE_END
         }
-        __syncthreads();
+        // ================= ray transformer =================
+        STAGE_BEGIN
+        gnt_ln_slice(c, SW_CUR, L + gnt_ln_w(2), L + gnt_ln_b(2), 1e-6f, ls + SL_RXH1, ls + SL_RRSTD1, SW_T);
+        STAGE_END
+        STAGE_BEGIN
+        for (int which = 0; which < 3; ++which) {
+            float o[16];
+            gnt_slice(L + gnt_wt(GR_Q + which), 64, P0, nullptr, 64, SMPP(SW_T), (size_t)c.S, o);
+            const int slot = ls + (which == 0 ? SL_QH : (which == 1 ? SL_KH : SL_VH));
+            for (int j = 0; j < 16; ++j) SMP(slot, P0 + j) = o[j];
+        }
+        STAGE_END
+        STAGE_BEGIN      // attention over the S samples: part = head
+        {
+            float q[16];
+            for (int d = 0; d < 16; ++d) q[d] = SMP(ls + SL_QH, P0 + d) * 0.25f;     // 1 / sqrt(16)
+            const float* Kb = c.ws_smp + (size_t)(ls + SL_KH + P0) * S;
+            const float* Vb = c.ws_smp + (size_t)(ls + SL_VH + P0) * S;
+            float mx = -3.0e38f;
+            for (int k = 0; k < S; ++k) mx = fmaxf(mx, gnt_score(Kb, (size_t)S, k, q));
+            float l = 0.f, acc[16];
+            for (int d = 0; d < 16; ++d) acc[d] = 0.f;
+            for (int k = 0; k < S; ++k) {
+                float p = expf(gnt_score(Kb, (size_t)S, k, q) - mx);
+                l += p;
+                for (int d = 0; d < 16; ++d) acc[d] = fmaf(p, Vb[(size_t)d * S + k], acc[d]);
+            }
+            for (int d = 0; d < 16; ++d) {
+                float o = acc[d] / l;
+                SMP(SW_U, P0 + d) = o;
+                SMP(ls + SL_OUTA, P0 + d) = o;
+            }
+            SMP(ls + SL_ML, c.part) = mx;
+            SMP(ls + SL_ML, 4 + c.part) = l;
+        }
+        STAGE_END
+        STAGE_BEGIN
+        float o[16];
+        gnt_slice(L + gnt_wt(GR_OUT), 64, P0, L + gnt_b(GR_OUT), 64, SMPP(SW_U), (size_t)c.S, o);
+        for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j];
+        STAGE_END
+        STAGE_BEGIN
+        gnt_ln_slice(c, SW_CUR, L + gnt_ln_w(3), L + gnt_ln_b(3), 1e-6f, ls + SL_RXH2, ls + SL_RRSTD2, SW_T);
+        STAGE_END
+        GNT_FF(L, GR_FF1, GR_FF2, ls + SL_F2)
     }
     // ---- final LayerNorm (eps 1e-5), mean over the samples, rgb_fc
     const float* Fp = blob + gnt_layer_base(depth);
-    if (active) gnt_layernorm(c, SW_CUR, Fp, Fp + 64, 1e-5f, SW_XHF, SW_RSTDF, SW_HF);
-    __syncthreads();
+    STAGE_BEGIN
+    gnt_ln_slice(c, SW_CUR, Fp, Fp + 64, 1e-5f, SW_XHF, SW_RSTDF, SW_HF);
+    STAGE_END
     if (threadIdx.x < 64) {
         float t = 0.f;
         const float* col = c.ws_smp + (size_t)(SW_HF + threadIdx.x) * S;
@@ -492,237 +480,200 @@ __global__ void __launch_bounds__(256) k_gnt_fwd(const float* __restrict__ blob,
 // ---------------------------------------------------------------------------------------------------------------
 // backward (reads the activations saved by the forward with save = 1)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gnt_bwd(const float* __restrict__ blob, const float* __restrict__ ray_diff,
-                                                 const float* __restrict__ mask, const float* __restrict__ d_rgb, int S, int V,
-                                                 int depth, float* __restrict__ d_rgb_feat, float* __restrict__ ws,
-                                                 int64_t row_floats, int64_t smp_floats) {
-    const int64_t ray = blockIdx.x;
-    GntCtx c;
-    c.blob = blob; c.S = S; c.V = V; c.s = threadIdx.x; c.depth = depth; c.save = 1;
+__global__ void __launch_bounds__(1024) k_gnt_bwd(const float* __restrict__ blob, const float* __restrict__ ray_diff,
+                                                  const float* __restrict__ mask, const float* __restrict__ d_rgb, int S, int V,
+                                                  int depth, float* __restrict__ d_rgb_feat, float* __restrict__ ws,
+                                                  int64_t row_floats, int64_t smp_floats) {
+    GNT_SETUP()
     c.rgb_feat = nullptr;
-    c.ray_diff = ray_diff + ray * S * V * 4;
-    c.mask = mask + ray * S * V;
-    const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;
-    c.ws_row = ws + ray * per_ray;
-    c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
-    const bool active = c.s < S;
     const float* Fp = blob + gnt_layer_base(depth);
-    if (active) {
-        // ---- rgb_fc, mean over samples, final LayerNorm
-        const float* g = d_rgb + ray * 3;
-        for (int j = 0; j < 64; ++j) {
-            float dm = Fp[320 + j] * g[0] + Fp[320 + 64 + j] * g[1] + Fp[320 + 128 + j] * g[2];
-            SMP(SW_U, j) = dm / (float)S;
-            SMP(SW_DCUR, j) = 0.f;
-        }
-        gnt_layernorm_bwd_add(c, SW_U, Fp, SW_XHF, SW_RSTDF, SW_DCUR);
-        for (int v = 0; v < V; ++v)
-            for (int n = 0; n < 64; ++n) ROW(RW_DX, n) = 0.f;
+    // ---- rgb_fc, mean over samples, final LayerNorm
+    STAGE_BEGIN
+    const float* g = d_rgb + ray * 3;
+    for (int j = P0; j < P0 + 16; ++j) {
+        float dm = Fp[320 + j] * g[0] + Fp[320 + 64 + j] * g[1] + Fp[320 + 128 + j] * g[2];
+        SMP(SW_U, j) = dm / (float)S;
+        SMP(SW_DCUR, j) = 0.f;
     }
+    for (int v = 0; v < V; ++v)
+        for (int j = P0; j < P0 + 16; ++j) ROW(RW_DX, j) = 0.f;
+    STAGE_END
+    STAGE_BEGIN
+    gnt_ln_bwd_slice(c, SW_U, Fp, SW_XHF, SW_RSTDF, SW_DCUR);
+    STAGE_END
     for (int i = depth - 1; i >= 0; --i) {
         const float* L = blob + gnt_layer_base(i);
         const int ls = SW_BASE + i * SW_LAYER;
         const int lr = RW_BASE + i * RW_LAYER;
-        if (active) {
-            // ================= ray transformer backward, per-sample part =================
-            gnt_ff_bwd(c, L, GR_FF1, GR_FF2, ls + SL_F2, 3, ls + SL_RXH2, ls + SL_RRSTD2);    // SW_DCUR = d q1
-            float d_out[64];
-#pragma unroll
-            for (int n = 0; n < 64; ++n) d_out[n] = 0.f;
-            nf_dense_bwd_ws<64>(L + gnt_w(GR_OUT), 64, 64, SMPP(SW_DCUR), (size_t)c.S, d_out);
-#pragma unroll
-            for (int hd = 0; hd < 4; ++hd) {
-                float D = 0.f;
-#pragma unroll
+        // ================= ray transformer backward =================
+        GNT_FF_BWD(L, GR_FF1, GR_FF2, ls + SL_F2, 3, ls + SL_RXH2, ls + SL_RRSTD2)        // DCUR = d q1
+        STAGE_BEGIN
+        float d_out[16];
+        for (int j = 0; j < 16; ++j) d_out[j] = 0.f;
+        gnt_slice_bwd(L + gnt_w(GR_OUT), 64, 64, P0, SMPP(SW_DCUR), (size_t)c.S, d_out);
+        float D = 0.f;
+        for (int d = 0; d < 16; ++d) {
+            SMP(SW_GO, P0 + d) = d_out[d];
+            D = fmaf(d_out[d], SMP(ls + SL_OUTA, P0 + d), D);
+        }
+        SMP(SW_DH, c.part) = D;
+        STAGE_END
+        STAGE_BEGIN      // attention backward for head = part: dQ as query, dK / dV as key
+        {
+            const float* Qb = c.ws_smp + (size_t)(ls + SL_QH + P0) * S;
+            const float* Kb = c.ws_smp + (size_t)(ls + SL_KH + P0) * S;
+            const float* Vb = c.ws_smp + (size_t)(ls + SL_VH + P0) * S;
+            const float* Gb = c.ws_smp + (size_t)(SW_GO + P0) * S;
+            const float* Mb = c.ws_smp + (size_t)(ls + SL_ML + c.part) * S;
+            const float* Lb = c.ws_smp + (size_t)(ls + SL_ML + 4 + c.part) * S;
+            const float* Db = c.ws_smp + (size_t)(SW_DH + c.part) * S;
+            {
+                float q[16], go[16], dq[16];
                 for (int d = 0; d < 16; ++d) {
-                    SMP(SW_GO, hd * 16 + d) = d_out[hd * 16 + d];
-                    D = fmaf(d_out[hd * 16 + d], SMP(ls + SL_OUTA, hd * 16 + d), D);
+                    q[d] = Qb[(size_t)d * S + c.s] * 0.25f;
+                    go[d] = Gb[(size_t)d * S + c.s];
+                    dq[d] = 0.f;
                 }
-                SMP(SW_DH, hd) = D;
+                float mx = Mb[c.s], rl = 1.f / Lb[c.s], D = Db[c.s];
+                for (int k = 0; k < S; ++k) {
+                    float p = expf(gnt_score(Kb, (size_t)S, k, q) - mx) * rl;
+                    float dS = p * (gnt_score(Vb, (size_t)S, k, go) - D);
+                    for (int d = 0; d < 16; ++d) dq[d] = fmaf(dS, Kb[(size_t)d * S + k], dq[d]);
+                }
+                for (int d = 0; d < 16; ++d) SMP(SW_DQ, P0 + d) = dq[d] * 0.25f;
             }
-        }
-        __syncthreads();
-        if (active) {
-            // ================= attention backward: dQ (as query), dK / dV (as key) =================
-            for (int hd = 0; hd < 4; ++hd) {
-                const float* Qb = c.ws_smp + (size_t)(ls + SL_QH + hd * 16) * S;
-                const float* Kb = c.ws_smp + (size_t)(ls + SL_KH + hd * 16) * S;
-                const float* Vb = c.ws_smp + (size_t)(ls + SL_VH + hd * 16) * S;
-                const float* Gb = c.ws_smp + (size_t)(SW_GO + hd * 16) * S;
-                const float* Mb = c.ws_smp + (size_t)(ls + SL_ML + hd) * S;
-                const float* Lb = c.ws_smp + (size_t)(ls + SL_ML + 4 + hd) * S;
-                const float* Db = c.ws_smp + (size_t)(SW_DH + hd) * S;
-                {
-                    float q[16], go[16], dq[16];
-#pragma unroll
-                    for (int d = 0; d < 16; ++d) {
-                        q[d] = Qb[(size_t)d * S + c.s] * 0.25f;
-                        go[d] = Gb[(size_t)d * S + c.s];
-                        dq[d] = 0.f;
-                    }
-                    float mx = Mb[c.s], rl = 1.f / Lb[c.s], D = Db[c.s];
-                    for (int k = 0; k < S; ++k) {
-                        float p = expf(gnt_score(Kb, (size_t)S, k, q) - mx) * rl;
-                        float dA = gnt_score(Vb, (size_t)S, k, go);
-                        float dS = p * (dA - D);
-#pragma unroll
-                        for (int d = 0; d < 16; ++d) dq[d] = fmaf(dS, Kb[(size_t)d * S + k], dq[d]);
-                    }
-#pragma unroll
-                    for (int d = 0; d < 16; ++d) SMP(SW_DQ, hd * 16 + d) = dq[d] * 0.25f;
+            {
+                float kk[16], vv[16], dk[16], dv[16];
+                for (int d = 0; d < 16; ++d) {
+                    kk[d] = Kb[(size_t)d * S + c.s];
+                    vv[d] = Vb[(size_t)d * S + c.s];
+                    dk[d] = dv[d] = 0.f;
                 }
-                {
-                    float kk[16], vv[16], dk[16], dv[16];
-#pragma unroll
+                for (int qi = 0; qi < S; ++qi) {
+                    float sc = 0.f, dA = 0.f;
                     for (int d = 0; d < 16; ++d) {
-                        kk[d] = Kb[(size_t)d * S + c.s];
-                        vv[d] = Vb[(size_t)d * S + c.s];
-                        dk[d] = dv[d] = 0.f;
+                        sc = fmaf(Qb[(size_t)d * S + qi] * 0.25f, kk[d], sc);
+                        dA = fmaf(Gb[(size_t)d * S + qi], vv[d], dA);
                     }
-                    for (int qi = 0; qi < S; ++qi) {
-                        float sc = 0.f, dA = 0.f;
-#pragma unroll
-                        for (int d = 0; d < 16; ++d) {
-                            sc = fmaf(Qb[(size_t)d * S + qi] * 0.25f, kk[d], sc);
-                            dA = fmaf(Gb[(size_t)d * S + qi], vv[d], dA);
-                        }
-                        float p = expf(sc - Mb[qi]) / Lb[qi];
-                        float dS = p * (dA - Db[qi]);
-#pragma unroll
-                        for (int d = 0; d < 16; ++d) {
-                            dv[d] = fmaf(p, Gb[(size_t)d * S + qi], dv[d]);
-                            dk[d] = fmaf(dS, Qb[(size_t)d * S + qi] * 0.25f, dk[d]);
-                        }
-                    }
-#pragma unroll
+                    float p = expf(sc - Mb[qi]) / Lb[qi];
+                    float dS = p * (dA - Db[qi]);
                     for (int d = 0; d < 16; ++d) {
-                        SMP(SW_DK, hd * 16 + d) = dk[d];
-                        SMP(SW_DV, hd * 16 + d) = dv[d];
+                        dv[d] = fmaf(p, Gb[(size_t)d * S + qi], dv[d]);
+                        dk[d] = fmaf(dS, Qb[(size_t)d * S + qi] * 0.25f, dk[d]);
                     }
+                }
+                for (int d = 0; d < 16; ++d) {
+                    SMP(SW_DK, P0 + d) = dk[d];
+                    SMP(SW_DV, P0 + d) = dv[d];
                 }
             }
         }
-        __syncthreads();
-        if (active) {
-            {
-                float dx[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) dx[n] = 0.f;
-                nf_dense_bwd_ws<64>(L + gnt_w(GR_Q), 64, 64, SMPP(SW_DQ), (size_t)c.S, dx);
-                nf_dense_bwd_ws<64>(L + gnt_w(GR_K), 64, 64, SMPP(SW_DK), (size_t)c.S, dx);
-                nf_dense_bwd_ws<64>(L + gnt_w(GR_V), 64, 64, SMPP(SW_DV), (size_t)c.S, dx);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_U, n) = dx[n];
-            }
-            gnt_layernorm_bwd_add(c, SW_U, L + gnt_ln_w(2), ls + SL_RXH1, ls + SL_RRSTD1, SW_DCUR);
-            // ================= positional MLP backward (even layers) =================
-            if ((i & 1) == 0) {
-                float dg[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) dg[n] = 0.f;
-                nf_dense_bwd_ws<64>(L + gnt_w(GQ_2), 64, 64, SMPP(SW_DCUR), (size_t)c.S, dg);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_T, n) = SMP(ls + SL_G, n) > 0.f ? dg[n] : 0.f;
-                float dq[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) dq[n] = 0.f;
-                nf_dense_bwd_ws<64>(L + gnt_w(GQ_0), 64, 190, SMPP(SW_T), (size_t)c.S, dq);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_DCUR, n) = dq[n];
-            }
-            // ================= view transformer backward =================
-            gnt_ff_bwd(c, L, GV_FF1, GV_FF2, ls + SL_F, 1, ls + SL_XH2, ls + SL_RSTD2);      // SW_DCUR = d q1
-            {
-                float du[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) du[n] = 0.f;
-                nf_dense_bwd_ws<64>(L + gnt_w(GV_OUT), 64, 64, SMPP(SW_DCUR), (size_t)c.S, du);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) {
-                    SMP(SW_DU, n) = du[n];
-                    SMP(SW_DQS, n) = 0.f;
-                }
-                float sp[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) sp[n] = 0.f;
-                for (int v = 0; v < V; ++v) {
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) sp[n] = fmaf(ROW(lr + RWL_PROB, n) * ROW(lr + RWL_VP, n), du[n], sp[n]);
-                }
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_SP, n) = sp[n];
-            }
-            for (int v = 0; v < V; ++v) {
-                const float mk = c.mask[(size_t)c.s * V + v];
-                float dl[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) {
-                    float pr = ROW(lr + RWL_PROB, n), du = SMP(SW_DU, n);
-                    dl[n] = mk == 0.f ? 0.f : pr * (ROW(lr + RWL_VP, n) * du - SMP(SW_SP, n));
-                    ROW(RW_T, n) = pr * du;                                   // d Vv
-                }
-                float dh[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int n = 0; n < 64; ++n) t = fmaf(L[gnt_w(GV_ATT2) + n * 8 + j], dl[n], t);
-                    dh[j] = ROW(lr + RWL_H, j) > 0.f ? t : 0.f;
-                }
-                float da[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) {
-                    float t = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) t = fmaf(L[gnt_w(GV_ATT0) + j * 64 + n], dh[j], t);
-                    da[n] = t;
-                    SMP(SW_DQS, n) += t;
-                }
-                nf_dense_bwd_ws<64>(L + gnt_w(GV_V), 64, 64, ROWP(RW_T), ROWSTRIDE, da);      // d K = d a + Wv^T d Vv
-#pragma unroll
-                for (int n = 0; n < 64; ++n) ROW(RW_T2, n) = da[n];
-                float dx[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) dx[n] = 0.f;
-                nf_dense_bwd_ws<64>(L + gnt_w(GV_K), 64, 64, ROWP(RW_T2), ROWSTRIDE, dx);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) ROW(RW_DX, n) += dx[n];
-            }
-            {
-                float dx[64];
-#pragma unroll
-                for (int n = 0; n < 64; ++n) {
-                    dx[n] = 0.f;
-                    SMP(SW_T, n) = -SMP(SW_DQS, n);                           // d Q = - sum_v d a_v
-                }
-                nf_dense_bwd_ws<64>(L + gnt_w(GV_Q), 64, 64, SMPP(SW_T), (size_t)c.S, dx);
-#pragma unroll
-                for (int n = 0; n < 64; ++n) SMP(SW_U, n) = dx[n];
-            }
-            gnt_layernorm_bwd_add(c, SW_U, L + gnt_ln_w(0), ls + SL_XH1, ls + SL_RSTD1, SW_DCUR);
+        STAGE_END
+        STAGE_BEGIN
+        float dx[16];
+        for (int j = 0; j < 16; ++j) dx[j] = 0.f;
+        gnt_slice_bwd(L + gnt_w(GR_Q), 64, 64, P0, SMPP(SW_DQ), (size_t)c.S, dx);
+        gnt_slice_bwd(L + gnt_w(GR_K), 64, 64, P0, SMPP(SW_DK), (size_t)c.S, dx);
+        gnt_slice_bwd(L + gnt_w(GR_V), 64, 64, P0, SMPP(SW_DV), (size_t)c.S, dx);
+        for (int j = 0; j < 16; ++j) SMP(SW_U, P0 + j) = dx[j];
+        STAGE_END
+        STAGE_BEGIN
+        gnt_ln_bwd_slice(c, SW_U, L + gnt_ln_w(2), ls + SL_RXH1, ls + SL_RRSTD1, SW_DCUR);
+        STAGE_END
+        // ================= positional MLP backward (even layers) =================
+        if ((i & 1) == 0) {
+            STAGE_BEGIN
+            float dg[16];
+            for (int j = 0; j < 16; ++j) dg[j] = 0.f;
+            gnt_slice_bwd(L + gnt_w(GQ_2), 64, 64, P0, SMPP(SW_DCUR), (size_t)c.S, dg);
+            for (int j = 0; j < 16; ++j) SMP(SW_T, P0 + j) = SMP(ls + SL_G, P0 + j) > 0.f ? dg[j] : 0.f;
+            STAGE_END
+            STAGE_BEGIN
+            float dq[16];
+            for (int j = 0; j < 16; ++j) dq[j] = 0.f;
+            gnt_slice_bwd(L + gnt_w(GQ_0), 64, 190, P0, SMPP(SW_T), (size_t)c.S, dq);
+            for (int j = 0; j < 16; ++j) SMP(SW_DCUR, P0 + j) = dq[j];
+            STAGE_END
         }
-        __syncthreads();
+        // ================= view transformer backward =================
+        GNT_FF_BWD(L, GV_FF1, GV_FF2, ls + SL_F, 1, ls + SL_XH2, ls + SL_RSTD2)           // DCUR = d q1
+        float du[16], sp[16], dqs[16];
+        STAGE_BEGIN
+        for (int j = 0; j < 16; ++j) du[j] = sp[j] = dqs[j] = 0.f;
+        gnt_slice_bwd(L + gnt_w(GV_OUT), 64, 64, P0, SMPP(SW_DCUR), (size_t)c.S, du);
+        for (int v = 0; v < V; ++v)
+            for (int j = 0; j < 16; ++j) sp[j] = fmaf(ROW(lr + RWL_PROB, P0 + j) * ROW(lr + RWL_VP, P0 + j), du[j], sp[j]);
+        STAGE_END
+        for (int v = 0; v < V; ++v) {
+            STAGE_BEGIN
+            const float mk = c.mask[(size_t)c.s * V + v];
+            for (int j = 0; j < 16; ++j) {
+                float pr = ROW(lr + RWL_PROB, P0 + j);
+                ROW(RW_T2, P0 + j) = mk == 0.f ? 0.f : pr * (ROW(lr + RWL_VP, P0 + j) * du[j] - sp[j]);    // d logit
+                ROW(RW_T, P0 + j) = pr * du[j];                                                               // d Vv
+            }
+            STAGE_END
+            STAGE_BEGIN
+            for (int j = 0; j < 2; ++j) {
+                int n = c.part * 2 + j;
+                float t = 0.f;
+                for (int k = 0; k < 64; ++k) t = fmaf(L[gnt_w(GV_ATT2) + k * 8 + n], ROW(RW_T2, k), t);
+                ROW(RW_R1H, n) = ROW(lr + RWL_H, n) > 0.f ? t : 0.f;
+            }
+            STAGE_END
+            STAGE_BEGIN
+            float dk[16];
+            for (int j = 0; j < 16; ++j) {
+                float t = 0.f;
+                for (int n = 0; n < 8; ++n) t = fmaf(L[gnt_w(GV_ATT0) + n * 64 + P0 + j], ROW(RW_R1H, n), t);
+                dqs[j] += t;
+                dk[j] = t;                                        // d a
+            }
+            gnt_slice_bwd(L + gnt_w(GV_V), 64, 64, P0, ROWP(RW_T), ROWSTRIDE, dk);      // d K = d a + Wv^T d Vv
+            for (int j = 0; j < 16; ++j) ROW(RW_T3, P0 + j) = dk[j];
+            STAGE_END
+            STAGE_BEGIN
+            float dx[16];
+            for (int j = 0; j < 16; ++j) dx[j] = 0.f;
+            gnt_slice_bwd(L + gnt_w(GV_K), 64, 64, P0, ROWP(RW_T3), ROWSTRIDE, dx);
+            for (int j = 0; j < 16; ++j) ROW(RW_DX, P0 + j) += dx[j];
+            STAGE_END
+        }
+        STAGE_BEGIN
+        for (int j = 0; j < 16; ++j) SMP(SW_T, P0 + j) = -dqs[j];        // d Q = - sum_v d a_v
+        STAGE_END
+        STAGE_BEGIN
+        float dx[16];
+        for (int j = 0; j < 16; ++j) dx[j] = 0.f;
+        gnt_slice_bwd(L + gnt_w(GV_Q), 64, 64, P0, SMPP(SW_T), (size_t)c.S, dx);
+        for (int j = 0; j < 16; ++j) SMP(SW_U, P0 + j) = dx[j];
+        STAGE_END
+        STAGE_BEGIN
+        gnt_ln_bwd_slice(c, SW_U, L + gnt_ln_w(0), ls + SL_XH1, ls + SL_RSTD1, SW_DCUR);
+        STAGE_END
     }
-    if (!active) return;
     // ---- q0 = max over views routes its gradient to the arg-max view; then the stem
-    for (int n = 0; n < 64; ++n) {
-        int v = (int)SMP(SW_AMAX, n);
-        ROW(RW_DX, n) += SMP(SW_DCUR, n);
+    STAGE_BEGIN
+    for (int j = P0; j < P0 + 16; ++j) {
+        int v = (int)SMP(SW_AMAX, j);
+        ROW(RW_DX, j) += SMP(SW_DCUR, j);
     }
+    STAGE_END
     for (int v = 0; v < V; ++v) {
-        float dr[64];
-#pragma unroll
-        for (int n = 0; n < 64; ++n) dr[n] = 0.f;
-        nf_dense_bwd_ws<64>(blob + GNT_STEM1 + 64 * 64, 64, 64, ROWP(RW_DX), ROWSTRIDE, dr);
-#pragma unroll
-        for (int n = 0; n < 64; ++n) ROW(RW_T, n) = ROW(RW_R1, n) > 0.f ? dr[n] : 0.f;
-        float df[35];
-#pragma unroll
-        for (int n = 0; n < 35; ++n) df[n] = 0.f;
-        nf_dense_bwd_ws<35>(blob + 35 * 64, 64, 35, ROWP(RW_T), ROWSTRIDE, df);
+        STAGE_BEGIN
+        float dr[16];
+        for (int j = 0; j < 16; ++j) dr[j] = 0.f;
+        gnt_slice_bwd(blob + GNT_STEM1 + 64 * 64, 64, 64, P0, ROWP(RW_DX), ROWSTRIDE, dr);
+        for (int j = 0; j < 16; ++j) ROW(RW_T, P0 + j) = ROW(RW_R1, P0 + j) > 0.f ? dr[j] : 0.f;
+        STAGE_END
+        STAGE_BEGIN
         float* o = d_rgb_feat + ((ray * S + c.s) * V + v) * 35;
-#pragma unroll
-        for (int n = 0; n < 35; ++n) o[n] = df[n];
+        for (int n = c.part * 9; n < min(35, c.part * 9 + 9); ++n) {       // 35 input channels split 9 / 9 / 9 / 8
+            float t = 0.f;
+            for (int k = 0; k < 64; ++k) t = fmaf(blob[35 * 64 + k * 35 + n], ROW(RW_T, k), t);
+            o[n] = t;
+        }
+        STAGE_END
     }
 }
 
@@ -742,7 +693,7 @@ extern "C" int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float*
                           float* workspace, nf_stream_t stream) {
     if (gnt_check("nf_gnt_fwd", n_rays, n_samples, n_views, depth)) return 1;
     const int S = n_samples, V = n_views;
-    const int threads = ((S + 63) / 64) * 64;
+    const int threads = GNT_PARTS * (((S + 15) / 16) * 16);       // 4 lanes per sample, multiple of 64
     const int64_t rf = gnt_row_floats(depth, save), sf = gnt_smp_floats(depth, save);
     const int64_t per_ray = (int64_t)S * V * rf + (int64_t)S * sf;
     const int64_t step = save ? n_rays : GNT_RAYS_PER_LAUNCH;
@@ -761,7 +712,7 @@ extern "C" int nf_gnt_bwd(const float* blob, const float* ray_diff, const float*
                           int n_samples, int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream) {
     if (gnt_check("nf_gnt_bwd", n_rays, n_samples, n_views, depth)) return 1;
     if (n_rays == 0) return 0;
-    const int threads = ((n_samples + 63) / 64) * 64;
+    const int threads = GNT_PARTS * (((n_samples + 15) / 16) * 16);
     hipLaunchKernelGGL(k_gnt_bwd, dim3((unsigned)n_rays), dim3(threads), 0, (hipStream_t)stream, blob, ray_diff, mask, d_rgb,
                        n_samples, n_views, depth, d_rgb_feat, workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1));
     NF_LAUNCH_CHECK("nf_gnt_bwd");
