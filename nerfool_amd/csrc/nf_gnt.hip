@@ -268,8 +268,7 @@ __device__ __forceinline__ float gnt_score(const float* __restrict__ base, size_
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAXT>
-__global__ void __launch_bounds__(MAXT) k_gnt_fwd(const float* __restrict__ blob, const float* __restrict__ rgb_feat_all,
+__global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob, const float* __restrict__ rgb_feat_all,
                                                   const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                   const float* __restrict__ pts, const float* __restrict__ ray_d, int S, int V,
                                                   int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
@@ -481,8 +480,7 @@ __global__ void __launch_bounds__(MAXT) k_gnt_fwd(const float* __restrict__ blob
 // ---------------------------------------------------------------------------------------------------------------
 // backward (reads the activations saved by the forward with save = 1)
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAXT>
-__global__ void __launch_bounds__(MAXT) k_gnt_bwd(const float* __restrict__ blob, const float* __restrict__ ray_diff,
+__global__ void __launch_bounds__(1024) k_gnt_bwd(const float* __restrict__ blob, const float* __restrict__ ray_diff,
                                                   const float* __restrict__ mask, const float* __restrict__ d_rgb, int S, int V,
                                                   int depth, float* __restrict__ d_rgb_feat, float* __restrict__ ws,
                                                   int64_t row_floats, int64_t smp_floats) {
@@ -701,14 +699,9 @@ extern "C" int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float*
     const int64_t step = save ? n_rays : GNT_RAYS_PER_LAUNCH;
     for (int64_t r0 = 0; r0 < n_rays; r0 += step) {
         int64_t nr = n_rays - r0 < step ? n_rays - r0 : step;
-        if (threads <= 256)
-            hipLaunchKernelGGL(k_gnt_fwd<256>, dim3((unsigned)nr), dim3(threads), 0, (hipStream_t)stream, blob,
-                               rgb_feat + r0 * S * V * 35, ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3,
-                               ray_d + r0 * 3, S, V, depth, save ? 1 : 0, rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf);
-        else
-            hipLaunchKernelGGL(k_gnt_fwd<1024>, dim3((unsigned)nr), dim3(threads), 0, (hipStream_t)stream, blob,
-                               rgb_feat + r0 * S * V * 35, ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3,
-                               ray_d + r0 * 3, S, V, depth, save ? 1 : 0, rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf);
+        hipLaunchKernelGGL(k_gnt_fwd, dim3((unsigned)nr), dim3(threads), 0, (hipStream_t)stream, blob, rgb_feat + r0 * S * V * 35,
+                           ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, S, V, depth, save ? 1 : 0,
+                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf);
         NF_LAUNCH_CHECK("nf_gnt_fwd");
     }
     return 0;
@@ -720,12 +713,8 @@ extern "C" int nf_gnt_bwd(const float* blob, const float* ray_diff, const float*
     if (gnt_check("nf_gnt_bwd", n_rays, n_samples, n_views, depth)) return 1;
     if (n_rays == 0) return 0;
     const int threads = GNT_PARTS * (((n_samples + 15) / 16) * 16);
-    if (threads <= 256)
-        hipLaunchKernelGGL(k_gnt_bwd<256>, dim3((unsigned)n_rays), dim3(threads), 0, (hipStream_t)stream, blob, ray_diff, mask,
-                           d_rgb, n_samples, n_views, depth, d_rgb_feat, workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1));
-    else
-        hipLaunchKernelGGL(k_gnt_bwd<1024>, dim3((unsigned)n_rays), dim3(threads), 0, (hipStream_t)stream, blob, ray_diff, mask,
-                           d_rgb, n_samples, n_views, depth, d_rgb_feat, workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1));
+    hipLaunchKernelGGL(k_gnt_bwd, dim3((unsigned)n_rays), dim3(threads), 0, (hipStream_t)stream, blob, ray_diff, mask, d_rgb,
+                       n_samples, n_views, depth, d_rgb_feat, workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1));
     NF_LAUNCH_CHECK("nf_gnt_bwd");
     return 0;
 }
