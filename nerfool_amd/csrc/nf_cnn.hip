@@ -116,24 +116,19 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_fwd(const float* __
             rstd_out[p] = rstd;
         }
     }
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp;
     const float* xp = x + p * HW;
     const float* rp = res ? res + n * rs_n + c * rs_c : nullptr;
-    float* out = yp + p * (int64_t)Hp * Wp;
-    // blockIdx.x owns a band of padded rows; threads walk the columns: no per-element integer division
-    const int rows_per = (Hp + gridDim.x - 1) / gridDim.x;
-    const int r0 = blockIdx.x * rows_per, r1 = min(r0 + rows_per, Hp);
-    for (int ph = r0; ph < r1; ++ph) {
-        const int sh = reflect_src(ph - pad, H);
-        const float* xr = xp + sh * W;
-        const float* rr = rp ? rp + sh * rs_h : nullptr;
-        float* orow = out + (int64_t)ph * Wp;
-        for (int pw = threadIdx.x; pw < Wp; pw += blockDim.x) {
-            int sw = reflect_src(pw - pad, W);
-            float v = (xr[sw] - mean) * rstd * g + b;
-            if (rr) v += rr[sw * rs_w];
-            orow[pw] = act_fwd(v, act);
-        }
+    float* out = yp + p * (int64_t)HWp;
+    int seg = (HWp + gridDim.x - 1) / gridDim.x;
+    int lo = blockIdx.x * seg, hi = min(lo + seg, HWp);
+#pragma unroll 4
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        int ph = i / Wp, pw = i - ph * Wp;
+        int sh = reflect_src(ph - pad, H), sw = reflect_src(pw - pad, W);
+        float v = (xp[sh * W + sw] - mean) * rstd * g + b;
+        if (rp) v += rp[sh * rs_h + sw * rs_w];
+        out[i] = act_fwd(v, act);
     }
 }
 
@@ -154,35 +149,39 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd1(const float* _
     float* dxp = dx + p * HW;
     float* drp = d_res ? d_res + p * HW : nullptr;
     const float mean = has_norm ? mean_in[p] : 0.f, rstd = has_norm ? rstd_in[p] : 1.f;
-    const int rows_per = (H + gridDim.x - 1) / gridDim.x;
-    const int r0 = blockIdx.x * rows_per, r1 = min(r0 + rows_per, H);
+    int seg = (HW + gridDim.x - 1) / gridDim.x;
+    int lo = blockIdx.x * seg, hi = min(lo + seg, HW);
     double s1 = 0.0, s2 = 0.0;
-    for (int h = r0; h < r1; ++h) {
-        // padded rows that mirror onto row h
-        int rows[3], nr = 0;
-        rows[nr++] = h + pad;
-        if (h >= 1 && h <= pad) rows[nr++] = pad - h;
-        if (h <= H - 2 && h >= H - 1 - pad) rows[nr++] = 2 * (H - 1) + pad - h;
-        for (int w = threadIdx.x; w < W; w += blockDim.x) {
-            const int i = h * W + w;
-            float d = ep ? ep[i] : 0.f;
-            if (gp) {
-                int cols[3], nc = 0;
+#pragma unroll 2
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        int h = i / W, w = i - h * W;
+        float d = ep ? ep[i] : 0.f;
+        if (gp) {
+            d += gp[(h + pad) * Wp + (w + pad)];
+            // border pixels also collect the padded positions that mirror onto them
+            bool hb = (h >= 1 && h <= pad) || (h <= H - 2 && h >= H - 1 - pad);
+            bool wb = (w >= 1 && w <= pad) || (w <= W - 2 && w >= W - 1 - pad);
+            if (hb || wb) {
+                int rows[3], cols[3], nr = 0, nc = 0;
+                rows[nr++] = h + pad;
+                if (h >= 1 && h <= pad) rows[nr++] = pad - h;
+                if (h <= H - 2 && h >= H - 1 - pad) rows[nr++] = 2 * (H - 1) + pad - h;
                 cols[nc++] = w + pad;
                 if (w >= 1 && w <= pad) cols[nc++] = pad - w;
                 if (w <= W - 2 && w >= W - 1 - pad) cols[nc++] = 2 * (W - 1) + pad - w;
                 for (int a = 0; a < nr; ++a)
-                    for (int b = 0; b < nc; ++b) d += gp[rows[a] * Wp + cols[b]];
+                    for (int b = 0; b < nc; ++b)
+                        if (a + b > 0) d += gp[rows[a] * Wp + cols[b]];
             }
-            float y = yq[(h + pad) * Wp + (w + pad)];
-            float dpre = d * act_grad_from_out(y, act);
-            if (drp) drp[i] = dpre;
-            dxp[i] = dpre;
-            if (has_norm) {
-                float xh = (xq[i] - mean) * rstd;
-                s1 += (double)dpre;
-                s2 += (double)dpre * xh;
-            }
+        }
+        float y = yq[(h + pad) * Wp + (w + pad)];
+        float dpre = d * act_grad_from_out(y, act);
+        if (drp) drp[i] = dpre;
+        dxp[i] = dpre;
+        if (has_norm) {
+            float xh = (xq[i] - mean) * rstd;
+            s1 += (double)dpre;
+            s2 += (double)dpre * xh;
         }
     }
     if (has_norm) block_store_sums(s1, s2, sums + (p * NF_MAX_SPLITS + blockIdx.x) * 2);
@@ -220,14 +219,6 @@ static unsigned nf_apply_splits(int planes, int n) {
     return (unsigned)(splits < 1 ? 1 : splits);
 }
 
-// row-wise passes: bands of rows per workgroup, ~8192 workgroups over the chip, at most NF_MAX_SPLITS bands per plane
-static unsigned nf_row_splits(int planes, int rows) {
-    int splits = 8192 / planes;
-    if (splits > rows) splits = rows;
-    if (splits > NF_MAX_SPLITS) splits = NF_MAX_SPLITS;
-    return (unsigned)(splits < 1 ? 1 : splits);
-}
-
 static unsigned nf_stat_splits(int planes, int HW) {
     int splits = 2048 / planes;
     int cap = HW / 4096;
@@ -250,7 +241,7 @@ extern "C" int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W,
         hipLaunchKernelGGL(k_in_stats, dim3(stat_splits, (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, HW, (double*)scratch);
         NF_LAUNCH_CHECK("nf_in_act_pad_fwd (stats)");
     }
-    hipLaunchKernelGGL(k_in_act_pad_fwd, dim3(nf_row_splits(planes, H + 2 * pad), (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, C, H, W,
+    hipLaunchKernelGGL(k_in_act_pad_fwd, dim3(nf_apply_splits(planes, HWp), (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, C, H, W,
                        gamma, beta, eps, (const double*)scratch, (int)stat_splits, res, rs_n, rs_c, rs_h, rs_w, act, pad, y_padded, mean,
                        rstd);
     NF_LAUNCH_CHECK("nf_in_act_pad_fwd");
@@ -269,13 +260,12 @@ extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, c
         NF_REQUIRE(scratch != nullptr, "nf_in_act_pad_bwd: scratch (512 bytes per plane) required with normalisation");
     }
     dim3 grid(nf_apply_splits(planes, HW), (unsigned)planes);
-    dim3 grid1(nf_row_splits(planes, H), (unsigned)planes);
-    hipLaunchKernelGGL(k_in_act_pad_bwd1, grid1, dim3(NF_CNN_BLOCK), 0, st, dy_padded, d_extra, y_padded, x, H, W, mean, rstd,
+    hipLaunchKernelGGL(k_in_act_pad_bwd1, grid, dim3(NF_CNN_BLOCK), 0, st, dy_padded, d_extra, y_padded, x, H, W, mean, rstd,
                        gamma ? 1 : 0, act, pad, d_res, dx, (double*)scratch);
     NF_LAUNCH_CHECK("nf_in_act_pad_bwd (fold)");
     if (gamma) {
         hipLaunchKernelGGL(k_in_act_pad_bwd2, grid, dim3(NF_CNN_BLOCK), 0, st, x, C, HW, gamma, mean, rstd, (const double*)scratch,
-                           (int)grid1.x, dx);
+                           (int)grid.x, dx);
         NF_LAUNCH_CHECK("nf_in_act_pad_bwd (norm)");
     }
     return 0;
