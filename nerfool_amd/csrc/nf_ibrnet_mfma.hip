@@ -60,7 +60,25 @@ enum {
     MT_BASE1 = MT_VIS0 + 16,         // 2 k-tiles x 16
     MT_BASE0 = MT_BASE1 + 32,        // 4 output tiles (mean feat, var feat, f feat, the 9 colour inputs) x 2 n-blocks x 16
     MT_RECORDS = MT_BASE0 + 128,     // 216
-    NF_MFMA_BLOB_FLOATS = MT_BASE + MT_RECORDS * 64
+    NF_ROWS_BLOB_FLOATS = MT_BASE + MT_RECORDS * 64,     // everything the row kernels stage
+    // ---- per-ray kernels (geometry_fc, q/k/v, fc, out_geometry_fc on the matrix cores; sample = MFMA row)
+    RY_BASE = NF_ROWS_BLOB_FLOATS,
+    RYR_GEO0 = 0,                    // 2 tiles x (16 mean2 + 16 var2 + 1 wmean)        (units: records, relative to RY_BASE)
+    RYR_GEO1 = RYR_GEO0 + 66,        // 2 k-blocks x 16 (16 outputs)
+    RYR_QKV = RYR_GEO1 + 32,         // tile [q | k] 8 steps, tile [v | -] 8 steps
+    RYR_FC = RYR_QKV + 16,           // 8
+    RYR_OG0 = RYR_FC + 8,            // 8
+    RYF_RECORDS = RYR_OG0 + 8,       // 130
+    RYS_BIAS = RYF_RECORDS * 64,     // floats, relative to RY_BASE: 4 bias tiles [h][16]: GEO0 t0, GEO0 t1, GEO1, OG0
+    RYS_LNW = RYS_BIAS + 4 * 32,     // [h][8] LayerNorm weight / bias in fragment order
+    RYS_LNB = RYS_LNW + 16,
+    RYS_OG1 = RYS_LNB + 16,          // [h][8] out_geometry_fc.2 weight, then its bias
+    RYF_FLOATS = RYS_OG1 + 16 + 8,   // forward part
+    RYT_BASE = RYF_FLOATS,           // transposed records (relative to RY_BASE, floats): OG0 8, FC 8, QKV 24, GEO1 16, GEO0 64
+    RYT_OG0 = 0, RYT_FC = 8, RYT_QKV = 16, RYT_GEO1 = 40, RYT_GEO0 = 56, RYT_RECORDS = 120,
+    RYS_GEO0W = RYT_BASE + RYT_RECORDS * 64,     // [2 tiles][h][16] column 64 (the wmean input) of geometry_fc.0
+    RY_FLOATS = RYS_GEO0W + 64,
+    NF_MFMA_BLOB_FLOATS = RY_BASE + RY_FLOATS
 };
 enum { BT_DIR0, BT_DIR1, BT_BASE0A, BT_BASE0B, BT_BASE1, BT_VIS0, BT_VIS1, BT_VISB0, BT_RGB0 };
 
@@ -193,7 +211,54 @@ extern "C" int nf_ibrnet_pack_mfma(const float* nat, float* out) {
                     rec[lane] = i < 9 ? W[(size_t)n * 105 + kcol[i]] : 0.f;
                 }
     }
-    if (rec - out != NF_MFMA_BLOB_FLOATS) return 2;
+    if (rec - out != NF_ROWS_BLOB_FLOATS) return 2;
+    // ================= per-ray kernels =================
+    float* ry = out + RY_BASE;
+    rec = ry;
+    W = nat + nf_lin_w(NF_L_GEO0);                           // [64][65]
+    for (int nt = 0; nt < 2; ++nt) {
+        emit_frag_block(rec, W, 64, 65, 0, nt, 0, 16);
+        emit_frag_block(rec, W, 64, 65, 0, nt, 32, 16);
+        emit_record(rec, W, 64, 65, 0, nt, 64, -1); rec += 64;
+    }
+    W = nat + nf_lin_w(NF_L_GEO1);                           // [16][64]
+    emit_frag_block(rec, W, 16, 64, 0, 0, 0, 16);
+    emit_frag_block(rec, W, 16, 64, 0, 0, 32, 16);
+    {
+        float qk[32 * 16];                                   // rows 0..15 = w_qs, rows 16..31 = w_ks
+        for (int i = 0; i < 256; ++i) { qk[i] = nat[nf_att_w(0) + i]; qk[256 + i] = nat[nf_att_w(1) + i]; }
+        emit_frag_block(rec, qk, 32, 16, 0, 0, 0, 8);
+        emit_frag_block(rec, nat + nf_att_w(2), 16, 16, 0, 0, 0, 8);
+        emit_frag_block(rec, nat + nf_att_w(3), 16, 16, 0, 0, 0, 8);             // fc
+        emit_frag_block(rec, nat + nf_lin_w(NF_L_OG0), 16, 16, 0, 0, 0, 8);
+        if (rec - ry != RYF_RECORDS * 64) return 3;
+        emit_bias_tile(ry + RYS_BIAS + 0 * 32, nat + nf_lin_b(NF_L_GEO0), 32, 0);
+        emit_bias_tile(ry + RYS_BIAS + 1 * 32, nat + nf_lin_b(NF_L_GEO0) + 32, 32, 0);
+        emit_bias_tile(ry + RYS_BIAS + 2 * 32, nat + nf_lin_b(NF_L_GEO1), 16, 0);
+        emit_bias_tile(ry + RYS_BIAS + 3 * 32, nat + nf_lin_b(NF_L_OG0), 16, 0);
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 8; ++r) {
+                ry[RYS_LNW + h * 8 + r] = nat[NF_LN_W + nf_nidx(r, h)];
+                ry[RYS_LNB + h * 8 + r] = nat[NF_LN_B + nf_nidx(r, h)];
+                ry[RYS_OG1 + h * 8 + r] = nat[nf_lin_w(NF_L_OG1) + nf_nidx(r, h)];
+            }
+        ry[RYS_OG1 + 16] = nat[nf_lin_b(NF_L_OG1)];
+        // transposed records
+        rec = ry + RYT_BASE;
+        emit_frag_block_T(rec, nat + nf_lin_w(NF_L_OG0), 16, 16, 0, 0, 8);
+        emit_frag_block_T(rec, nat + nf_att_w(3), 16, 16, 0, 0, 8);
+        emit_frag_block_T(rec, qk, 32, 16, 0, 0, 16);
+        emit_frag_block_T(rec, nat + nf_att_w(2), 16, 16, 0, 0, 8);
+        emit_frag_block_T(rec, nat + nf_lin_w(NF_L_GEO1), 16, 64, 0, 0, 8);
+        emit_frag_block_T(rec, nat + nf_lin_w(NF_L_GEO1), 16, 64, 32, 0, 8);
+        W = nat + nf_lin_w(NF_L_GEO0);
+        for (int kt = 0; kt < 2; ++kt)
+            for (int nb = 0; nb < 2; ++nb) emit_frag_block_T(rec, W, 64, 65, kt * 32, nb * 32, 16);
+        if (rec - (ry + RYT_BASE) != RYT_RECORDS * 64) return 4;
+        for (int t = 0; t < 2; ++t)
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) ry[RYS_GEO0W + t * 32 + h * 16 + r] = W[(size_t)(t * 32 + nf_nidx(r, h)) * 65 + 64];
+    }
     return 0;
 }
 
@@ -604,7 +669,7 @@ __global__ void __launch_bounds__(256, 1) k_ibr_rows_bwd(const float* __restrict
                                                          const float* __restrict__ d_smp, int64_t n_samples, int aa,
                                                          float* __restrict__ d_rgb_feat) {
     HIP_DYNAMIC_SHARED(float, lds)
-    for (int i = threadIdx.x; i < NF_MFMA_BLOB_FLOATS; i += blockDim.x) lds[i] = wblob[i];
+    for (int i = threadIdx.x; i < NF_ROWS_BLOB_FLOATS; i += blockDim.x) lds[i] = wblob[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
@@ -1014,6 +1079,355 @@ __global__ void __launch_bounds__(MAXT) k_ibr_ray_bwd(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// kernel B on the matrix cores (S in {32, 64, 128}): a wave owns 32 consecutive samples of one ray (sample = MFMA row),
+// geometry_fc / q,k,v / fc / out_geometry_fc are register-chained MFMA GEMMs like the row kernels, the ray attention runs
+// on the VALU with K/V of the ray in LDS -- each lane half holds two complete heads of its sample (fragment registers
+// 0-3 = head h, 4-7 = head 2 + h), so the halves split the four heads.  Workgroups are persistent (weights staged once).
+// ---------------------------------------------------------------------------------------------------------------
+#define RYL(off) (lds[RY_OFF + (off)])      // RY_OFF: where the ray section sits inside this kernel's LDS image
+
+struct RayActs {
+    f32x16 MEAN2, VAR2, G1a, G1b;
+    float g[8], gpe[8], q[8], k[8], v[8], o[8], xhat[8], og1[8];
+    float wmean, nval, rstd, sig_pre, mx[2], l[2];
+};
+
+__device__ __forceinline__ f32x16 ray_bias(const float* rs, int tile, int h) {
+    f32x16 a;
+    const float* b = rs + RYS_BIAS + tile * 32 + h * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = b[r];
+    return a;
+}
+
+template <int NSTEPS>
+__device__ __forceinline__ f32x16 ray_gemm(const float* rs, int rec, int lane, const f32x16& x, f32x16 acc) {
+#pragma unroll
+    for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(rs[(rec + r) * 64 + lane], x[r], acc);
+    return acc;
+}
+
+template <int NSTEPS>
+__device__ __forceinline__ f32x16 ray_gemm8(const float* rs, int rec, int lane, const float (&x)[8], f32x16 acc) {
+#pragma unroll
+    for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(rs[(rec + r) * 64 + lane], x[r], acc);
+    return acc;
+}
+
+// per-sample forward up to q/k/v (rs = LDS pointer to the ray section)
+__device__ __forceinline__ void ray_forward_a(const float* rs, int lane, int h, const float* __restrict__ rec,
+                                              const float* __restrict__ pe, RayActs& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        a.MEAN2[r] = rec[nf_nidx(r, h)];
+        a.VAR2[r] = rec[32 + nf_nidx(r, h)];
+    }
+    a.wmean = rec[64];
+    a.nval = rec[68];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        int rc = RYR_GEO0 + nt * 33;
+        f32x16 acc = ray_bias(rs, nt, h);
+        acc = ray_gemm<16>(rs, rc, lane, a.MEAN2, acc);
+        acc = ray_gemm<16>(rs, rc + 16, lane, a.VAR2, acc);
+        acc = NF_MFMA(rs[(rc + 32) * 64 + lane], h ? 0.f : a.wmean, acc);
+        if (nt == 0) a.G1a = elu16(acc); else a.G1b = elu16(acc);
+    }
+    {
+        f32x16 acc = ray_bias(rs, 2, h);
+        acc = ray_gemm<16>(rs, RYR_GEO1, lane, a.G1a, acc);
+        acc = ray_gemm<16>(rs, RYR_GEO1 + 16, lane, a.G1b, acc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            a.g[r] = mf_elu(acc[r]);
+            a.gpe[r] = a.g[r] + pe[nf_nidx(r, h)];
+        }
+    }
+    {
+        f32x16 z = zero16();
+        f32x16 qk = ray_gemm8<8>(rs, RYR_QKV, lane, a.gpe, z);
+        f32x16 vv = ray_gemm8<8>(rs, RYR_QKV + 8, lane, a.gpe, z);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            a.q[r] = qk[r];
+            a.k[r] = qk[8 + r];
+            a.v[r] = vv[r];
+        }
+    }
+}
+
+// attention of this lane's two heads over the S keys in LDS (Ks / Vs: [S][16]); masked query rows (n_valid <= 1) use
+// q = 0: all scores equal => uniform attention, exactly what masked_fill(-1e9) + softmax gives (mlp_network.py:36)
+__device__ __forceinline__ void ray_attention(const float* Ks, const float* Vs, int S, int h, RayActs& a) {
+    const bool row_on = a.nval > 1.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int head = h + 2 * j;
+        float q0 = row_on ? a.q[4 * j + 0] * 0.5f : 0.f, q1 = row_on ? a.q[4 * j + 1] * 0.5f : 0.f,
+              q2 = row_on ? a.q[4 * j + 2] * 0.5f : 0.f, q3 = row_on ? a.q[4 * j + 3] * 0.5f : 0.f;
+        float mx = -3.0e38f;
+        for (int k = 0; k < S; ++k) {
+            const float* kp = Ks + k * 16 + head * 4;
+            mx = fmaxf(mx, fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0]))));
+        }
+        float l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int k = 0; k < S; ++k) {
+            const float* kp = Ks + k * 16 + head * 4;
+            const float* vp = Vs + k * 16 + head * 4;
+            float p = mf_exp(fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0]))) - mx);
+            l += p;
+            a0 = fmaf(p, vp[0], a0); a1 = fmaf(p, vp[1], a1); a2 = fmaf(p, vp[2], a2); a3 = fmaf(p, vp[3], a3);
+        }
+        float rl = 1.f / l;
+        a.o[4 * j + 0] = a0 * rl; a.o[4 * j + 1] = a1 * rl; a.o[4 * j + 2] = a2 * rl; a.o[4 * j + 3] = a3 * rl;
+        a.mx[j] = mx;
+        a.l[j] = l;
+    }
+}
+
+// fc + residual, LayerNorm (eps 1e-6), out_geometry_fc -> sigma
+__device__ __forceinline__ float ray_forward_b(const float* rs, int lane, int h, RayActs& a) {
+    f32x16 pre = ray_gemm8<8>(rs, RYR_FC, lane, a.o, zero16());
+    float s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        pre[r] += a.gpe[r];
+        s1 += pre[r];
+    }
+    float mu = half_sum(s1) / 16.f;
+    float s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s2 += (pre[r] - mu) * (pre[r] - mu);
+    a.rstd = 1.f / sqrtf(half_sum(s2) / 16.f + 1e-6f);
+    float gat[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        a.xhat[r] = (pre[r] - mu) * a.rstd;
+        gat[r] = a.xhat[r] * rs[RYS_LNW + h * 8 + r] + rs[RYS_LNB + h * 8 + r];
+    }
+    f32x16 og = ray_gemm8<8>(rs, RYR_OG0, lane, gat, ray_bias(rs, 3, h));
+    float sp = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        a.og1[r] = mf_elu(og[r]);
+        sp = fmaf(rs[RYS_OG1 + h * 8 + r], a.og1[r], sp);
+    }
+    a.sig_pre = half_sum(sp) + rs[RYS_OG1 + 16];
+    float sigma = fmaxf(a.sig_pre, 0.f);
+    return a.nval < 1.f ? 0.f : sigma;
+}
+
+template <int WPR>      // waves (32-sample tiles) per ray: S = 32 * WPR
+__global__ void __launch_bounds__(256, 2) k_ibr_ray_fwd_mfma(const float* __restrict__ wblob, const float* __restrict__ pos_enc,
+                                                             const float* __restrict__ smp, int64_t n_rays,
+                                                             float* __restrict__ raw) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int S = 32 * WPR, RPI = 4 / WPR;           // rays per workgroup iteration
+    float* rs = lds;                                      // [0, RYF_FLOATS): forward part of the ray section
+    float* kv = lds + RYF_FLOATS;                         // 4 waves x 32 samples x (16 K + 16 V)
+    for (int i = threadIdx.x; i < RYF_FLOATS; i += blockDim.x) rs[i] = wblob[RY_BASE + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t n_iter = (n_rays + RPI - 1) / RPI;
+    for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        asm volatile("" ::: "memory");
+        int64_t ray = it * RPI + wave / WPR;
+        const bool live = ray < n_rays;
+        if (!live) ray = n_rays - 1;
+        const int s = (wave % WPR) * 32 + m;
+        const float* rec = smp + (ray * S + s) * NF_SMP_STRIDE;
+        RayActs a;
+        ray_forward_a(rs, lane, h, rec, pos_enc + (size_t)s * 16, a);
+        float* Ks = kv + (wave / WPR) * (S * 32);
+        float* Vs = Ks + S * 16;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            Ks[s * 16 + nf_nidx(r, h)] = a.k[r];
+            Vs[s * 16 + nf_nidx(r, h)] = a.v[r];
+        }
+        __syncthreads();
+        ray_attention(Ks, Vs, S, h, a);
+        float sigma = ray_forward_b(rs, lane, h, a);
+        if (live && h == 0) {
+            float* ro = raw + (ray * S + s) * 4;
+            ro[0] = rec[65]; ro[1] = rec[66]; ro[2] = rec[67]; ro[3] = sigma;
+        }
+        __syncthreads();      // K/V of this iteration are dead before the next one overwrites them
+    }
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------
+template <int NSTEPS>
+__device__ __forceinline__ f32x16 ray_gemm_T(const float* rs, int rec, int lane, const f32x16& dy, f32x16 acc) {
+#pragma unroll
+    for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(rs[RYT_BASE + (rec + r) * 64 + lane], dy[r], acc);
+    return acc;
+}
+template <int NSTEPS>
+__device__ __forceinline__ f32x16 ray_gemm8_T(const float* rs, int rec, int lane, const float (&dy)[8], f32x16 acc) {
+#pragma unroll
+    for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(rs[RYT_BASE + (rec + r) * 64 + lane], dy[r], acc);
+    return acc;
+}
+
+// LDS per ray in the backward: K, V, Q, dO [S][16]; M, Linv, D [S][4]
+#define RAY_BWD_LDS_PER_SAMPLE (4 * 16 + 3 * 4)
+
+template <int WPR>
+__global__ void __launch_bounds__(256, 1) k_ibr_ray_bwd_mfma(const float* __restrict__ wblob, const float* __restrict__ pos_enc,
+                                                             const float* __restrict__ smp, const float* __restrict__ d_raw,
+                                                             int64_t n_rays, float* __restrict__ d_smp) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int S = 32 * WPR, RPI = 4 / WPR;
+    float* rs = lds;
+    float* ray_lds = lds + RY_FLOATS;
+    for (int i = threadIdx.x; i < RY_FLOATS; i += blockDim.x) rs[i] = wblob[RY_BASE + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t n_iter = (n_rays + RPI - 1) / RPI;
+    for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        asm volatile("" ::: "memory");
+        int64_t ray = it * RPI + wave / WPR;
+        const bool live = ray < n_rays;
+        if (!live) ray = n_rays - 1;
+        const int s = (wave % WPR) * 32 + m;
+        const float* rec = smp + (ray * S + s) * NF_SMP_STRIDE;
+        RayActs a;
+        ray_forward_a(rs, lane, h, rec, pos_enc + (size_t)s * 16, a);
+        float* Ks = ray_lds + (wave / WPR) * (S * RAY_BWD_LDS_PER_SAMPLE);
+        float* Vs = Ks + S * 16;
+        float* Qs = Vs + S * 16;
+        float* Gs = Qs + S * 16;          // d_o
+        float* Ms = Gs + S * 16;          // row max, 1 / row sum, D per (sample, head)
+        float* Ls = Ms + S * 4;
+        float* Ds = Ls + S * 4;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            Ks[s * 16 + nf_nidx(r, h)] = a.k[r];
+            Vs[s * 16 + nf_nidx(r, h)] = a.v[r];
+            Qs[s * 16 + nf_nidx(r, h)] = a.nval > 1.f ? a.q[r] * 0.5f : 0.f;      // scaled; masked query rows score 0
+        }
+        __syncthreads();
+        ray_attention(Ks, Vs, S, h, a);
+        (void)ray_forward_b(rs, lane, h, a);
+        // ---- density head + LayerNorm backward (oracle/ibrnet_manual_bwd.py)
+        const float* graw = d_raw + (ray * S + s) * 4;
+        float d_sp = (a.nval >= 1.f && a.sig_pre > 0.f) ? graw[3] : 0.f;
+        float d_og[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d_og[r] = rs[RYS_OG1 + h * 8 + r] * d_sp * mf_elu_grad(a.og1[r]);
+        f32x16 d_gat = ray_gemm8_T<8>(rs, RYT_OG0, lane, d_og, zero16());
+        float d_xh[8], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            d_xh[r] = d_gat[r] * rs[RYS_LNW + h * 8 + r];
+            m1 += d_xh[r];
+            m2 += d_xh[r] * a.xhat[r];
+        }
+        m1 = half_sum(m1) / 16.f;
+        m2 = half_sum(m2) / 16.f;
+        float d_pre[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d_pre[r] = a.rstd * (d_xh[r] - m1 - a.xhat[r] * m2);
+        f32x16 d_o = ray_gemm8_T<8>(rs, RYT_FC, lane, d_pre, zero16());
+        const bool row_on = a.nval > 1.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int head = h + 2 * j;
+            float D = 0.f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                Gs[s * 16 + head * 4 + d] = d_o[4 * j + d];
+                D = fmaf(d_o[4 * j + d], a.o[4 * j + d], D);
+            }
+            Ms[s * 4 + head] = row_on ? a.mx[j] : 0.f;
+            Ls[s * 4 + head] = 1.f / a.l[j];
+            Ds[s * 4 + head] = D;
+        }
+        __syncthreads();
+        // ---- attention backward: dQ (this sample as query), dK / dV (this sample as key); masked query rows have zero
+        //      scores (q = 0), contribute to dV with uniform weights and nothing to dQ / dK
+        float dq[8], dk[8], dv[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int head = h + 2 * j;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            if (row_on) {
+                float q0 = a.q[4 * j] * 0.5f, q1 = a.q[4 * j + 1] * 0.5f, q2 = a.q[4 * j + 2] * 0.5f, q3 = a.q[4 * j + 3] * 0.5f;
+                float g0 = d_o[4 * j], g1 = d_o[4 * j + 1], g2 = d_o[4 * j + 2], g3 = d_o[4 * j + 3];
+                float mx = a.mx[j], rl = 1.f / a.l[j], D = Ds[s * 4 + head];
+                for (int k = 0; k < S; ++k) {
+                    const float* kp = Ks + k * 16 + head * 4;
+                    const float* vp = Vs + k * 16 + head * 4;
+                    float p = mf_exp(fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0]))) - mx) * rl;
+                    float dA = fmaf(g3, vp[3], fmaf(g2, vp[2], fmaf(g1, vp[1], g0 * vp[0])));
+                    float dS = p * (dA - D);
+                    a0 = fmaf(dS, kp[0], a0); a1 = fmaf(dS, kp[1], a1); a2 = fmaf(dS, kp[2], a2); a3 = fmaf(dS, kp[3], a3);
+                }
+            }
+            dq[4 * j] = a0 * 0.5f; dq[4 * j + 1] = a1 * 0.5f; dq[4 * j + 2] = a2 * 0.5f; dq[4 * j + 3] = a3 * 0.5f;
+            float k0 = a.k[4 * j], k1 = a.k[4 * j + 1], k2 = a.k[4 * j + 2], k3 = a.k[4 * j + 3];
+            float v0 = a.v[4 * j], v1 = a.v[4 * j + 1], v2 = a.v[4 * j + 2], v3 = a.v[4 * j + 3];
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+            for (int qi = 0; qi < S; ++qi) {
+                const float* qp = Qs + qi * 16 + head * 4;
+                const float* gp = Gs + qi * 16 + head * 4;
+                float q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];          // pre-scaled; zero for masked query rows
+                float p = mf_exp(fmaf(q3, k3, fmaf(q2, k2, fmaf(q1, k1, q0 * k0))) - Ms[qi * 4 + head]) * Ls[qi * 4 + head];
+                c0 = fmaf(p, gp[0], c0); c1 = fmaf(p, gp[1], c1); c2 = fmaf(p, gp[2], c2); c3 = fmaf(p, gp[3], c3);
+                float dA = fmaf(gp[3], v3, fmaf(gp[2], v2, fmaf(gp[1], v1, gp[0] * v0)));
+                float dS = p * (dA - Ds[qi * 4 + head]);
+                b0 = fmaf(dS, q0, b0); b1 = fmaf(dS, q1, b1); b2 = fmaf(dS, q2, b2); b3 = fmaf(dS, q3, b3);
+            }
+            dk[4 * j] = b0; dk[4 * j + 1] = b1; dk[4 * j + 2] = b2; dk[4 * j + 3] = b3;
+            dv[4 * j] = c0; dv[4 * j + 1] = c1; dv[4 * j + 2] = c2; dv[4 * j + 3] = c3;
+        }
+        // ---- d gpe = d pre + Wq^T dq + Wk^T dk + Wv^T dv ; geometry_fc backward
+        f32x16 dqk;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            dqk[r] = dq[r];
+            dqk[8 + r] = dk[r];
+        }
+        f32x16 d_gpe = ray_gemm_T<16>(rs, RYT_QKV, lane, dqk, zero16());
+        d_gpe = ray_gemm8_T<8>(rs, RYT_QKV + 16, lane, dv, d_gpe);
+        float d_g[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d_g[r] = (d_gpe[r] + d_pre[r]) * mf_elu_grad(a.g[r]);
+        f32x16 d_g1a = ray_gemm8_T<8>(rs, RYT_GEO1, lane, d_g, zero16());
+        f32x16 d_g1b = ray_gemm8_T<8>(rs, RYT_GEO1 + 8, lane, d_g, zero16());
+        float dw = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            d_g1a[r] *= mf_elu_grad(a.G1a[r]);
+            d_g1b[r] *= mf_elu_grad(a.G1b[r]);
+            dw = fmaf(rs[RYS_GEO0W + 0 * 32 + h * 16 + r], d_g1a[r], dw);
+            dw = fmaf(rs[RYS_GEO0W + 1 * 32 + h * 16 + r], d_g1b[r], dw);
+        }
+        dw = half_sum(dw);
+        f32x16 d_mean2 = ray_gemm_T<16>(rs, RYT_GEO0 + 16, lane, d_g1b, ray_gemm_T<16>(rs, RYT_GEO0, lane, d_g1a, zero16()));
+        f32x16 d_var2 = ray_gemm_T<16>(rs, RYT_GEO0 + 48, lane, d_g1b, ray_gemm_T<16>(rs, RYT_GEO0 + 32, lane, d_g1a, zero16()));
+        if (live) {
+            float* out = d_smp + (ray * S + s) * NF_SMP_STRIDE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                out[nf_nidx(r, h)] = d_mean2[r];
+                out[32 + nf_nidx(r, h)] = d_var2[r];
+            }
+            if (h == 0) {
+                out[64] = dw;
+                out[65] = graw[0];
+                out[66] = graw[1];
+                out[67] = graw[2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int nf_ibrnet_mfma_supported(int n_samples, int n_views) {
@@ -1052,6 +1466,20 @@ extern "C" int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, con
         default: launch_rows_fwd<32>(mfma_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
     }
     NF_LAUNCH_CHECK("nf_ibrnet_fwd_mfma (rows)");
+    if (n_samples == 32 || n_samples == 64 || n_samples == 128) {       // per-ray part on the matrix cores as well
+        const int wpr = n_samples / 32, rpi = 4 / wpr;
+        int64_t iters = (n_rays + rpi - 1) / rpi;
+        unsigned blocks = (unsigned)(iters < 512 ? iters : 512);
+        size_t smem_ray = (size_t)(RYF_FLOATS + 4 * 32 * 32) * sizeof(float);
+        if (wpr == 1)
+            hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<1>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);
+        else if (wpr == 2)
+            hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<2>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);
+        else
+            hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<4>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);
+        NF_LAUNCH_CHECK("nf_ibrnet_fwd_mfma (ray, mfma)");
+        return 0;
+    }
     int threads = ((n_samples + 63) / 64) * 64;
     size_t smem = (size_t)n_samples * 32 * sizeof(float);
     if (threads <= 256)
@@ -1068,7 +1496,7 @@ template <int V>
 static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
                            const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, hipStream_t st) {
     static bool configured = false;      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
-    const size_t smem = NF_MFMA_BLOB_FLOATS * sizeof(float);
+    const size_t smem = NF_ROWS_BLOB_FLOATS * sizeof(float);
     if (!configured) {
         if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
             hipSuccess) {
@@ -1096,6 +1524,30 @@ extern "C" int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, con
     hipStream_t st = (hipStream_t)stream;
     int threads = ((n_samples + 63) / 64) * 64;
     size_t smem = (size_t)n_samples * 77 * sizeof(float);
+    const bool ray_mfma = n_samples == 32 || n_samples == 64 || n_samples == 128;
+    if (ray_mfma) {
+        const int wpr = n_samples / 32, rpi = 4 / wpr;
+        int64_t iters = (n_rays + rpi - 1) / rpi;
+        unsigned blocks = (unsigned)(iters < 256 ? iters : 256);
+        size_t smem_ray = (size_t)(RY_FLOATS + 4 * 32 * RAY_BWD_LDS_PER_SAMPLE) * sizeof(float);
+        static bool configured[3] = {false, false, false};
+        const void* fn = wpr == 1 ? (const void*)k_ibr_ray_bwd_mfma<1> : (wpr == 2 ? (const void*)k_ibr_ray_bwd_mfma<2>
+                                                                                   : (const void*)k_ibr_ray_bwd_mfma<4>);
+        int slot = wpr == 1 ? 0 : (wpr == 2 ? 1 : 2);
+        if (!configured[slot]) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ray) != hipSuccess) {
+                nf_set_error("nf_ibrnet_bwd_mfma: cannot reserve %zu bytes of LDS", smem_ray);
+                return 1;
+            }
+            configured[slot] = true;
+        }
+        if (wpr == 1)
+            hipLaunchKernelGGL(k_ibr_ray_bwd_mfma<1>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
+        else if (wpr == 2)
+            hipLaunchKernelGGL(k_ibr_ray_bwd_mfma<2>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
+        else
+            hipLaunchKernelGGL(k_ibr_ray_bwd_mfma<4>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
+    } else {
     NF_REQUIRE(smem <= 64 * 1024, "nf_ibrnet_bwd_mfma: S=%d exceeds the LDS budget of the ray kernel", n_samples);
     if (threads <= 256)
         hipLaunchKernelGGL(k_ibr_ray_bwd<256>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc, smp, d_raw,
@@ -1103,6 +1555,7 @@ extern "C" int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, con
     else
         hipLaunchKernelGGL(k_ibr_ray_bwd<NF_IBR_MAX_S>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc, smp,
                            d_raw, n_samples, d_workspace);
+    }
     NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (ray)");
     int64_t ns = n_rays * n_samples;
     int rc;

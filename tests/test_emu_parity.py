@@ -95,7 +95,7 @@ def test_mfma_kernels_match_generic_kernels():
     import torch
     from nerfool_amd import ops
     from oracle.ibrnet_ref import random_ibrnet_params
-    for R, S, V in ((3, 10, 4), (2, 9, 2)):
+    for R, S, V in ((3, 10, 4), (2, 9, 2), (5, 32, 4), (3, 64, 2)):      # S = 32 / 64: per-ray part on MFMA too
         gen = torch.Generator().manual_seed(S)
         p = random_ibrnet_params(S, seed=3)
         blob = ops.pack_ibrnet_blob(p, 'cpu')
