@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--model', choices=('ibrnet', 'gnt'), default='ibrnet',
                     help="'gnt' = BASELINE config 4 (GNT depth 8, 800x800, 10 views, 64 samples) -- not the headline line")
     ap.add_argument('--depth', type=int, default=8, help='GNT trans_depth')
+    ap.add_argument('--cnn-shard', choices=('view', 'replicated'), default='view',
+                    help='N > 1: feature CNN sharded by source view (exchange of feature maps) or replicated on every rank')
     ap.add_argument('--cpu-iters', type=int, default=2, help='timed CPU-oracle PGD iterations for cpu_baseline (0 = skip)')
     return ap.parse_args()
 
@@ -128,16 +130,24 @@ def main():
     import __graft_entry__ as entry
     if not os.path.exists(entry.LIB):
         entry.build()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one rank per GPU; the modulo only matters for the 1-GPU debugging set-up below (several ranks on one device)
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     shard = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        # 'nccl' is RCCL.  NERFOOL_DIST_BACKEND=gloo lets two ranks share ONE GPU to exercise the sharded path on a
+        # single-GPU box (RCCL refuses duplicate devices); it is a functional check, never a measurement.
+        backend = os.environ.get('NERFOOL_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     args, data, model, sampler, src_ray_batch, projector, EA = build_problem(a, dev)
     if world > 1:
-        shard = EA.RayShard()
+        shard = EA.RayShard(shard_views=a.cnn_shard == 'view')
     from nerfool_amd import prof
     attack = EA.PGDAttack(args, model, projector, src_ray_batch, shard=shard)
 
@@ -238,7 +248,7 @@ def main():
                                 % (a.height, a.width, V, Sc, a.importance, a.n_rand)) if a.model == 'ibrnet' else
                                ('BASELINE config 4: GNT depth %d view-specific attack, synthetic scene %dx%d, %d source views, %d '
                                 'samples/ray, N_rand=%d rays per rank per step' % (a.depth, a.height, a.width, V, Sc, a.n_rand)),
-                   'rays_per_step_all_ranks': rays_per_step, 'parallelism': 'ray-sharded dp%d' % world},
+                   'rays_per_step_all_ranks': rays_per_step, 'parallelism': 'ray-sharded dp%d%s' % (world, ', feature CNN sharded by source view' if world > 1 and a.cnn_shard == 'view' else '')},
         'roofline': roofline,
         'cpu_baseline': None,
         'extra': {'attack_s_per_1000_iters': 1e3 * elapsed / a.steps, 'final_loss': final_loss, 'kernels': table,

@@ -67,7 +67,10 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
         if shard is not None:
             select_inds = select_inds[shard.rank::shard.world]
     train_ray_batch = sampler.select(select_inds)
-    featmaps = model.feature_net((src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
+    if shard is not None and shard.shard_views and shard.world > 1:
+        featmaps = shard.view_sharded_featmaps(model.feature_net, src_ray_batch['src_rgbs'], delta)
+    else:
+        featmaps = model.feature_net((src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
     if _is_gnt(model):      # eval/gnt/eval_adv.py:319-333: GNT renderer, criterion passed in (unmasked MSE)
         from .gnt.criterion import Criterion as GntCriterion
         from .gnt.render_ray import render_rays as gnt_render_rays
@@ -95,18 +98,85 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
     return torch.autograd.grad(loss, delta)[0].detach()
 
 
-class RayShard:
-    """Data-parallel ray sharding over the ranks of a torch.distributed group (backend 'nccl' = RCCL over xGMI on the
-    GPU box, 'gloo' in the CPU tests).  Two collectives per PGD step: a 2-float all-reduce of the mask counts (they set
-    the loss denominators, utils.py:58) and ONE all-reduce of d(delta) (valid because the CNN backward is linear in the
-    upstream gradient).  Every rank then applies the identical deterministic update, so delta stays replicated."""
+class _GatherViewFeatures(torch.autograd.Function):
+    """forward: each rank contributes the feature maps of the source views it owns and every rank receives all V of them
+    (sum of disjointly filled buffers); backward: d featmaps summed over the ranks (each rank rendered other rays), every
+    rank keeps the slice of its own views.  Runs on every rank in both directions, also on ranks that own no view."""
 
-    def __init__(self, group=None):
+    @staticmethod
+    def forward(ctx, local, shard, lo, hi, n_views):
+        full = torch.zeros((n_views,) + tuple(local.shape[1:]), dtype=local.dtype,
+                           device=local.device).contiguous(memory_format=torch.channels_last)
+        if hi > lo:
+            full[lo:hi] = local
+        shard.all_reduce_nhwc_(full)
+        ctx.shard, ctx.lo, ctx.hi = shard, lo, hi
+        return full
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone(memory_format=torch.channels_last)          # never reduce into autograd's own buffer
+        ctx.shard.all_reduce_nhwc_(g)
+        return g[ctx.lo:ctx.hi], None, None, None, None
+
+
+class RayShard:
+    """Data-parallel sharding of one PGD step over the ranks of a torch.distributed group (backend 'nccl' = RCCL over
+    xGMI on the GPU box, 'gloo' in the CPU tests).
+
+    rays: every rank renders its slice of the step's rays.  Collectives: a 2-float all-reduce of the mask counts (they
+    set the loss denominators, utils.py:58) and ONE all-reduce of d(delta) (valid because the CNN backward is linear in the
+    upstream gradient).  Every rank then applies the identical deterministic update, so delta stays replicated.
+
+    source views (shard_views=True, SURVEY 8e "shard the CNN by view"): the V source images are independent samples of
+    the feature CNN (InstanceNorm is per sample, feature_network.py:137,180), so rank r runs the CNN forward/backward only
+    for its contiguous block of views; the feature maps are exchanged with one all-reduce of disjointly filled buffers
+    forward and one all-reduce (sum) of d featmaps backward.  d(delta) of a rank is then non-zero only on its own views
+    and the all-reduce above assembles the full gradient."""
+
+    def __init__(self, group=None, shard_views=True):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.shard_views = bool(shard_views)
+
+    def view_range(self, n_views):
+        """contiguous block of source views owned by this rank (ragged when world does not divide V; empty for the
+        ranks beyond V)."""
+        base, extra = divmod(n_views, self.world)
+        lo = self.rank * base + min(self.rank, extra)
+        return lo, lo + base + (1 if self.rank < extra else 0)
+
+    def all_reduce_nhwc_(self, t):
+        flat = t.permute(0, 2, 3, 1)            # channels-last storage seen as a plain contiguous [V,H,W,C] tensor
+        assert flat.is_contiguous()
+        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def view_sharded_featmaps(self, feature_net, src_rgbs, delta):
+        """feature_net(src + delta) with the views split over the ranks -> the same tuple the network returns."""
+        n_views, H, W = src_rgbs.shape[1], src_rgbs.shape[2], src_rgbs.shape[3]
+        lo, hi = self.view_range(n_views)
+        if hi > lo:
+            outs = feature_net((src_rgbs[:, lo:hi] + delta[:, lo:hi]).squeeze(0).permute(0, 3, 1, 2))
+            twice = outs[1] is outs[0]
+            parts = [o for o in (outs[:1] if twice else outs) if o is not None]
+            channels = [int(o.shape[1]) for o in parts]
+            local = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+            layout = (channels, twice, outs[1] is None)
+        else:       # nothing to compute here, but this rank still takes part in both exchanges
+            channels, twice, second_none, Hf, Wf = feature_net.describe_output(H, W)
+            local = delta.new_zeros((0, sum(channels), Hf, Wf)) + delta[:, 0:0].sum()
+            layout = (channels, twice, second_none)
+        full = _GatherViewFeatures.apply(local, self, lo, hi, n_views)
+        channels, twice, second_none = layout
+        if twice:
+            return full, full
+        if second_none:
+            return full, None
+        return full[:, :channels[0]], full[:, channels[0]:]
 
     def global_mask_counts(self, ret):
         def count(o):       # masked MSE counts the valid rays, the unmasked one (GNT) every ray

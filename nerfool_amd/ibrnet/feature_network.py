@@ -96,6 +96,19 @@ class ResUNet(nn.Module):
         self.iconv2 = _ConvNormELU(64 + 64, out_ch, 3)
         self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
 
+    def describe_output(self, H, W):
+        """(channels of the distinct maps, same-map-twice, second-is-None, Hf, Wf) of forward() on [*, 3, H, W]: every
+        stride-2 stage gives ceil(n / 2), the decoder doubles twice (feature_network.py:245-268)."""
+        def size(n):
+            for _ in range(4):
+                n = (n + 1) // 2
+            return 4 * n
+        if self.single_net:
+            return [self.coarse_out_ch], True, False, size(H), size(W)
+        if self.coarse_only:
+            return [self.coarse_out_ch], False, True, size(H), size(W)
+        return [self.coarse_out_ch, self.fine_out_ch], False, False, size(H), size(W)
+
     def forward(self, x):
         frozen = not any(p.requires_grad for p in self.parameters())
         if CNN_PATH == 'fused' and frozen and (x.is_cuda or ops._lib.emulated()):

@@ -1,7 +1,8 @@
-"""CPU, world_size 2, gloo: the ray-sharded PGD step.  Each rank differentiates its slice of the step's rays
+"""CPU, world_size 2 / 3, gloo: the sharded PGD step.  Each rank differentiates its slice of the step's rays
 through the CPU stand-in build of the kernels; the mask counts are all-reduced before the loss is normalised and
-d(delta) is all-reduced once; the result must equal the single-process gradient of the union of the rays, and both
-ranks must hold the same delta after the fused update."""
+d(delta) is all-reduced once; with view sharding each rank also runs the feature CNN only for its own source views and
+the feature maps / their gradients are exchanged.  The result must equal the single-process gradient of the union of the
+rays, and all ranks must hold the same delta after the fused update."""
 import os
 import subprocess
 import sys
@@ -31,40 +32,104 @@ torch.set_num_threads(2)
 g, args, model, data, sampler, dims = pc._attack_setup('cpu')
 src = sampler.get_all()
 picks = g.np('adam/selected_inds')[0]
-shard = EA.RayShard() if world > 1 else None
+shard = EA.RayShard(shard_views=os.environ['SHARD_VIEWS'] == '1') if world > 1 else None
 atk = EA.PGDAttack(args, model, Projector('cpu'), src, shard=shard, delta=g.t('in/delta0').clone().requires_grad_(True))
 mine = picks if world == 1 else picks[rank::world]
 grad = atk.gradient(data, select_inds=mine).clone()
 atk.apply(grad)
-np.savez(os.path.join(%(out)r, 'rank%%d_of_%%d.npz' %% (rank, world)), grad=grad.numpy(), delta=atk.delta.detach().numpy(),
+np.savez(os.path.join(%(out)r, 'rank%%d_of_%%d_%%s.npz' %% (rank, world, os.environ['SHARD_VIEWS'])), grad=grad.numpy(), delta=atk.delta.detach().numpy(),
          loss=float(atk.last_loss))
 if world > 1:
     dist.destroy_process_group()
 '''
 
 
-@pytest.mark.timeout(900)
-def test_ray_sharded_step_equals_single_process(tmp_path):
+def _build_and_script(tmp_path):
     if not os.path.exists('/opt/rocm/lib/llvm/bin/clang++'):
         pytest.skip('clang++ of the ROCm toolchain is needed to build the CPU stand-in')
     subprocess.run([os.path.join(HARNESS, 'build.sh')], check=True, capture_output=True)
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % dict(root=ROOT, harness=HARNESS, out=str(tmp_path)))
+    return script
+
+
+def _run_world(script, env, world, shard_views):
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(env, RANK=str(r), WORLD_SIZE=str(world), SHARD_VIEWS='1' if shard_views else '0'))
+             for r in range(world)]
+    assert all(p.wait() == 0 for p in procs)
+
+
+@pytest.mark.timeout(1500)
+def test_sharded_step_equals_single_process(tmp_path):
+    script = _build_and_script(tmp_path)
     # the shape-generic kernels emulate ~30x faster than the MFMA ones; the sharding logic under test is the same
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', OMP_NUM_THREADS='2',
                NERFOOL_IBRNET_KERNELS='generic', NERFOOL_CNN='torch')
-    single = subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK='0', WORLD_SIZE='1'))
-    assert single.wait() == 0
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE='2')) for r in range(2)]
-    assert all(p.wait() == 0 for p in procs)
-    ref = np.load(tmp_path / 'rank0_of_1.npz')
-    r0 = np.load(tmp_path / 'rank0_of_2.npz')
-    r1 = np.load(tmp_path / 'rank1_of_2.npz')
+    _run_world(script, env, 1, False)
+    ref = np.load(tmp_path / 'rank0_of_1_0.npz')
     scale = np.abs(ref['grad']).max()
-    # all-reduced gradient == gradient of the union of the rays (different summation order only)
-    assert np.abs(r0['grad'] - ref['grad']).max() <= 2e-4 * scale
-    assert np.array_equal(r0['grad'], r1['grad']), 'ranks must hold the identical all-reduced gradient'
-    assert np.array_equal(r0['delta'], r1['delta']), 'delta must stay replicated'
-    # per-rank losses are partial sums over the global denominator: they add up to the single-process loss
-    assert abs(float(r0['loss']) + float(r1['loss']) - float(ref['loss'])) <= 1e-5 * abs(float(ref['loss']))
-    assert np.abs(r0['delta'] - ref['delta']).mean() <= 1e-6
+    # (world, view sharding): rays only; rays + CNN by view (2 + 2 views); ragged view blocks (2 + 1 + 1)
+    for world, shard_views in ((2, False), (2, True), (3, True)):
+        _run_world(script, dict(env, MASTER_PORT=str(29532 + world + 4 * shard_views)), world, shard_views)
+        ranks = [np.load(tmp_path / ('rank%d_of_%d_%d.npz' % (r, world, shard_views))) for r in range(world)]
+        # all-reduced gradient == gradient of the union of the rays (different summation order only)
+        assert np.abs(ranks[0]['grad'] - ref['grad']).max() <= 2e-4 * scale, (world, shard_views)
+        for r in ranks[1:]:
+            assert np.array_equal(ranks[0]['grad'], r['grad']), 'ranks must hold the identical all-reduced gradient'
+            assert np.array_equal(ranks[0]['delta'], r['delta']), 'delta must stay replicated'
+        # per-rank losses are partial sums over the global denominator: they add up to the single-process loss
+        assert abs(sum(float(r['loss']) for r in ranks) - float(ref['loss'])) <= 1e-5 * abs(float(ref['loss']))
+        assert np.abs(ranks[0]['delta'] - ref['delta']).mean() <= 1e-6
+
+
+VIEW_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import torch.distributed as dist
+from nerfool_amd import eval_adv as EA
+from nerfool_amd.ibrnet.feature_network import ResUNet
+
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+torch.set_num_threads(2)
+torch.manual_seed(0)
+net = ResUNet(coarse_out_ch=8, fine_out_ch=8).eval()
+for p in net.parameters():
+    p.requires_grad_(False)
+V, H, W = 2, 40, 56
+src = torch.rand(1, V, H, W, 3)
+delta = (0.03 * torch.randn(1, V, H, W, 3)).requires_grad_(True)
+shard = EA.RayShard()
+assert [shard.view_range(V)] == [[(0, 1), (1, 2), (2, 2)][rank]]
+coarse, fine = shard.view_sharded_featmaps(net, src, delta)
+ref_c, ref_f = net((src + delta.detach()).squeeze(0).permute(0, 3, 1, 2))
+assert coarse.shape == ref_c.shape and fine.shape == ref_f.shape
+tol = 1e-4 * float(ref_c.abs().max())      # batch-1 vs batch-2 convolutions take different CPU code paths
+assert float((coarse.detach() - ref_c).abs().max()) <= tol and float((fine.detach() - ref_f).abs().max()) <= tol, (
+    float((coarse.detach() - ref_c).abs().max()), tol)
+# every rank weights the maps differently (as if it had rendered other rays); d(delta) must be the gradient of the sum
+gen = torch.Generator().manual_seed(5)
+wts = [(torch.randn(ref_c.shape, generator=gen), torch.randn(ref_f.shape, generator=gen)) for _ in range(world)]
+((coarse * wts[rank][0]).sum() + (fine * wts[rank][1]).sum()).backward()
+grad = delta.grad.clone()
+lo, hi = shard.view_range(V)
+assert float(grad[:, :lo].abs().sum()) == 0 and float(grad[:, hi:].abs().sum()) == 0      # only the own views
+shard.all_reduce_grad(grad)
+d2 = delta.detach().clone().requires_grad_(True)
+c2, f2 = net((src + d2).squeeze(0).permute(0, 3, 1, 2))
+((c2 * sum(w[0] for w in wts)).sum() + (f2 * sum(w[1] for w in wts)).sum()).backward()
+assert float((grad - d2.grad).abs().max()) <= 2e-4 * float(d2.grad.abs().max())
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_view_sharded_feature_maps_with_idle_rank(tmp_path):
+    """world 3 over V = 2 source views: rank 2 owns no view but takes part in both exchanges (torch CNN path, no kernels)."""
+    script = tmp_path / 'view_worker.py'
+    script.write_text(VIEW_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', OMP_NUM_THREADS='2', NERFOOL_CNN='torch')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE='3')) for r in range(3)]
+    assert all(p.wait() == 0 for p in procs)
