@@ -149,6 +149,16 @@ int nf_masked_mse_bwd(const float* rgb, const float* gt, const uint8_t* mask, in
                       const float* d_loss, float* d_rgb, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * a14 (glue only)  decoder `upconv`: F.interpolate(scale 2, bilinear, align_corners=True) fused with the reflect padding of
+ * the convolution behind it.   ref: ibrnet/feature_network.py:143-151.
+ *   x: `planes` planes of h x w floats addressed by (xs_plane, xs_row) element strides (unit column stride; may be the
+ *   interior of a padded tensor); y_padded [planes, 2h+2p, 2w+2p].  The backward is nf_in_act_pad_bwd (fold, act 0)
+ *   followed by the transposed interpolation.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int nf_upsample2x_pad_fwd(const float* x, int64_t planes, int64_t xs_plane, int64_t xs_row, int h, int w, int pad,
+                          float* y_padded, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * a11/a13  perturbation update             ref: eval/ibrnet/eval_adv.py:28-29, :248-254, :805-839
  * All tensors flat [n] (delta, grad, exp_avg, exp_avg_sq, src all shaped [1,V,H,W,3]).
  *   nf_project_perturb : delta = max(min(delta, eps), -eps) (skipped if eps < 0); delta = max(min(delta, hi-src), lo-src)

@@ -176,8 +176,9 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd1(const float* _
         }
         float y = yq[(h + pad) * Wp + (w + pad)];
         float dpre = d * act_grad_from_out(y, act);
+        // with a residual output AND a normalisation pass behind, d_pre is stored once (in d_res) and pass 2 reads it there
         if (drp) drp[i] = dpre;
-        dxp[i] = dpre;
+        if (!drp || !has_norm) dxp[i] = dpre;
         if (has_norm) {
             float xh = (xq[i] - mean) * rstd;
             s1 += (double)dpre;
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd1(const float* _
 __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd2(const float* __restrict__ x, int C, int HW,
                                                                   const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                                   const float* __restrict__ rstd_in, const double* __restrict__ sums,
-                                                                  int n_splits, float* __restrict__ dx) {
+                                                                  int n_splits, const float* d_pre, float* dx) {
     const int64_t p = blockIdx.y;
     const int c = (int)(p % C);
     const float mean = mean_in[p], rstd = rstd_in[p];
@@ -200,13 +201,14 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd2(const float* _
     const float m1 = (float)(sa / (double)HW), m2 = (float)(sb / (double)HW);
     const float gr = gamma[c] * rstd;
     const float* xq = x + p * HW;
+    const float* dpp = d_pre + p * HW;       // == dx (in place) unless pass 1 left d_pre in the residual gradient
     float* dxp = dx + p * HW;
     int seg = (HW + gridDim.x - 1) / gridDim.x;
     int lo = blockIdx.x * seg, hi = min(lo + seg, HW);
 #pragma unroll 4
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         float xh = (xq[i] - mean) * rstd;
-        dxp[i] = gr * (dxp[i] - m1 - xh * m2);
+        dxp[i] = gr * (dpp[i] - m1 - xh * m2);
     }
 }
 
@@ -225,6 +227,33 @@ static unsigned nf_stat_splits(int planes, int HW) {
     if (splits > cap) splits = cap;
     if (splits > NF_MAX_SPLITS) splits = NF_MAX_SPLITS;
     return (unsigned)(splits < 1 ? 1 : splits);
+}
+
+// ---- decoder: bilinear x2 upsampling (align_corners = True) written directly as the reflect-padded input of the 3x3
+//      convolution that follows (feature_network.py:143-151: F.interpolate -> conv with padding_mode='reflect').
+//      Arithmetic in the order of ATen's upsample_bilinear2d so that the values equal F.interpolate's.
+__global__ void __launch_bounds__(NF_CNN_BLOCK) k_upsample2x_pad(const float* __restrict__ x, int64_t xs_plane, int64_t xs_row,
+                                                                 int h, int w, int pad, float* __restrict__ yp) {
+    const int64_t p = blockIdx.y;
+    const int H = 2 * h, W = 2 * w, Hp = H + 2 * pad, Wp = W + 2 * pad, HWp = Hp * Wp;
+    const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float* xp = x + p * xs_plane;
+    float* out = yp + p * (int64_t)HWp;
+    int seg = (HWp + gridDim.x - 1) / gridDim.x;
+    int lo = blockIdx.x * seg, hi = min(lo + seg, HWp);
+#pragma unroll 2
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        int ph = i / Wp, pw = i - ph * Wp;
+        int oh = reflect_src(ph - pad, H), ow = reflect_src(pw - pad, W);
+        float h1r = rh * (float)oh, w1r = rw * (float)ow;
+        int h1 = (int)h1r, w1 = (int)w1r;
+        int h1p = h1 < h - 1 ? 1 : 0, w1p = w1 < w - 1 ? 1 : 0;
+        float h1l = h1r - (float)h1, h0l = 1.f - h1l, w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        const float* r0 = xp + (int64_t)h1 * xs_row + w1;
+        const float* r1 = r0 + (int64_t)h1p * xs_row;
+        out[i] = h0l * (w0l * r0[0] + w1l * r0[w1p]) + h1l * (w0l * r1[0] + w1l * r1[w1p]);
+    }
 }
 
 extern "C" int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W, const float* gamma, const float* beta, float eps,
@@ -265,8 +294,19 @@ extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, c
     NF_LAUNCH_CHECK("nf_in_act_pad_bwd (fold)");
     if (gamma) {
         hipLaunchKernelGGL(k_in_act_pad_bwd2, grid, dim3(NF_CNN_BLOCK), 0, st, x, C, HW, gamma, mean, rstd, (const double*)scratch,
-                           (int)grid.x, dx);
+                           (int)grid.x, d_res ? d_res : dx, dx);
         NF_LAUNCH_CHECK("nf_in_act_pad_bwd (norm)");
     }
+    return 0;
+}
+
+extern "C" int nf_upsample2x_pad_fwd(const float* x, int64_t planes, int64_t xs_plane, int64_t xs_row, int h, int w, int pad,
+                                     float* y_padded, nf_stream_t stream) {
+    NF_REQUIRE(planes >= 1 && planes <= 0x7fffffff && h >= 1 && w >= 1 && pad >= 0 && pad < 2 * h && pad < 2 * w && xs_row >= w,
+               "nf_upsample2x_pad_fwd: bad arguments (planes %lld h %d w %d pad %d)", (long long)planes, h, w, pad);
+    const int HWp = (2 * h + 2 * pad) * (2 * w + 2 * pad);
+    hipLaunchKernelGGL(k_upsample2x_pad, dim3(nf_apply_splits((int)planes, HWp), (unsigned)planes), dim3(NF_CNN_BLOCK), 0,
+                       (hipStream_t)stream, x, xs_plane, xs_row, h, w, pad, y_padded);
+    NF_LAUNCH_CHECK("nf_upsample2x_pad_fwd");
     return 0;
 }

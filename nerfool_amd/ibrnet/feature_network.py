@@ -214,16 +214,20 @@ def _resblock(tape, blk, xin):
     return _fuse(tape, t2, blk.bn2, res, ops.ACT_RELU, 1)
 
 
-def _upsample(tape, a):
+def _upsample_pad(tape, a, pad):
+    """F.interpolate(x2, bilinear, align_corners) + the reflect padding of the following convolution in one kernel; the
+    backward folds the padded gradient (fused kernel) and applies the transposed interpolation (ATen)."""
     src = a.interior()
-    out = _Slot(F.interpolate(src, scale_factor=2, mode='bilinear', align_corners=True))
+    up = _Act(ops.upsample2x_pad_fwd(src, pad), pad)
     in_size = list(src.shape)
+    out_hw = [2 * in_size[2], 2 * in_size[3]]
 
     def bwd():
-        a.add_i(_aten.upsample_bilinear2d_backward(out.g, list(out.v.shape[2:]), in_size, True, None, None))
-        out.g = None
+        g, _ = ops.in_act_pad_bwd(up.gp, up.gi, up.yp, None, None, None, None, ops.ACT_NONE, pad, False)
+        a.add_i(_aten.upsample_bilinear2d_backward(g, out_hw, in_size, True, None, None))
+        up.gp = up.gi = None
     tape.append(bwd)
-    return out
+    return up
 
 
 def _join_tape(tape, enc, dec):
@@ -257,8 +261,7 @@ def fused_forward(net, x):
     x1, x2, x3 = feats
 
     def decoder_stage(src, up, iconv, enc):
-        u = _upsample(tape, src)
-        up_p = _fuse(tape, u, None, None, ops.ACT_NONE, 1)
+        up_p = _upsample_pad(tape, src, 1)
         t = _conv(tape, up_p.yp, up.conv.conv.weight, 1, up_p.add_p)
         dec = _fuse(tape, t, up.conv.bn, None, ops.ACT_ELU, 0)
         j = _join_tape(tape, enc, dec)

@@ -372,6 +372,22 @@ def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res)
     return dx, d_res
 
 
+def upsample2x_pad_fwd(x, pad):
+    """reflect_pad(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True), pad); x [N,C,h,w] may be the
+    interior view of a padded tensor (unit column stride, planes laid out like a contiguous [N,C] grid)."""
+    _f32(x, 'x')
+    N, C, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    if sw != 1 or sn != C * sc:
+        x = x.contiguous()
+        sn, sc, sh, sw = x.stride()
+    yp = torch.empty(N, C, 2 * h + 2 * pad, 2 * w + 2 * pad, dtype=torch.float32, device=x.device)
+    with prof.launch('nf_upsample2x_pad_fwd', x, n=yp.numel()):
+        _lib.check(_lib.lib().nf_upsample2x_pad_fwd(_ptr(x), N * C, sc, sh, h, w, int(pad), _ptr(yp), _stream(x)),
+                   'nf_upsample2x_pad_fwd')
+    return yp
+
+
 def pack_gnt_blob(state, depth, device):
     """reference GNT state-dict (gnt/transformer_network.py module paths) -> flat blob in the kernels' layout"""
     import ctypes

@@ -354,6 +354,14 @@ def check_fused_cnn_glue(dev):
         assert_close(dx, grads[0], 1e-3, 1e-4 * float(grads[0].abs().max()), 'fused glue d x')
         if use_res:
             assert_close(d_res, grads[1], 1e-4, 1e-5, 'fused glue d residual')
+    # decoder: x2 bilinear upsampling (align_corners) fused with the reflect padding, from contiguous and strided sources
+    for (N, C, h, w, pad, strided) in ((2, 3, 5, 7, 1, False), (1, 4, 6, 4, 1, True), (1, 2, 1, 3, 0, False)):
+        store = torch.randn(N, C, h + 2, w + 2, generator=gen)
+        x = store[:, :, 1:-1, 1:-1] if strided else store[:, :, 1:-1, 1:-1].contiguous()
+        up = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True)
+        ref = F.pad(up, (pad,) * 4, mode='reflect') if pad else up
+        got = ops.upsample2x_pad_fwd(store.to(dev)[:, :, 1:-1, 1:-1] if strided else x.to(dev), pad)
+        assert_close(got, ref, 1e-6, 1e-6, 'fused upsample + pad')
 
 
 def check_fused_resunet(dev, size=(96, 128)):
