@@ -53,7 +53,7 @@ _PROTOTYPES = {
     'nf_gnt_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_in_act_pad_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_int64, c_int64, c_int64, c_int64,
                                   c_int, c_int, _P, _P, _P, _P, _P]),
-    'nf_in_act_pad_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    'nf_in_act_pad_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
     'nf_upsample2x_pad_fwd': (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, _P]),
     'nf_project_perturb': (c_int, [_P, _P, c_int64, c_float, c_float, c_float, _P]),
     'nf_pgd_adam_step': (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float,
@@ -89,11 +89,12 @@ def lib():
     return _lib
 
 
-def use_library_for_tests(path):
-    """TEST HOOK: bind a CPU stand-in build of the kernel sources (tests/host_harness)."""
+def use_library_for_tests(path, emulated=True):
+    """TEST HOOK: bind a CPU stand-in build of the kernel sources (tests/host_harness); emulated=False binds another GPU
+    build of the same sources (tuning variants, tools/build_variant.sh)."""
     global _lib, _emulated
     _lib = bind(ctypes.CDLL(path))
-    _emulated = True
+    _emulated = bool(emulated)
     return _lib
 
 

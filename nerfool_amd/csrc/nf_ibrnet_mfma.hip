@@ -24,6 +24,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define NF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// waves per workgroup of the row kernels (all waves of a workgroup share one LDS image of the weights)
+#ifndef NF_ROWS_FWD_WAVES
+#define NF_ROWS_FWD_WAVES 8      // 8 waves x 2 workgroups per CU = 4 waves per SIMD at <= 128 VGPRs (measured +10 % over 4 x 2)
+#endif
+#ifndef NF_ROWS_FWD_OCC
+#define NF_ROWS_FWD_OCC 4
+#endif
+#ifndef NF_ROWS_BWD_WAVES
+#define NF_ROWS_BWD_WAVES 4
+#endif
+#ifndef NF_ROWS_BWD_OCC
+#define NF_ROWS_BWD_OCC 1
+#endif
+
 __host__ __device__ constexpr int nf_nidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---- record layout of the MFMA-order weight blob (units: records of 64 floats) -------------------------------------
@@ -477,7 +491,7 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
 }
 
 template <int V>
-__global__ void __launch_bounds__(256, 2) k_ibr_rows_fwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
+__global__ void __launch_bounds__(64 * NF_ROWS_FWD_WAVES, NF_ROWS_FWD_OCC) k_ibr_rows_fwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                          int64_t n_samples, int aa, float* __restrict__ smp) {
     HIP_DYNAMIC_SHARED(float, lds)
@@ -487,7 +501,7 @@ __global__ void __launch_bounds__(256, 2) k_ibr_rows_fwd(const float* __restrict
     const int m = lane & 31, h = lane >> 5;
     const int64_t n_rows = n_samples * V;
     const int64_t n_tiles = (n_rows + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)blockIdx.x * NF_ROWS_FWD_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NF_ROWS_FWD_WAVES) {
         // compiler barrier: keeps the (tile-invariant) weight reads from being hoisted out of the loop into 200+ VGPRs
         asm volatile("" ::: "memory");
         int64_t row = tile * 32 + m;
@@ -664,7 +678,7 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
 }
 
 template <int V>
-__global__ void __launch_bounds__(256, 1) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
+__global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, NF_ROWS_BWD_OCC) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                          const float* __restrict__ d_smp, int64_t n_samples, int aa,
                                                          float* __restrict__ d_rgb_feat) {
@@ -675,7 +689,7 @@ __global__ void __launch_bounds__(256, 1) k_ibr_rows_bwd(const float* __restrict
     const int m = lane & 31, h = lane >> 5;
     const int64_t n_rows = n_samples * V;
     const int64_t n_tiles = (n_rows + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)blockIdx.x * NF_ROWS_BWD_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NF_ROWS_BWD_WAVES) {
         asm volatile("" ::: "memory");
         int64_t row = tile * 32 + m;
         const bool live = row < n_rows;
@@ -1443,9 +1457,9 @@ template <int V>
 static void launch_rows_fwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
                             int64_t n_samples, int aa, float* smp, hipStream_t st) {
     int64_t tiles = (n_samples * V + 31) / 32;
-    int64_t blocks = (tiles + 3) / 4;
+    int64_t blocks = (tiles + NF_ROWS_FWD_WAVES - 1) / NF_ROWS_FWD_WAVES;
     if (blocks > 1024) blocks = 1024;     // persistent-ish: 2 workgroups per CU hold the 58 KB weight image each
-    hipLaunchKernelGGL(k_ibr_rows_fwd<V>, dim3((unsigned)blocks), dim3(256), NF_MFMA_FWD_FLOATS * sizeof(float), st, wblob,
+    hipLaunchKernelGGL(k_ibr_rows_fwd<V>, dim3((unsigned)blocks), dim3(64 * NF_ROWS_FWD_WAVES), NF_MFMA_FWD_FLOATS * sizeof(float), st, wblob,
                        rgb_feat, ray_diff, mask, n_samples, aa, smp);
 }
 
@@ -1506,9 +1520,9 @@ static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const floa
         configured = true;
     }
     int64_t tiles = (n_samples * V + 31) / 32;
-    int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 512) blocks = 512;        // one 4-wave workgroup per CU holds the 113 KB weight image (fwd + transposed)
-    hipLaunchKernelGGL(k_ibr_rows_bwd<V>, dim3((unsigned)blocks), dim3(256), smem, st, wblob, rgb_feat, ray_diff, mask, d_smp,
+    int64_t blocks = (tiles + NF_ROWS_BWD_WAVES - 1) / NF_ROWS_BWD_WAVES;
+    if (blocks > 512) blocks = 512;        // one workgroup per CU holds the 113 KB weight image (fwd + transposed)
+    hipLaunchKernelGGL(k_ibr_rows_bwd<V>, dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask, d_smp,
                        n_samples, aa, d_rgb_feat);
     return 0;
 }

@@ -191,7 +191,7 @@ def _fuse(tape, xs, norm, res, act, pad):
 
     def bwd():
         dx, d_res = ops.in_act_pad_bwd(a.gp, a.gi, yp, xs.v if norm is not None else None, gamma, mean, rstd, act, pad,
-                                       res is not None)
+                                       res is not None, beta=beta)
         xs.add(dx)
         if res is not None:
             res.add_i(d_res)

@@ -355,7 +355,7 @@ def in_act_pad_fwd(x, gamma, beta, res, act, pad, eps=1e-5):
     return yp, mean, rstd
 
 
-def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res):
+def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res, beta=None):
     N, C, Hp, Wp = yp.shape
     H, W = Hp - 2 * pad, Wp - 2 * pad
     if dyp is not None:
@@ -366,7 +366,7 @@ def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res)
     d_res = torch.empty_like(dx) if want_d_res else None
     scratch = torch.empty(N * C * 64, dtype=torch.float64, device=yp.device) if gamma is not None else None
     with prof.launch('nf_in_act_pad_bwd', yp, n=dx.numel()):
-        _lib.check(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(mean),
+        _lib.check(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta), _ptr(mean),
                                                 _ptr(rstd), int(act), int(pad), _ptr(d_res), _ptr(dx), _ptr(scratch), _stream(yp)),
                    'nf_in_act_pad_bwd')
     return dx, d_res

@@ -329,7 +329,11 @@ def check_fused_cnn_glue(dev):
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(3)
     for (N, C, H, W, pad, act, use_norm, use_res) in ((2, 5, 9, 11, 1, ops.ACT_RELU, True, True), (1, 3, 8, 6, 3, ops.ACT_NONE, False, False),
-                                                      (2, 4, 7, 10, 0, ops.ACT_ELU, True, False), (1, 6, 12, 9, 1, ops.ACT_NONE, True, True)):
+                                                      (2, 4, 7, 10, 0, ops.ACT_ELU, True, False), (1, 6, 12, 9, 1, ops.ACT_NONE, True, True),
+                                                      (1, 2, 9, 23, 3, ops.ACT_RELU, True, True), (1, 2, 5, 16, 1, ops.ACT_ELU, False, False),
+                                                      # plane-resident variants 2 and 3, and the two-pass path behind them
+                                                      (1, 2, 40, 81, 1, ops.ACT_RELU, True, True), (1, 1, 100, 126, 1, ops.ACT_ELU, True, False),
+                                                      (1, 1, 200, 250, 1, ops.ACT_RELU, True, True)):
         x = torch.randn(N, C, H, W, generator=gen)
         gamma = (1 + 0.3 * torch.randn(C, generator=gen)) if use_norm else None
         beta = 0.2 * torch.randn(C, generator=gen) if use_norm else None
@@ -351,6 +355,9 @@ def check_fused_cnn_glue(dev):
         assert_close(yp, ref_y, 1e-4, 1e-5, 'fused glue forward')
         dx, d_res = ops.in_act_pad_bwd(dyp.to(dev), dex.to(dev), yp, x.to(dev) if use_norm else None, dv(gamma), mean, rstd, act,
                                        pad, use_res)
+        if use_norm and not use_res:      # with beta the activation derivative is recomputed from x instead of read from y
+            dx2, _ = ops.in_act_pad_bwd(dyp.to(dev), dex.to(dev), yp, x.to(dev), dv(gamma), mean, rstd, act, pad, False, beta=dv(beta))
+            assert_close(dx2, dx, 1e-5, 1e-5 * float(dx.abs().max()), 'fused glue d x (derivative from x)')
         assert_close(dx, grads[0], 1e-3, 1e-4 * float(grads[0].abs().max()), 'fused glue d x')
         if use_res:
             assert_close(d_res, grads[1], 1e-4, 1e-5, 'fused glue d residual')

@@ -1,0 +1,56 @@
+"""Isolated timing of the IBRNet network kernels (forward + backward) at the attack and render sizes; also the program
+profiled with rocprofv3 --pmc for the counters quoted in DESIGN.md.  usage: python tools/bench_ibrnet_kernels.py [iters] [library.so]"""
+import os
+import sys
+
+from types import SimpleNamespace
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nerfool_amd import _lib, ops                             # noqa: E402
+from nerfool_amd.ibrnet.mlp_network import IBRNet             # noqa: E402
+
+
+def flops(R, S, V):
+    return 2.0 * R * S * (V * 13256 + 6480 + 32 * S)
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    if len(sys.argv) > 2:          # a tuning build (tools/build_variant.sh)
+        _lib.use_library_for_tests(sys.argv[2], emulated=False)
+    dev = torch.device('cuda', 0)
+    gen = torch.Generator().manual_seed(0)
+    for (R, S, V) in ((512, 64, 4), (512, 128, 4), (4096, 64, 4), (4096, 128, 4)):
+        torch.manual_seed(3)
+        net = IBRNet(SimpleNamespace(anti_alias_pooling=1), in_feat_ch=32, n_samples=S).to(dev)
+        blob, mblob = net._packed(dev)
+        rgb_feat = torch.randn(R, S, V, 35, generator=gen).to(dev)
+        rd = torch.randn(R, S, V, 4, generator=gen)
+        rd[..., :3] = torch.nn.functional.normalize(rd[..., :3], dim=-1)
+        rd = rd.to(dev)
+        mask = (torch.rand(R, S, V, generator=gen) > 0.1).float().to(dev)
+        pe = net.pos_encoding
+        d_raw = torch.randn(R, S, 4, generator=gen).to(dev)
+        for _ in range(3):
+            raw, ws = ops.ibrnet_fwd_mfma(mblob, blob, pe, rgb_feat, rd, mask, True)
+            ops.ibrnet_bwd_mfma(mblob, blob, pe, rgb_feat, rd, mask, ws, d_raw, True)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        e[0].record()
+        for _ in range(iters):
+            raw, ws = ops.ibrnet_fwd_mfma(mblob, blob, pe, rgb_feat, rd, mask, True)
+        e[1].record()
+        for _ in range(iters):
+            ops.ibrnet_bwd_mfma(mblob, blob, pe, rgb_feat, rd, mask, ws, d_raw, True)
+        e[2].record()
+        torch.cuda.synchronize()
+        tf, tb = e[0].elapsed_time(e[1]) / iters, e[1].elapsed_time(e[2]) / iters
+        F = flops(R, S, V)
+        print('R %5d S %3d V %d: fwd %.3f ms (%.1f TFLOP/s)  bwd %.3f ms (%.1f TFLOP/s algorithmic)' %
+              (R, S, V, tf, F / tf / 1e9, tb, F / tb / 1e9), flush=True)
+
+
+if __name__ == '__main__':
+    main()
