@@ -191,6 +191,16 @@ int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, 
 int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
                int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 
+/* GNT forward on the matrix cores (S in {32, 64, 96, 128}): same contract and workspace as nf_gnt_fwd -- nf_gnt_bwd consumes
+ * what it saves -- with the weights re-ordered by nf_gnt_pack_mfma (HOST pointers: natural blob -> MFMA-order blob of
+ * nf_gnt_mfma_blob_floats(depth) floats).                                    ref: gnt/transformer_network.py:270-309 */
+int64_t nf_gnt_mfma_blob_floats(int depth);
+int nf_gnt_pack_mfma(int depth, const float* natural_blob_host, float* mfma_blob_host);
+int nf_gnt_mfma_supported(int n_samples, int n_views);
+int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+                    const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
+                    float* workspace, nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * a14 (glue only)  ResUNet: InstanceNorm + affine + residual + ReLU/ELU + reflect padding fused into one pass over a
  * convolution output, producing the pre-padded input of the next convolution.   ref: ibrnet/feature_network.py:38-78,

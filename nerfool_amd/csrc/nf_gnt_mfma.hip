@@ -1,0 +1,675 @@
+// GNT per-ray network (a15), forward on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+// ref: gnt/transformer_network.py:270-309 (GNT.forward, ret_alpha = False, eval mode), :55-89, :93-113, :121-171, :175-202.
+//
+// One workgroup per ray, one wave per 32 samples (S in {32, 64, 96, 128}); sample = MFMA column (lane & 31), so every
+// 64-wide per-sample vector is TWO accumulator tiles: register r of tile t in lane (m, h) holds feature 32 t + n(r, h),
+// n(r, h) = (r & 3) + 8 (r >> 2) + 4 h -- which is exactly the B operand of the next layer's k-step r, so activations are
+// chained through registers (same scheme as nf_ibrnet_mfma.hip).  Weights are host-packed into "records" of 64 floats in
+// consumption order and streamed from L2 (a layer is 471 KB: no LDS image), one coalesced 256-byte load per MFMA.
+//   * view transformer: the V source views are walked serially per wave with an online softmax (running max / sum /
+//     weighted sum per channel in registers), any V; X_v comes back from the workspace the stem wrote.
+//   * ray transformer: K and V^T of the ray are laid out in LDS as MFMA A-operand records by the lanes that produced them;
+//     scores^T = K Q^T (keys on rows => the softmax over keys is in-lane + one cross-half shuffle), O^T = V^T P^T.
+// With save != 0 every activation nf_gnt_bwd reads is written to the workspace in the layout of nf_gnt.h, so the existing
+// backward consumes this forward unchanged.
+#include "nf_gnt.h"
+
+#include <string.h>
+
+typedef float g16 __attribute__((ext_vector_type(16)));
+#define GM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__host__ __device__ constexpr int gm_nidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- record layout (units: records of 64 floats), per layer -----------------------------------------------------------
+enum {
+    MG_VQ = 0, MG_VK = 64, MG_VV = 128, MG_POS0 = 192, MG_POS2 = 194, MG_ATT0 = 202, MG_ATT2 = 234, MG_VOUT = 242,
+    MG_VFF = 306,            // 8 x [fc1 tile j: 32][fc2 k-tile j: 2 x 16]
+    MG_Q0 = 818,             // 2 x [cur 32 | pe 63]
+    MG_Q2 = 1008, MG_RQ = 1072, MG_RK = 1136, MG_RV = 1200, MG_ROUT = 1264,
+    MG_RFF = 1328, MG_LAYER_RECORDS = 1840
+};
+// ---- per-layer tables behind the records (floats): bias tiles [h][16], LayerNorm vectors in fragment order [t][h][16]
+enum {
+    MB_POS0 = 0, MB_POS2 = 32, MB_ATT0 = 96, MB_ATT2 = 128, MB_VOUT = 192, MB_VFF1 = 256, MB_VFF2 = 512, MB_Q0 = 576, MB_Q2 = 640,
+    MB_ROUT = 704, MB_RFF1 = 768, MB_RFF2 = 1024, MB_LN = 1088,       // 4 x (weight 64, bias 64)
+    MB_FLOATS = MB_LN + 512
+};
+static constexpr int64_t GM_LAYER_FLOATS = (int64_t)MG_LAYER_RECORDS * 64 + MB_FLOATS;
+// stem: rgbfeat_fc.0 (35 -> 64, k order 2 s + h, 18 steps per tile), rgbfeat_fc.2 (64 -> 64); then 2 + 2 bias tiles
+enum { MS_L1 = 0, MS_L2 = 36, MS_RECORDS = 100, MS_B1 = MS_RECORDS * 64, MS_B2 = MS_B1 + 64, GM_STEM_FLOATS = MS_B2 + 64 };
+// final: norm weight, bias (fragment order), rgb_fc weight [3] x fragment order, bias 3 (+1 pad)
+enum { MF_LNW = 0, MF_LNB = 64, MF_W = 128, MF_B = 320, GM_FINAL_FLOATS = 324 };
+
+NF_HD inline int64_t gm_layer_base(int i) { return GM_STEM_FLOATS + (int64_t)i * GM_LAYER_FLOATS; }
+
+extern "C" int64_t nf_gnt_mfma_blob_floats(int depth) { return GM_STEM_FLOATS + (int64_t)depth * GM_LAYER_FLOATS + GM_FINAL_FLOATS; }
+
+extern "C" int nf_gnt_mfma_supported(int n_samples, int n_views) {
+    return n_samples >= 32 && n_samples <= 128 && n_samples % 32 == 0 && n_views >= 1 && n_views <= 64;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: natural blob (nf_gnt.h) -> MFMA-order blob
+// ---------------------------------------------------------------------------------------------------------------
+// record: lane (i, h) holds W[n = 32 nt + i][k = h ? k1 : k0]   (W is [N][K] row-major; out-of-range -> 0)
+static void gm_record(float*& rec, const float* W, int N, int K, int nt, int k0, int k1) {
+    for (int lane = 0; lane < 64; ++lane) {
+        int n = nt * 32 + (lane & 31), k = (lane >> 5) ? k1 : k0;
+        rec[lane] = (n < N && k >= 0 && k < K) ? W[(size_t)n * K + k] : 0.f;
+    }
+    rec += 64;
+}
+// k-steps over fragment-ordered inputs kbase + n(r, h), r < nsteps
+static void gm_frag(float*& rec, const float* W, int N, int K, int nt, int kbase, int nsteps) {
+    for (int r = 0; r < nsteps; ++r) gm_record(rec, W, N, K, nt, kbase + gm_nidx(r, 0), kbase + gm_nidx(r, 1));
+}
+// k-steps over memory-ordered inputs kbase + 2 s + h, s < nsteps
+static void gm_seq(float*& rec, const float* W, int N, int K, int nt, int kbase, int nsteps) {
+    for (int s = 0; s < nsteps; ++s) gm_record(rec, W, N, K, nt, kbase + 2 * s, kbase + 2 * s + 1);
+}
+static void gm_lin64(float*& rec, const float* W, int N, int K) {      // N outputs (tiles of 32) x K = 64 inputs
+    for (int nt = 0; nt < (N + 31) / 32; ++nt) {
+        gm_frag(rec, W, N, K, nt, 0, 16);
+        gm_frag(rec, W, N, K, nt, 32, 16);
+    }
+}
+static void gm_vec_tiles(float* dst, const float* b, int N) {          // fragment order [t][h][16]
+    for (int t = 0; t < (N + 31) / 32; ++t)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                int n = 32 * t + gm_nidx(r, h);
+                dst[t * 32 + h * 16 + r] = n < N ? b[n] : 0.f;
+            }
+}
+
+extern "C" int nf_gnt_pack_mfma(int depth, const float* nat, float* out) {
+    const int64_t total = nf_gnt_mfma_blob_floats(depth);
+    for (int64_t i = 0; i < total; ++i) out[i] = 0.f;
+    {   // stem
+        float* rec = out;
+        const float* W1 = nat + 35 * 64;                        // native [64][35]
+        for (int nt = 0; nt < 2; ++nt) gm_seq(rec, W1, 64, 35, nt, 0, 18);
+        gm_lin64(rec, nat + GNT_STEM1 + 64 * 64, 64, 64);
+        if (rec - out != MS_RECORDS * 64) return 1;
+        gm_vec_tiles(out + MS_B1, nat + 2 * 35 * 64, 64);
+        gm_vec_tiles(out + MS_B2, nat + GNT_STEM1 + 2 * 64 * 64, 64);
+    }
+    for (int i = 0; i < depth; ++i) {
+        const float* L = nat + gnt_layer_base(i);
+        float* base = out + gm_layer_base(i);
+        float* rec = base;
+        gm_lin64(rec, L + gnt_w(GV_Q), 64, 64);
+        gm_lin64(rec, L + gnt_w(GV_K), 64, 64);
+        gm_lin64(rec, L + gnt_w(GV_V), 64, 64);
+        gm_seq(rec, L + gnt_w(GV_POS0), 8, 4, 0, 0, 2);
+        for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_w(GV_POS2), 64, 8, nt, 0, 4);
+        gm_lin64(rec, L + gnt_w(GV_ATT0), 8, 64);
+        for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_w(GV_ATT2), 64, 8, nt, 0, 4);
+        gm_lin64(rec, L + gnt_w(GV_OUT), 64, 64);
+        if (rec - base != MG_VFF * 64) return 2;
+        for (int pass = 0; pass < 2; ++pass) {                  // view FF, then ray FF: hidden tile j chained into fc2
+            const int l1 = pass == 0 ? GV_FF1 : GR_FF1, l2 = pass == 0 ? GV_FF2 : GR_FF2;
+            if (pass == 1) {
+                if (rec - base != MG_Q0 * 64) return 3;
+                if ((i & 1) == 0) {
+                    const float* W0 = L + gnt_w(GQ_0);          // [64][190]: 64 current features, 126 positional
+                    for (int nt = 0; nt < 2; ++nt) {
+                        gm_frag(rec, W0, 64, 190, nt, 0, 16);
+                        gm_frag(rec, W0, 64, 190, nt, 32, 16);
+                        gm_seq(rec, W0, 64, 190, nt, 64, 63);
+                    }
+                    gm_lin64(rec, L + gnt_w(GQ_2), 64, 64);
+                } else {
+                    rec += (190 + 64) * 64;
+                }
+                gm_lin64(rec, L + gnt_w(GR_Q), 64, 64);
+                gm_lin64(rec, L + gnt_w(GR_K), 64, 64);
+                gm_lin64(rec, L + gnt_w(GR_V), 64, 64);
+                gm_lin64(rec, L + gnt_w(GR_OUT), 64, 64);
+                if (rec - base != MG_RFF * 64) return 4;
+            }
+            for (int j = 0; j < 8; ++j) {
+                gm_frag(rec, L + gnt_w(l1), 256, 64, j, 0, 16);
+                gm_frag(rec, L + gnt_w(l1), 256, 64, j, 32, 16);
+                for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_w(l2), 64, 256, nt, 32 * j, 16);
+            }
+        }
+        if (rec - base != MG_LAYER_RECORDS * 64) return 5;
+        float* tb = base + (int64_t)MG_LAYER_RECORDS * 64;
+        gm_vec_tiles(tb + MB_POS0, L + gnt_b(GV_POS0), 8);
+        gm_vec_tiles(tb + MB_POS2, L + gnt_b(GV_POS2), 64);
+        gm_vec_tiles(tb + MB_ATT0, L + gnt_b(GV_ATT0), 8);
+        gm_vec_tiles(tb + MB_ATT2, L + gnt_b(GV_ATT2), 64);
+        gm_vec_tiles(tb + MB_VOUT, L + gnt_b(GV_OUT), 64);
+        gm_vec_tiles(tb + MB_VFF1, L + gnt_b(GV_FF1), 256);
+        gm_vec_tiles(tb + MB_VFF2, L + gnt_b(GV_FF2), 64);
+        if ((i & 1) == 0) {
+            gm_vec_tiles(tb + MB_Q0, L + gnt_b(GQ_0), 64);
+            gm_vec_tiles(tb + MB_Q2, L + gnt_b(GQ_2), 64);
+        }
+        gm_vec_tiles(tb + MB_ROUT, L + gnt_b(GR_OUT), 64);
+        gm_vec_tiles(tb + MB_RFF1, L + gnt_b(GR_FF1), 256);
+        gm_vec_tiles(tb + MB_RFF2, L + gnt_b(GR_FF2), 64);
+        for (int j = 0; j < 4; ++j) {
+            gm_vec_tiles(tb + MB_LN + j * 128, L + gnt_ln_w(j), 64);
+            gm_vec_tiles(tb + MB_LN + j * 128 + 64, L + gnt_ln_b(j), 64);
+        }
+    }
+    {   // final
+        const float* F = nat + gnt_layer_base(depth);
+        float* fo = out + gm_layer_base(depth);
+        gm_vec_tiles(fo + MF_LNW, F, 64);
+        gm_vec_tiles(fo + MF_LNB, F + 64, 64);
+        for (int c = 0; c < 3; ++c) gm_vec_tiles(fo + MF_W + c * 64, F + 320 + c * 64, 64);      // native W [3][64]
+        for (int c = 0; c < 3; ++c) fo[MF_B + c] = F[512 + c];
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------------------------
+struct V64 { g16 t[2]; };       // a 64-wide per-sample vector in fragment order
+
+__device__ __forceinline__ g16 gm_zero() {
+    g16 a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+    return a;
+}
+__device__ __forceinline__ g16 gm_tile(const float* __restrict__ tb, int h) {      // one [h][16] tile of a table
+    g16 a;
+    const float* b = tb + h * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = b[r];
+    return a;
+}
+__device__ __forceinline__ float gm_half_sum(float x) { return x + __shfl_xor(x, 32, NF_WAVE); }
+__device__ __forceinline__ float gm_half_max(float x) { return fmaxf(x, __shfl_xor(x, 32, NF_WAVE)); }
+
+// acc += sum over NSTEPS k-steps: records at rec (global, L2), B operand = x[r]
+// makes a (wave-uniform) pointer opaque to the optimiser: without it the loop-invariant record loads of the view loop --
+// 178 of them -- are hoisted out of the loop into registers and spilled
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GM_LAUNDER(p) asm volatile("" : "+s"(p))
+#else
+#define GM_LAUNDER(p) asm volatile("" : "+r"(p))
+#endif
+
+#ifndef GM_FENCE
+#define GM_FENCE 0
+#endif
+template <int NSTEPS>
+__device__ __forceinline__ g16 gm_gemm(const float* __restrict__ rec, int lane, const g16& x, g16 acc) {
+    if (GM_FENCE) asm volatile("" ::: "memory");      // keeps the record loads of LATER k-blocks from being hoisted up here
+#pragma unroll
+    for (int r = 0; r < NSTEPS; ++r) acc = GM_MFMA(rec[r * 64 + lane], x[r], acc);
+    return acc;
+}
+// one 32-output tile of a 64-input linear: records [k-tile 0: 16][k-tile 1: 16]
+__device__ __forceinline__ g16 gm_lin_tile(const float* __restrict__ rec, int lane, const V64& x, g16 acc) {
+    acc = gm_gemm<16>(rec, lane, x.t[0], acc);
+    return gm_gemm<16>(rec + 16 * 64, lane, x.t[1], acc);
+}
+// 64 -> 64 linear; bias tiles at tb (nullptr: none)
+__device__ __forceinline__ V64 gm_lin64(const float* __restrict__ rec, const float* __restrict__ tb, int lane, int h, const V64& x) {
+    V64 y;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) y.t[t] = gm_lin_tile(rec + t * 32 * 64, lane, x, tb ? gm_tile(tb + t * 32, h) : gm_zero());
+    return y;
+}
+
+// Workspace addressing: feature 32 t + n(r, h) = [32 t + n(r, 0)] + 4 h, so every access is a WAVE-UNIFORM base (scalar
+// registers, scalar arithmetic) plus one of two per-lane 32-bit offsets computed once: 4 h S + s for the per-sample slots,
+// 4 h V S + s for the per-(sample, view) slots.  (Per-element 64-bit vector address arithmetic, hoisted out of the view loop
+// by the optimiser, was worth ~450 spilled registers.)
+struct GmCtx {
+    float* ws_row;      // [slot][V][S], uniform
+    float* ws_smp;      // [slot][S], uniform
+    int S, V, s, h;
+    unsigned row_lane, smp_lane;
+};
+__device__ __forceinline__ float* gm_smp_at(const GmCtx& c, int slot_feature) { return c.ws_smp + (size_t)slot_feature * c.S; }
+__device__ __forceinline__ float* gm_row_at(const GmCtx& c, int slot_feature, int v) {
+    return c.ws_row + ((size_t)slot_feature * c.V + v) * c.S;
+}
+__device__ __forceinline__ void gm_store_smp(const GmCtx& c, int slot, const V64& x) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm_smp_at(c, slot + 32 * t + gm_nidx(r, 0))[c.smp_lane] = x.t[t][r];
+}
+__device__ __forceinline__ V64 gm_load_smp(const GmCtx& c, int slot) {
+    V64 x;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x.t[t][r] = gm_smp_at(c, slot + 32 * t + gm_nidx(r, 0))[c.smp_lane];
+    return x;
+}
+__device__ __forceinline__ void gm_store_row(const GmCtx& c, int slot, int v, const V64& x) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gm_row_at(c, slot + 32 * t + gm_nidx(r, 0), v)[c.row_lane] = x.t[t][r];
+}
+__device__ __forceinline__ V64 gm_load_row(const GmCtx& c, int slot, int v) {
+    V64 x;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x.t[t][r] = gm_row_at(c, slot + 32 * t + gm_nidx(r, 0), v)[c.row_lane];
+    return x;
+}
+
+// LayerNorm over the 64 features of the lane's sample: y = xhat * w + b; xhat -> xh (also saved when xh_slot >= 0)
+__device__ __forceinline__ V64 gm_layernorm(const GmCtx& c, const V64& x, const float* __restrict__ w, const float* __restrict__ b,
+                                            float eps, bool save, int xh_slot, int rstd_slot, V64* xh_out = nullptr) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += x.t[t][r];
+    const float mu = gm_half_sum(s) / 64.f;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q += (x.t[t][r] - mu) * (x.t[t][r] - mu);
+    const float rstd = 1.f / sqrtf(gm_half_sum(q) / 64.f + eps);
+    V64 xh, y;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            xh.t[t][r] = (x.t[t][r] - mu) * rstd;
+            y.t[t][r] = xh.t[t][r] * w[t * 32 + c.h * 16 + r] + b[t * 32 + c.h * 16 + r];
+        }
+    if (save) {
+        gm_store_smp(c, xh_slot, xh);
+        if (c.h == 0) gm_smp_at(c, rstd_slot)[c.s] = rstd;
+    }
+    if (xh_out) *xh_out = xh;
+    return y;
+}
+
+// feed-forward 64 -> 256 (ReLU) -> 64, hidden tile j chained straight into fc2; returns FF(y) (bias included)
+__device__ __forceinline__ V64 gm_ff(const GmCtx& c, const float* __restrict__ rec, const float* __restrict__ b1,
+                                     const float* __restrict__ b2, int lane, const V64& y, bool save, int f_slot) {
+    V64 o;
+    o.t[0] = gm_tile(b2, c.h);
+    o.t[1] = gm_tile(b2 + 32, c.h);
+    for (int j = 0; j < 8; ++j) {
+        const float* rj = rec + (size_t)j * 64 * 64;
+        g16 f = gm_lin_tile(rj, lane, y, gm_tile(b1 + j * 32, c.h));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[r] = fmaxf(f[r], 0.f);
+        if (save) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gm_smp_at(c, f_slot + 32 * j + gm_nidx(r, 0))[c.smp_lane] = f[r];
+        }
+        o.t[0] = gm_gemm<16>(rj + 32 * 64, lane, f, o.t[0]);
+        o.t[1] = gm_gemm<16>(rj + 48 * 64, lane, f, o.t[1]);
+    }
+    return o;
+}
+
+// LDS image of a ray's keys / values as MFMA A-operand records
+#define GM_VT_STRIDE 65      // odd record stride: the transposing V^T writes of a wave spread over the banks
+template <int NW> struct GmLds {
+    static constexpr int K_FLOATS = 4 * NW * 8 * 64;
+    static constexpr int VT_FLOATS = 4 * NW * 16 * GM_VT_STRIDE;
+    static constexpr int RED_FLOATS = NW * 4;
+    static constexpr int FLOATS = K_FLOATS + VT_FLOATS + RED_FLOATS;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restrict__ wb, const float* __restrict__ rgb_feat_all,
+                                                          const float* __restrict__ ray_diff_all, const float* __restrict__ mask_all,
+                                                          const float* __restrict__ pts, const float* __restrict__ ray_d, int V,
+                                                          int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
+                                                          int64_t row_floats, int64_t smp_floats) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int S = 32 * NW;
+    float* Kl = lds;
+    float* Vl = lds + GmLds<NW>::K_FLOATS;
+    float* red = Vl + GmLds<NW>::VT_FLOATS;
+    const int64_t ray = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    GmCtx c;
+    c.S = S; c.V = V; c.s = wave * 32 + m; c.h = h;
+    c.smp_lane = (unsigned)(4 * h * S + c.s);
+    c.row_lane = (unsigned)(4 * h * V * S + c.s);
+    const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;
+    c.ws_row = ws + ray * per_ray;
+    c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
+    const float* rgb_feat = rgb_feat_all + ray * S * V * 35;
+    const float* ray_diff = ray_diff_all + ray * S * V * 4;
+    const float* mask = mask_all + ray * S * V;
+    const bool sv = save != 0;
+
+    // ---- stem: X_v = W2 relu(W1 rgb_feat_v + b1) + b2 (kept in the workspace), q = max over the views (first maximum wins)
+    V64 cur, amax;
+    cur.t[0] = cur.t[1] = amax.t[0] = amax.t[1] = gm_zero();
+    for (int v = 0; v < V; ++v) {
+        const float* rf = rgb_feat + ((size_t)c.s * V + v) * 35;
+        g16 in0, in1;                     // k order 2 s + h: 18 steps, feature 35 is padding
+#pragma unroll
+        for (int st = 0; st < 16; ++st) in0[st] = rf[2 * st + h];
+        in1 = gm_zero();
+        in1[0] = rf[32 + h];
+        in1[1] = h == 0 ? rf[34] : 0.f;
+        V64 r1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            g16 acc = gm_tile(wb + MS_B1 + t * 32, h);
+            acc = gm_gemm<16>(wb + (MS_L1 + t * 18) * 64, lane, in0, acc);
+            acc = gm_gemm<2>(wb + (MS_L1 + t * 18 + 16) * 64, lane, in1, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+            r1.t[t] = acc;
+        }
+        if (sv) gm_store_row(c, RW_R1, v, r1);
+        V64 x = gm_lin64(wb + MS_L2 * 64, wb + MS_B2, lane, h, r1);
+        gm_store_row(c, RW_X, v, x);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (v == 0 || x.t[t][r] > cur.t[t][r]) {
+                    cur.t[t][r] = x.t[t][r];
+                    amax.t[t][r] = (float)v;
+                }
+    }
+    if (sv) gm_store_smp(c, SW_AMAX, amax);
+    // ---- positional encodings (sample position | unit view direction), 126 features at SW_PE in memory order: lane (m, h)
+    //      writes the features 2 st + h
+    {
+        const float* p3 = pts + (ray * S + c.s) * 3;
+        const float* d3 = ray_d + ray * 3;
+        const float dn = sqrtf(d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2]);
+        for (int st = 0; st < 63; ++st) {
+            const int f = 2 * st + h, part = f >= 63 ? 1 : 0, j = f - 63 * part;
+            float val;
+            if (j < 3) {
+                val = part == 0 ? p3[j] : d3[j] / dn;
+            } else {
+                const int k = (j - 3) / 6, a = (j - 3) - 6 * k, ax = a >= 3 ? a - 3 : a;
+                const float xa = part == 0 ? p3[ax] : d3[ax] / dn;
+                const float arg = xa * (float)(1 << k);
+                val = a >= 3 ? cosf(arg) : sinf(arg);
+            }
+            gm_smp_at(c, SW_PE + 2 * st)[h * S + c.s] = val;
+        }
+    }
+    for (int i = 0; i < depth; ++i) {
+        const float* Lbase = wb + gm_layer_base(i);
+        const float* tbase = Lbase + (size_t)MG_LAYER_RECORDS * 64;
+        const float* L = Lbase;
+        const float* tb = tbase;
+        const int ls = SW_BASE + (sv ? i : 0) * SW_LAYER;
+        const int lr = RW_BASE + (sv ? i : 0) * RW_LAYER;
+        // ================= view transformer =================
+        {
+            V64 y = gm_layernorm(c, cur, tb + MB_LN, tb + MB_LN + 64, 1e-6f, sv, ls + SL_XH1, ls + SL_RSTD1);
+            // the running state of the online softmax needs 96 registers: the residual stream and Q wait in the (L2-resident)
+            // workspace while the views are walked
+            gm_store_smp(c, SW_CUR, cur);
+            gm_store_smp(c, SW_QV, gm_lin64(L + MG_VQ * 64, nullptr, lane, h, y));
+            V64 mx, sum, acc;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    mx.t[t][r] = -3.0e38f;
+                    sum.t[t][r] = 0.f;
+                    acc.t[t][r] = 0.f;
+                }
+            for (int v = 0; v < V; ++v) {
+                const float* L = Lbase;
+                const float* tb = tbase;
+                GM_LAUNDER(L);
+                GM_LAUNDER(tb);
+                // register budget: the running softmax state (96) stays live across the views, so V + pos is parked in its
+                // workspace slot (the backward wants it there anyway) and Q is read per element instead of held
+                V64 T2;
+                {
+                    const V64 X = gm_load_row(c, RW_X, v);
+                    const V64 K = gm_lin64(L + MG_VK * 64, nullptr, lane, h, X);
+                    const float* rd = ray_diff + ((size_t)c.s * V + v) * 4;
+                    g16 rin = gm_zero();
+                    rin[0] = rd[h];
+                    rin[1] = rd[2 + h];
+                    g16 h0 = gm_gemm<2>(L + MG_POS0 * 64, lane, rin, gm_tile(tb + MB_POS0, h));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h0[r] = fmaxf(h0[r], 0.f);
+                    const V64 Vv = gm_lin64(L + MG_VV * 64, nullptr, lane, h, K);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const g16 pos = gm_gemm<4>(L + (MG_POS2 + 4 * t) * 64, lane, h0, gm_tile(tb + MB_POS2 + t * 32, h));
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int f0 = 32 * t + gm_nidx(r, 0);
+                            gm_row_at(c, lr + RWL_VP + f0, v)[c.row_lane] = Vv.t[t][r] + pos[r];
+                            T2.t[t][r] = K.t[t][r] - gm_smp_at(c, SW_QV + f0)[c.smp_lane] + pos[r];      // k - q + pos
+                        }
+                    }
+                }
+                g16 hid = gm_lin_tile(L + MG_ATT0 * 64, lane, T2, gm_tile(tb + MB_ATT0, h));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hid[r] = fmaxf(hid[r], 0.f);
+                if (sv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gm_row_at(c, lr + RWL_H + r, v)[c.row_lane] = hid[r];
+                }
+                const float mk = mask[(size_t)c.s * V + v];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    g16 a = gm_gemm<4>(L + (MG_ATT2 + 4 * t) * 64, lane, hid, gm_tile(tb + MB_ATT2 + t * 32, h));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float lg = mk == 0.f ? -1e9f : a[r];
+                        const int f0 = 32 * t + gm_nidx(r, 0);
+                        if (sv) gm_row_at(c, lr + RWL_PROB + f0, v)[c.row_lane] = lg;
+                        const float vp = gm_row_at(c, lr + RWL_VP + f0, v)[c.row_lane];
+                        const float mn = fmaxf(mx.t[t][r], lg);
+                        const float sc = __expf(mx.t[t][r] - mn), p = __expf(lg - mn);
+                        sum.t[t][r] = sum.t[t][r] * sc + p;
+                        acc.t[t][r] = acc.t[t][r] * sc + p * vp;
+                        mx.t[t][r] = mn;
+                    }
+                }
+            }
+            V64 u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u.t[t][r] = acc.t[t][r] / sum.t[t][r];
+            if (sv) {       // the backward wants the normalised attention weights where the raw logits were parked
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float* pp = gm_row_at(c, lr + RWL_PROB + 32 * t + gm_nidx(r, 0), v) + c.row_lane;
+                            *pp = __expf(*pp - mx.t[t][r]) / sum.t[t][r];
+                        }
+            }
+            const V64 o = gm_lin64(L + MG_VOUT * 64, tb + MB_VOUT, lane, h, u);
+            cur = gm_load_smp(c, SW_CUR);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) cur.t[t] += o.t[t];
+            y = gm_layernorm(c, cur, tb + MB_LN + 128, tb + MB_LN + 192, 1e-6f, sv, ls + SL_XH2, ls + SL_RSTD2);
+            const V64 f = gm_ff(c, L + MG_VFF * 64, tb + MB_VFF1, tb + MB_VFF2, lane, y, sv, ls + SL_F);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) cur.t[t] += f.t[t];
+        }
+        // ================= positional MLP on even layers =================
+        if ((i & 1) == 0) {
+            V64 g;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float* rq = L + (MG_Q0 + 95 * t) * 64;
+                g16 a = gm_lin_tile(rq, lane, cur, gm_tile(tb + MB_Q0 + t * 32, h));
+                for (int st = 0; st < 63; ++st)
+                    a = GM_MFMA(rq[(32 + st) * 64 + lane], gm_smp_at(c, SW_PE + 2 * st)[h * S + c.s], a);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
+                g.t[t] = a;
+            }
+            if (sv) gm_store_smp(c, ls + SL_G, g);
+            cur = gm_lin64(L + MG_Q2 * 64, tb + MB_Q2, lane, h, g);
+        }
+        // ================= ray transformer =================
+        {
+            V64 y = gm_layernorm(c, cur, tb + MB_LN + 256, tb + MB_LN + 320, 1e-6f, sv, ls + SL_RXH1, ls + SL_RRSTD1);
+            V64 q = gm_lin64(L + MG_RQ * 64, nullptr, lane, h, y);
+            {
+                const V64 k = gm_lin64(L + MG_RK * 64, nullptr, lane, h, y);
+                const V64 vv = gm_lin64(L + MG_RV * 64, nullptr, lane, h, y);
+                if (sv) {
+                    gm_store_smp(c, ls + SL_QH, q);
+                    gm_store_smp(c, ls + SL_KH, k);
+                    gm_store_smp(c, ls + SL_VH, vv);
+                }
+                // head hd = features 16 hd .. 16 hd + 15 = tile hd / 2, registers 8 (hd & 1) .. + 7, dims n(j, h)
+                // K record (hd, key tile = wave, step j): lane (key m, h) -> K[key][dim n(j, h)]  == own register
+                // V^T record (hd, key tile, step r): lane (dim i < 16, hh) -> V[key n(r, hh)][dim i]: this key is m = n(r, hh)
+                const int rk = ((m & 3) | ((m >> 3) << 2)), hk = (m >> 2) & 1;      // inverse of n(r, hh) for key m
+#pragma unroll
+                for (int hd = 0; hd < 4; ++hd) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 8 * (hd & 1) + j;
+                        Kl[((hd * NW + wave) * 8 + j) * 64 + lane] = k.t[hd >> 1][r];
+                        Vl[((hd * NW + wave) * 16 + rk) * GM_VT_STRIDE + gm_nidx(j, h) + 32 * hk] = vv.t[hd >> 1][r];
+                    }
+                }
+            }
+            __syncthreads();
+            V64 att;
+#pragma unroll
+            for (int hd = 0; hd < 4; ++hd) {
+                g16 sc[NW];
+                float mxh = -3.0e38f;
+#pragma unroll
+                for (int kt = 0; kt < NW; ++kt) {
+                    g16 a = gm_zero();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        a = GM_MFMA(Kl[((hd * NW + kt) * 8 + j) * 64 + lane], q.t[hd >> 1][8 * (hd & 1) + j] * 0.25f, a);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mxh = fmaxf(mxh, a[r]);
+                    sc[kt] = a;
+                }
+                mxh = gm_half_max(mxh);
+                float l = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NW; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        sc[kt][r] = __expf(sc[kt][r] - mxh);
+                        l += sc[kt][r];
+                    }
+                l = gm_half_sum(l);
+                g16 o = gm_zero();
+#pragma unroll
+                for (int kt = 0; kt < NW; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float av = (lane & 31) < 16 ? Vl[((hd * NW + kt) * 16 + r) * GM_VT_STRIDE + (lane & 31) + 32 * h] : 0.f;
+                        o = GM_MFMA(av, sc[kt][r], o);
+                    }
+                if (sv && h == 0) {
+                    gm_smp_at(c, ls + SL_ML + hd)[c.s] = mxh;
+                    gm_smp_at(c, ls + SL_ML + 4 + hd)[c.s] = l;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) att.t[hd >> 1][8 * (hd & 1) + j] = o[j] / l;
+            }
+            __syncthreads();        // K / V of this layer are dead: the next layer may overwrite the LDS image
+            if (sv) gm_store_smp(c, ls + SL_OUTA, att);
+            const V64 o = gm_lin64(L + MG_ROUT * 64, tb + MB_ROUT, lane, h, att);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) cur.t[t] += o.t[t];
+            y = gm_layernorm(c, cur, tb + MB_LN + 384, tb + MB_LN + 448, 1e-6f, sv, ls + SL_RXH2, ls + SL_RRSTD2);
+            const V64 f = gm_ff(c, L + MG_RFF * 64, tb + MB_RFF1, tb + MB_RFF2, lane, y, sv, ls + SL_F2);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) cur.t[t] += f.t[t];
+        }
+    }
+    // ---- final LayerNorm (eps 1e-5), mean over the samples, rgb_fc
+    {
+        const float* F = wb + gm_layer_base(depth);
+        const V64 hf = gm_layernorm(c, cur, F + MF_LNW, F + MF_LNB, 1e-5f, true, SW_XHF, SW_RSTDF);
+        float part[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float t = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t = fmaf(F[MF_W + ch * 64 + tt * 32 + h * 16 + r], hf.t[tt][r], t);
+            part[ch] = nf_wave_sum(t);
+        }
+        if (lane == 0) {
+            red[wave * 4 + 0] = part[0];
+            red[wave * 4 + 1] = part[1];
+            red[wave * 4 + 2] = part[2];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += red[w * 4 + threadIdx.x];
+            rgb_out[ray * 3 + threadIdx.x] = t / (float)S + F[MF_B + threadIdx.x];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+                     const float* ray_d, int64_t n_rays, int V, int depth, int save, float* rgb, float* workspace, hipStream_t st) {
+    constexpr int S = 32 * NW;
+    static bool configured = false;
+    const size_t smem = GmLds<NW>::FLOATS * sizeof(float);
+    if (!configured && smem > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            nf_set_error("nf_gnt_fwd_mfma: cannot reserve %zu bytes of LDS", smem);
+            return 1;
+        }
+        configured = true;
+    }
+    const int64_t rf = gnt_row_floats(depth, save), sf = gnt_smp_floats(depth, save);
+    const int64_t per_ray = (int64_t)S * V * rf + (int64_t)S * sf;
+    const int64_t step = save ? n_rays : GNT_RAYS_PER_LAUNCH;
+    for (int64_t r0 = 0; r0 < n_rays; r0 += step) {
+        const int64_t nr = n_rays - r0 < step ? n_rays - r0 : step;
+        hipLaunchKernelGGL(k_gnt_fwd_mfma<NW>, dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
+                           ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, V, depth, save ? 1 : 0,
+                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf);
+        NF_LAUNCH_CHECK("nf_gnt_fwd_mfma");
+    }
+    return 0;
+}
+
+/* Same contract as nf_gnt_fwd (workspace of nf_gnt_workspace_floats, consumed by nf_gnt_bwd when save != 0); weights in the
+ * layout of nf_gnt_pack_mfma.  S must satisfy nf_gnt_mfma_supported. */
+extern "C" int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
+                               const float* pts, const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save,
+                               float* rgb, float* workspace, nf_stream_t stream) {
+    NF_REQUIRE(nf_gnt_mfma_supported(n_samples, n_views) && depth >= 1 && depth <= 16 && n_rays >= 0,
+               "nf_gnt_fwd_mfma: S must be 32, 64, 96 or 128 and 1 <= V <= 64 (got S %d V %d depth %d)", n_samples, n_views, depth);
+    if (n_rays == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_samples / 32) {
+        case 1: return gm_launch<1>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
+        case 2: return gm_launch<2>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
+        case 3: return gm_launch<3>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
+        default: return gm_launch<4>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
+    }
+}

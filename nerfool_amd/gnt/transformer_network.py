@@ -2,10 +2,15 @@
 gnt/transformer_network.py:205-268 (rgbfeat_fc, view_crosstrans.N.{attn_norm, ff_norm, ff.fc1/fc2, attn.{q_fc,k_fc,v_fc,
 pos_fc.0/2, attn_fc.0/2, out_fc}}, view_selftrans.N.{...}, q_fcs.N.0/2 on even N, norm, rgb_fc) so that the public GNT
 checkpoints load by key.  Eval-mode semantics (Dropout = identity); the parameters are constants of the attack."""
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import ops
+
+# 'mfma': forward on the matrix cores where the shape allows (S in {32, 64, 96, 128}); 'generic': shape-generic kernels only
+KERNEL_PATH = os.environ.get('NERFOOL_GNT_KERNELS', 'mfma')
 
 
 class _FF(nn.Module):
@@ -46,9 +51,13 @@ class _TransformerParams(nn.Module):
 
 class _GNTFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, depth):
+    def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, mfma_blob, depth):
         need_grad = rgb_feat.requires_grad
-        rgb, ws = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad)
+        if mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2]):
+            # same workspace layout as the generic forward: the backward below consumes either
+            rgb, ws = ops.gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad)
+        else:
+            rgb, ws = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad)
         ctx.depth = depth
         ctx.shape = tuple(rgb_feat.shape[:3])
         ctx.have_ws = ws is not None
@@ -62,7 +71,7 @@ class _GNTFunction(torch.autograd.Function):
             raise RuntimeError('GNT forward ran without saved activations (input did not require grad)')
         ray_diff, mask, blob, ws = ctx.saved_tensors
         d_rgb_feat = ops.gnt_bwd(blob, ray_diff, mask, d_rgb, ws, ctx.shape, ctx.depth)
-        return d_rgb_feat, None, None, None, None, None, None
+        return d_rgb_feat, None, None, None, None, None, None, None
 
 
 class GNT(nn.Module):
@@ -86,16 +95,19 @@ class GNT(nn.Module):
         self.norm = nn.LayerNorm(w)
         self.rgb_fc = nn.Linear(w, 3)
         self._blob = None
+        self._mfma_blob = None
         self._blob_key = None
 
     def _packed(self, device):
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (str(device), KERNEL_PATH) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._blob is None or key != self._blob_key:
             self._blob = ops.pack_gnt_blob(self.state_dict(), self.trans_depth, device)
+            self._mfma_blob = ops.pack_gnt_mfma_blob(self._blob, self.trans_depth) if KERNEL_PATH == 'mfma' else None
             self._blob_key = key
-        return self._blob
+        return self._blob, self._mfma_blob
 
     def forward(self, rgb_feat, ray_diff, mask, pts, ray_d):
         """rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V,1], pts [R,S,3], ray_d [R,3] -> rgb [R,3]"""
-        blob = self._packed(rgb_feat.device)
-        return _GNTFunction.apply(rgb_feat, ray_diff, mask[..., 0], pts.detach(), ray_d.detach(), blob, self.trans_depth)
+        blob, mfma_blob = self._packed(rgb_feat.device)
+        return _GNTFunction.apply(rgb_feat, ray_diff, mask[..., 0], pts.detach(), ray_d.detach(), blob, mfma_blob,
+                                  self.trans_depth)

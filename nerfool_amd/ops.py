@@ -424,6 +424,34 @@ def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save):
     return rgb, (ws if save else None)
 
 
+def pack_gnt_mfma_blob(blob, depth):
+    """natural GNT blob (pack_gnt_blob) -> record-ordered blob of the matrix-core forward, on the same device"""
+    L = _lib.lib()
+    nat = blob.detach().to('cpu', torch.float32).contiguous()
+    out = torch.empty(L.nf_gnt_mfma_blob_floats(depth), dtype=torch.float32)
+    _lib.check(L.nf_gnt_pack_mfma(depth, nat.data_ptr(), out.data_ptr()), 'nf_gnt_pack_mfma')
+    return out.to(blob.device)
+
+
+def gnt_mfma_supported(n_samples, n_views):
+    return bool(_lib.lib().nf_gnt_mfma_supported(int(n_samples), int(n_views)))
+
+
+def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save):
+    rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
+    pts, ray_d = _c(pts, 'pts'), _c(ray_d, 'ray_d')
+    R, S, V, F = rgb_feat.shape
+    if F != 35:
+        raise ValueError('GNT expects 3+32 channels per view (got %d)' % F)
+    L = _lib.lib()
+    ws = torch.empty(L.nf_gnt_workspace_floats(R, S, V, depth, int(bool(save))), dtype=torch.float32, device=rgb_feat.device)
+    rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
+    with prof.launch('nf_gnt_fwd_mfma', rgb, R=R, S=S, V=V, depth=depth):
+        _lib.check(L.nf_gnt_fwd_mfma(_ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
+                                     depth, int(bool(save)), _ptr(rgb), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd_mfma')
+    return rgb, (ws if save else None)
+
+
 def gnt_bwd(blob, ray_diff, mask, d_rgb, ws, shape, depth):
     R, S, V = shape
     ray_diff, mask, d_rgb = _c(ray_diff, 'ray_diff'), _c(mask, 'mask'), _c(d_rgb, 'd_rgb')

@@ -464,6 +464,40 @@ def check_gnt(case, dev):
     assert_close(grad, gref, 1e-2, 2e-3 * float(np.abs(gref).max()), 'GNT d loss / d featmap', frac_ok=2e-3)
 
 
+def check_gnt_mfma_vs_generic(dev, shapes=((2, 32, 3, 2),)):
+    """Matrix-core GNT forward vs the shape-generic forward on random weights / inputs: the colour, and the gradient the
+    (shared) backward kernel derives from the activations each forward saved -- which checks every saved slot."""
+    from nerfool_amd.gnt.transformer_network import GNT
+    for (R, S, V, depth) in shapes:
+        torch.manual_seed(7 + S)
+        net = GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63)
+        with torch.no_grad():
+            for mod in net.modules():
+                if isinstance(mod, torch.nn.LayerNorm):
+                    mod.weight.uniform_(0.7, 1.3)
+                    mod.bias.uniform_(-0.2, 0.2)
+        blob = ops.pack_gnt_blob(net.state_dict(), depth, dev)
+        mblob = ops.pack_gnt_mfma_blob(blob, depth)
+        gen = torch.Generator().manual_seed(S)
+        rgb_feat = torch.randn(R, S, V, 35, generator=gen).to(dev)
+        rd = torch.randn(R, S, V, 4, generator=gen)
+        rd[..., :3] = torch.nn.functional.normalize(rd[..., :3], dim=-1)
+        mask = (torch.rand(R, S, V, generator=gen) > 0.2).float()
+        mask[0, :2] = 0                      # samples no view sees
+        pts = torch.randn(R, S, 3, generator=gen)
+        ray_d = torch.randn(R, 3, generator=gen)
+        args = (rgb_feat, rd.to(dev), mask.to(dev), pts.to(dev), ray_d.to(dev), depth)
+        rgb_a, ws_a = ops.gnt_fwd(blob, *args, save=True)
+        rgb_b, ws_b = ops.gnt_fwd_mfma(mblob, *args, save=True)
+        assert_close(rgb_b, rgb_a, 1e-4, 1e-4 * float(rgb_a.abs().max()), 'GNT rgb (matrix cores vs generic)')
+        rgb_c, _ = ops.gnt_fwd_mfma(mblob, *args, save=False)
+        assert_close(rgb_c, rgb_a, 1e-4, 1e-4 * float(rgb_a.abs().max()), 'GNT rgb (matrix cores, no save)')
+        d_rgb = torch.randn(R, 3, generator=gen).to(dev)
+        ga = ops.gnt_bwd(blob, args[1], args[2], d_rgb, ws_a, (R, S, V), depth)
+        gb = ops.gnt_bwd(blob, args[1], args[2], d_rgb, ws_b, (R, S, V), depth)
+        assert_close(gb, ga, 1e-3, 2e-4 * float(ga.abs().max()), 'GNT d rgb_feat from the activations saved by either forward')
+
+
 def check_gnt_attack_step(dev):
     """One GNT PGD step (ResUNet single_net + GNT renderer + unmasked MSE + backward to delta + fused Adam update) against
     the CPU oracle on the same weights and rays."""

@@ -123,3 +123,7 @@ def test_render_rays_through_mfma_kernels():
         pc.check_render_rays('ibrnet_tiny_invu', 'cpu')
     finally:
         mlp_network.KERNEL_PATH = 'generic'
+
+
+def test_gnt_matrix_core_forward_matches_generic():
+    pc.check_gnt_mfma_vs_generic('cpu', shapes=((2, 32, 3, 2),))

@@ -191,3 +191,8 @@ def test_full_size_properties():
         ops.pgd_adam_step_(delta, grad, m, v, src, 1e-3, t, eps)
         assert float(delta.abs().max()) <= eps + 1e-7
         assert float((src + delta).min()) >= -1e-6 and float((src + delta).max()) <= 1 + 1e-6
+
+
+@pytest.mark.parametrize('shape', [(3, 32, 4, 2), (2, 64, 10, 3), (2, 96, 3, 2), (2, 128, 5, 2)])
+def test_gnt_matrix_core_forward_matches_generic(shape):
+    pc.check_gnt_mfma_vs_generic('cuda', shapes=(shape,))

@@ -7,7 +7,7 @@ name=$1; shift
 mkdir -p build/variants/$name
 for f in nerfool_amd/csrc/*.hip; do
   o=build/variants/$name/$(basename $f).o
-  if [ "$(basename $f)" = nf_cnn.hip ] || [ ! -f $o ]; then
+  if [ "$(basename $f)" = ${NF_VARIANT_SRC:-nf_cnn.hip} ] || [ ! -f $o ]; then
     /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -std=c++17 -Iinclude -Inerfool_amd/csrc "$@" -c $f -o $o &
   fi
 done
