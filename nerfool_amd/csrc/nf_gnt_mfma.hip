@@ -21,14 +21,19 @@ typedef float g16 __attribute__((ext_vector_type(16)));
 
 __host__ __device__ constexpr int gm_nidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// ---- record layout (units: records of 64 floats), per layer -----------------------------------------------------------
+// ---- record layout (units: records of 64 floats), per layer: the few records of the tiny GEMMs first, then the STREAM --
+//      every 64-input GEMM tile is two chunks of 16 records, laid out in exactly the order the kernel consumes them, so the
+//      kernel can run a two-chunk-deep software pipeline over one monotonically advancing pointer (GmW below).
 enum {
-    MG_VQ = 0, MG_VK = 64, MG_VV = 128, MG_POS0 = 192, MG_POS2 = 194, MG_ATT0 = 202, MG_ATT2 = 234, MG_VOUT = 242,
-    MG_VFF = 306,            // 8 x [fc1 tile j: 32][fc2 k-tile j: 2 x 16]
-    MG_Q0 = 818,             // 2 x [cur 32 | pe 63]
-    MG_Q2 = 1008, MG_RQ = 1072, MG_RK = 1136, MG_RV = 1200, MG_ROUT = 1264,
-    MG_RFF = 1328, MG_LAYER_RECORDS = 1840
+    MG_POS0 = 0, MG_POS2 = 2, MG_ATT2 = 10, MG_STREAM = 32,
+    ST_VQ = 0, ST_VK = 64, ST_VV = 128, ST_ATT0 = 192, ST_VOUT = 224,
+    ST_VFF = 288,            // 8 x [fc1 tile j: 2 chunks][fc2 k-tile j: out tile 0, out tile 1]
+    ST_Q0 = 800,             // 2 x [cur: 2 chunks | positional: 4 chunks (63 k-steps + 1 zero record)]
+    ST_Q2 = 992, ST_RQ = 1056, ST_RK = 1120, ST_RV = 1184, ST_ROUT = 1248, ST_RFF = 1312, ST_END = 1824,
+    MG_LAYER_RECORDS = MG_STREAM + ST_END
 };
+#define GM_CHUNK 1024        // floats per chunk (16 records)
+#define GM_BLOB_PAD 4096     // the pipeline reads up to two chunks past the last record it needs
 // ---- per-layer tables behind the records (floats): bias tiles [h][16], LayerNorm vectors in fragment order [t][h][16]
 enum {
     MB_POS0 = 0, MB_POS2 = 32, MB_ATT0 = 96, MB_ATT2 = 128, MB_VOUT = 192, MB_VFF1 = 256, MB_VFF2 = 512, MB_Q0 = 576, MB_Q2 = 640,
@@ -43,7 +48,9 @@ enum { MF_LNW = 0, MF_LNB = 64, MF_W = 128, MF_B = 320, GM_FINAL_FLOATS = 324 };
 
 NF_HD inline int64_t gm_layer_base(int i) { return GM_STEM_FLOATS + (int64_t)i * GM_LAYER_FLOATS; }
 
-extern "C" int64_t nf_gnt_mfma_blob_floats(int depth) { return GM_STEM_FLOATS + (int64_t)depth * GM_LAYER_FLOATS + GM_FINAL_FLOATS; }
+extern "C" int64_t nf_gnt_mfma_blob_floats(int depth) {
+    return GM_STEM_FLOATS + (int64_t)depth * GM_LAYER_FLOATS + GM_FINAL_FLOATS + GM_BLOB_PAD;
+}
 
 extern "C" int nf_gnt_mfma_supported(int n_samples, int n_views) {
     return n_samples >= 32 && n_samples <= 128 && n_samples % 32 == 0 && n_views >= 1 && n_views <= 64;
@@ -99,43 +106,45 @@ extern "C" int nf_gnt_pack_mfma(int depth, const float* nat, float* out) {
         const float* L = nat + gnt_layer_base(i);
         float* base = out + gm_layer_base(i);
         float* rec = base;
+        gm_seq(rec, L + gnt_w(GV_POS0), 8, 4, 0, 0, 2);
+        for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_w(GV_POS2), 64, 8, nt, 0, 4);
+        for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_w(GV_ATT2), 64, 8, nt, 0, 4);
+        if (rec - base != 18 * 64) return 2;
+        rec = base + MG_STREAM * 64;
+        float* st0 = rec;
         gm_lin64(rec, L + gnt_w(GV_Q), 64, 64);
         gm_lin64(rec, L + gnt_w(GV_K), 64, 64);
         gm_lin64(rec, L + gnt_w(GV_V), 64, 64);
-        gm_seq(rec, L + gnt_w(GV_POS0), 8, 4, 0, 0, 2);
-        for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_w(GV_POS2), 64, 8, nt, 0, 4);
         gm_lin64(rec, L + gnt_w(GV_ATT0), 8, 64);
-        for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_w(GV_ATT2), 64, 8, nt, 0, 4);
         gm_lin64(rec, L + gnt_w(GV_OUT), 64, 64);
-        if (rec - base != MG_VFF * 64) return 2;
         for (int pass = 0; pass < 2; ++pass) {                  // view FF, then ray FF: hidden tile j chained into fc2
             const int l1 = pass == 0 ? GV_FF1 : GR_FF1, l2 = pass == 0 ? GV_FF2 : GR_FF2;
-            if (pass == 1) {
-                if (rec - base != MG_Q0 * 64) return 3;
-                if ((i & 1) == 0) {
-                    const float* W0 = L + gnt_w(GQ_0);          // [64][190]: 64 current features, 126 positional
-                    for (int nt = 0; nt < 2; ++nt) {
-                        gm_frag(rec, W0, 64, 190, nt, 0, 16);
-                        gm_frag(rec, W0, 64, 190, nt, 32, 16);
-                        gm_seq(rec, W0, 64, 190, nt, 64, 63);
-                    }
-                    gm_lin64(rec, L + gnt_w(GQ_2), 64, 64);
-                } else {
-                    rec += (190 + 64) * 64;
-                }
-                gm_lin64(rec, L + gnt_w(GR_Q), 64, 64);
-                gm_lin64(rec, L + gnt_w(GR_K), 64, 64);
-                gm_lin64(rec, L + gnt_w(GR_V), 64, 64);
-                gm_lin64(rec, L + gnt_w(GR_OUT), 64, 64);
-                if (rec - base != MG_RFF * 64) return 4;
-            }
+            if (rec - st0 != (pass == 0 ? ST_VFF : ST_RFF) * 64) return 3;
             for (int j = 0; j < 8; ++j) {
                 gm_frag(rec, L + gnt_w(l1), 256, 64, j, 0, 16);
                 gm_frag(rec, L + gnt_w(l1), 256, 64, j, 32, 16);
                 for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_w(l2), 64, 256, nt, 32 * j, 16);
             }
+            if (pass == 0) {
+                if ((i & 1) == 0) {
+                    const float* W0 = L + gnt_w(GQ_0);          // [64][190]: 64 current features, 126 positional
+                    for (int nt = 0; nt < 2; ++nt) {
+                        gm_frag(rec, W0, 64, 190, nt, 0, 16);
+                        gm_frag(rec, W0, 64, 190, nt, 32, 16);
+                        gm_seq(rec, W0, 64, 190, nt, 64, 64);   // step 63 reads inputs 190, 191: out of range -> zero record
+                    }
+                    gm_lin64(rec, L + gnt_w(GQ_2), 64, 64);
+                } else {
+                    rec += (192 + 64) * 64;
+                }
+                if (rec - st0 != ST_RQ * 64) return 4;
+                gm_lin64(rec, L + gnt_w(GR_Q), 64, 64);
+                gm_lin64(rec, L + gnt_w(GR_K), 64, 64);
+                gm_lin64(rec, L + gnt_w(GR_V), 64, 64);
+                gm_lin64(rec, L + gnt_w(GR_OUT), 64, 64);
+            }
         }
-        if (rec - base != MG_LAYER_RECORDS * 64) return 5;
+        if (rec - st0 != ST_END * 64) return 5;
         float* tb = base + (int64_t)MG_LAYER_RECORDS * 64;
         gm_vec_tiles(tb + MB_POS0, L + gnt_b(GV_POS0), 8);
         gm_vec_tiles(tb + MB_POS2, L + gnt_b(GV_POS2), 64);
@@ -220,6 +229,50 @@ __device__ __forceinline__ V64 gm_lin64(const float* __restrict__ rec, const flo
     return y;
 }
 
+// ---- weight stream: two chunks (2 x 16 records) are always in flight; consuming a chunk immediately issues the loads of the
+//      chunk two ahead (w.p).  With one wave per SIMD (512 rays x 2 waves = one wave per SIMD of the chip) nothing else hides
+//      the ~1 us L2 latency of the weight loads.  Non-contiguous transitions set w.p before the last TWO chunks of a segment.
+struct GmW { g16 a, b; const float* p; };
+__device__ __forceinline__ g16 gm_ld16(const float* __restrict__ p, int lane) {
+    g16 v;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = p[r * 64 + lane];
+    return v;
+}
+__device__ __forceinline__ void gm_w_start(GmW& w, const float* p, int lane) {
+    w.a = gm_ld16(p, lane);
+    w.b = gm_ld16(p + GM_CHUNK, lane);
+    w.p = p + 2 * GM_CHUNK;
+}
+__device__ __forceinline__ g16 gm_mfma16(const g16& wv, const g16& x, g16 acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc = GM_MFMA(wv[r], x[r], acc);
+    return acc;
+}
+__device__ __forceinline__ g16 gm_take_a(GmW& w, int lane, const g16& x, g16 acc) {
+    acc = gm_mfma16(w.a, x, acc);
+    w.a = gm_ld16(w.p, lane);
+    w.p += GM_CHUNK;
+    return acc;
+}
+__device__ __forceinline__ g16 gm_take_b(GmW& w, int lane, const g16& x, g16 acc) {
+    acc = gm_mfma16(w.b, x, acc);
+    w.b = gm_ld16(w.p, lane);
+    w.p += GM_CHUNK;
+    return acc;
+}
+// one 32-output tile of a 64-input linear = chunk a (k-tile 0) then chunk b (k-tile 1)
+__device__ __forceinline__ g16 gm_tile_s(GmW& w, int lane, const V64& x, g16 acc) {
+    acc = gm_take_a(w, lane, x.t[0], acc);
+    return gm_take_b(w, lane, x.t[1], acc);
+}
+__device__ __forceinline__ V64 gm_lin64_s(GmW& w, const float* __restrict__ tb, int lane, int h, const V64& x) {
+    V64 y;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) y.t[t] = gm_tile_s(w, lane, x, tb ? gm_tile(tb + t * 32, h) : gm_zero());
+    return y;
+}
+
 // Workspace addressing: feature 32 t + n(r, h) = [32 t + n(r, 0)] + 4 h, so every access is a WAVE-UNIFORM base (scalar
 // registers, scalar arithmetic) plus one of two per-lane 32-bit offsets computed once: 4 h S + s for the per-sample slots,
 // 4 h V S + s for the per-(sample, view) slots.  (Per-element 64-bit vector address arithmetic, hoisted out of the view loop
@@ -294,23 +347,25 @@ __device__ __forceinline__ V64 gm_layernorm(const GmCtx& c, const V64& x, const 
     return y;
 }
 
-// feed-forward 64 -> 256 (ReLU) -> 64, hidden tile j chained straight into fc2; returns FF(y) (bias included)
-__device__ __forceinline__ V64 gm_ff(const GmCtx& c, const float* __restrict__ rec, const float* __restrict__ b1,
-                                     const float* __restrict__ b2, int lane, const V64& y, bool save, int f_slot) {
+// feed-forward 64 -> 256 (ReLU) -> 64, hidden tile j chained straight into fc2; returns FF(y) (bias included).
+// jump (nullable): where the stream continues behind this block when that is not the next record in memory.
+__device__ __forceinline__ V64 gm_ff(const GmCtx& c, GmW& w, const float* __restrict__ b1, const float* __restrict__ b2, int lane,
+                                     const V64& y, bool save, int f_slot, const float* jump) {
     V64 o;
     o.t[0] = gm_tile(b2, c.h);
     o.t[1] = gm_tile(b2 + 32, c.h);
+#pragma unroll 1
     for (int j = 0; j < 8; ++j) {
-        const float* rj = rec + (size_t)j * 64 * 64;
-        g16 f = gm_lin_tile(rj, lane, y, gm_tile(b1 + j * 32, c.h));
+        g16 f = gm_tile_s(w, lane, y, gm_tile(b1 + j * 32, c.h));
+        if (j == 7 && jump) w.p = jump;
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[r] = fmaxf(f[r], 0.f);
         if (save) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) gm_smp_at(c, f_slot + 32 * j + gm_nidx(r, 0))[c.smp_lane] = f[r];
         }
-        o.t[0] = gm_gemm<16>(rj + 32 * 64, lane, f, o.t[0]);
-        o.t[1] = gm_gemm<16>(rj + 48 * 64, lane, f, o.t[1]);
+        o.t[0] = gm_take_a(w, lane, f, o.t[0]);
+        o.t[1] = gm_take_b(w, lane, f, o.t[1]);
     }
     return o;
 }
@@ -404,11 +459,15 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
             gm_smp_at(c, SW_PE + 2 * st)[h * S + c.s] = val;
         }
     }
+    GmW w;
+    gm_w_start(w, wb + gm_layer_base(0) + MG_STREAM * 64, lane);
     for (int i = 0; i < depth; ++i) {
         const float* Lbase = wb + gm_layer_base(i);
         const float* tbase = Lbase + (size_t)MG_LAYER_RECORDS * 64;
         const float* L = Lbase;
         const float* tb = tbase;
+        const float* Lst = Lbase + MG_STREAM * 64;                                        // this layer's stream
+        const float* next_stream = i + 1 < depth ? wb + gm_layer_base(i + 1) + MG_STREAM * 64 : nullptr;
         const int ls = SW_BASE + (sv ? i : 0) * SW_LAYER;
         const int lr = RW_BASE + (sv ? i : 0) * RW_LAYER;
         // ================= view transformer =================
@@ -417,7 +476,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
             // the running state of the online softmax needs 96 registers: the residual stream and Q wait in the (L2-resident)
             // workspace while the views are walked
             gm_store_smp(c, SW_CUR, cur);
-            gm_store_smp(c, SW_QV, gm_lin64(L + MG_VQ * 64, nullptr, lane, h, y));
+            gm_store_smp(c, SW_QV, gm_lin64_s(w, nullptr, lane, h, y));
             V64 mx, sum, acc;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -437,7 +496,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                 V64 T2;
                 {
                     const V64 X = gm_load_row(c, RW_X, v);
-                    const V64 K = gm_lin64(L + MG_VK * 64, nullptr, lane, h, X);
+                    const V64 K = gm_lin64_s(w, nullptr, lane, h, X);
                     const float* rd = ray_diff + ((size_t)c.s * V + v) * 4;
                     g16 rin = gm_zero();
                     rin[0] = rd[h];
@@ -445,7 +504,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                     g16 h0 = gm_gemm<2>(L + MG_POS0 * 64, lane, rin, gm_tile(tb + MB_POS0, h));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) h0[r] = fmaxf(h0[r], 0.f);
-                    const V64 Vv = gm_lin64(L + MG_VV * 64, nullptr, lane, h, K);
+                    const V64 Vv = gm_lin64_s(w, nullptr, lane, h, K);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const g16 pos = gm_gemm<4>(L + (MG_POS2 + 4 * t) * 64, lane, h0, gm_tile(tb + MB_POS2 + t * 32, h));
@@ -457,7 +516,8 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                         }
                     }
                 }
-                g16 hid = gm_lin_tile(L + MG_ATT0 * 64, lane, T2, gm_tile(tb + MB_ATT0, h));
+                if (v + 1 < V) w.p = Lst + ST_VK * 64;      // the last two chunks of the body prefetch the next view's first two
+                g16 hid = gm_tile_s(w, lane, T2, gm_tile(tb + MB_ATT0, h));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hid[r] = fmaxf(hid[r], 0.f);
                 if (sv) {
@@ -497,12 +557,12 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                             *pp = __expf(*pp - mx.t[t][r]) / sum.t[t][r];
                         }
             }
-            const V64 o = gm_lin64(L + MG_VOUT * 64, tb + MB_VOUT, lane, h, u);
+            const V64 o = gm_lin64_s(w, tb + MB_VOUT, lane, h, u);
             cur = gm_load_smp(c, SW_CUR);
 #pragma unroll
             for (int t = 0; t < 2; ++t) cur.t[t] += o.t[t];
             y = gm_layernorm(c, cur, tb + MB_LN + 128, tb + MB_LN + 192, 1e-6f, sv, ls + SL_XH2, ls + SL_RSTD2);
-            const V64 f = gm_ff(c, L + MG_VFF * 64, tb + MB_VFF1, tb + MB_VFF2, lane, y, sv, ls + SL_F);
+            const V64 f = gm_ff(c, w, tb + MB_VFF1, tb + MB_VFF2, lane, y, sv, ls + SL_F, (i & 1) ? Lst + ST_RQ * 64 : nullptr);
 #pragma unroll
             for (int t = 0; t < 2; ++t) cur.t[t] += f.t[t];
         }
@@ -511,24 +571,31 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
             V64 g;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const float* rq = L + (MG_Q0 + 95 * t) * 64;
-                g16 a = gm_lin_tile(rq, lane, cur, gm_tile(tb + MB_Q0 + t * 32, h));
-                for (int st = 0; st < 63; ++st)
-                    a = GM_MFMA(rq[(32 + st) * 64 + lane], gm_smp_at(c, SW_PE + 2 * st)[h * S + c.s], a);
+                g16 a = gm_tile_s(w, lane, cur, gm_tile(tb + MB_Q0 + t * 32, h));
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {        // 126 positional features in memory order 2 st + h (+ one zero step)
+                    g16 pe;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int st = 16 * ch + r;
+                        pe[r] = st < 63 ? gm_smp_at(c, SW_PE + 2 * st)[h * S + c.s] : 0.f;
+                    }
+                    a = (ch & 1) ? gm_take_b(w, lane, pe, a) : gm_take_a(w, lane, pe, a);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[r] = fmaxf(a[r], 0.f);
                 g.t[t] = a;
             }
             if (sv) gm_store_smp(c, ls + SL_G, g);
-            cur = gm_lin64(L + MG_Q2 * 64, tb + MB_Q2, lane, h, g);
+            cur = gm_lin64_s(w, tb + MB_Q2, lane, h, g);
         }
         // ================= ray transformer =================
         {
             V64 y = gm_layernorm(c, cur, tb + MB_LN + 256, tb + MB_LN + 320, 1e-6f, sv, ls + SL_RXH1, ls + SL_RRSTD1);
-            V64 q = gm_lin64(L + MG_RQ * 64, nullptr, lane, h, y);
+            V64 q = gm_lin64_s(w, nullptr, lane, h, y);
             {
-                const V64 k = gm_lin64(L + MG_RK * 64, nullptr, lane, h, y);
-                const V64 vv = gm_lin64(L + MG_RV * 64, nullptr, lane, h, y);
+                const V64 k = gm_lin64_s(w, nullptr, lane, h, y);
+                const V64 vv = gm_lin64_s(w, nullptr, lane, h, y);
                 if (sv) {
                     gm_store_smp(c, ls + SL_QH, q);
                     gm_store_smp(c, ls + SL_KH, k);
@@ -591,11 +658,11 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
             }
             __syncthreads();        // K / V of this layer are dead: the next layer may overwrite the LDS image
             if (sv) gm_store_smp(c, ls + SL_OUTA, att);
-            const V64 o = gm_lin64(L + MG_ROUT * 64, tb + MB_ROUT, lane, h, att);
+            const V64 o = gm_lin64_s(w, tb + MB_ROUT, lane, h, att);
 #pragma unroll
             for (int t = 0; t < 2; ++t) cur.t[t] += o.t[t];
             y = gm_layernorm(c, cur, tb + MB_LN + 384, tb + MB_LN + 448, 1e-6f, sv, ls + SL_RXH2, ls + SL_RRSTD2);
-            const V64 f = gm_ff(c, L + MG_RFF * 64, tb + MB_RFF1, tb + MB_RFF2, lane, y, sv, ls + SL_F2);
+            const V64 f = gm_ff(c, w, tb + MB_RFF1, tb + MB_RFF2, lane, y, sv, ls + SL_F2, next_stream);
 #pragma unroll
             for (int t = 0; t < 2; ++t) cur.t[t] += f.t[t];
         }
