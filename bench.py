@@ -36,6 +36,25 @@ def ibrnet_flops(R, S, V):
     return 2.0 * R * S * (V * 13256 + 6480 + 32 * S)
 
 
+def pmc_traffic(kernel, a):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in their own runs of this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the
+    profile does not cover this workload: counters cannot be read from inside the benchmark process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+    except (OSError, ValueError):
+        return None
+    w = prof.get('workload', {})
+    if (w.get('model'), w.get('n_rand'), w.get('height'), w.get('width'), w.get('views')) != (a.model, a.n_rand, a.height, a.width, a.views):
+        return None
+    entry = prof.get('abi_kernels', {}).get(kernel)
+    return None if entry is None else {'hbm_bytes_per_launch': entry['hbm_bytes_per_launch'], 'unit': 'B',
+                                       'algorithmic_bytes_per_launch': entry.get('algorithmic_bytes_per_launch'),
+                                       'source': 'profiles/r01_pmc_traffic.json'}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -122,7 +141,7 @@ def main():
     if a.model == 'gnt':          # config 4 defaults unless the user overrode the sizes
         if (a.height, a.width, a.views) == (756, 1008, 4):
             a.height, a.width, a.views = 800, 800, 10
-        a.importance, a.render_chunks, a.cpu_iters = 0, 0, 0
+        a.importance, a.cpu_iters = 0, 0
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -176,7 +195,14 @@ def main():
     # ---- render-throughput leg (forward only, feature maps resident), outside the timed region of the headline value
     render = None
     if a.render_chunks > 0 and rank == 0:
-        from nerfool_amd.ibrnet.render_ray import render_rays
+        if a.model == 'gnt':
+            from nerfool_amd.gnt.render_ray import render_rays as gnt_render_rays
+
+            def render_rays(rb, model, featmaps, projector, n_samples, **kw):
+                kw.pop('N_importance', None)
+                return gnt_render_rays(rb, model, featmaps, projector, n_samples, N_importance=0, **kw)
+        else:
+            from nerfool_amd.ibrnet.render_ray import render_rays
         with torch.no_grad():
             featmaps = model.feature_net((src_ray_batch['src_rgbs'] + attack.delta).squeeze(0).permute(0, 3, 1, 2))
             rays = sampler.get_all()
@@ -214,7 +240,7 @@ def main():
             elif name == 'nf_project_gather_bwd':
                 b = meta['n_pts'] * meta['V'] * ((3 + meta['C']) * 4 + 4 * meta['C'] * 4)
                 per_launch.append(('hbm', b / (ms * 1e-3) / 1e9))
-            elif name in ('nf_gnt_fwd', 'nf_gnt_bwd'):
+            elif name in ('nf_gnt_fwd', 'nf_gnt_fwd_mfma', 'nf_gnt_bwd'):
                 fl = 2.0 * meta['R'] * meta['S'] * (meta['V'] * (6336 + meta['depth'] * 9760)
                                                     + meta['depth'] * 98304 + ((meta['depth'] + 1) // 2) * 16256)
                 per_launch.append(('mfma', fl / (ms * 1e-3) / 1e12))
@@ -232,7 +258,7 @@ def main():
     if dominant:
         d = table[dominant]
         roofline = {'kernel': dominant, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'], 'unit': d['unit'],
-                    'frac': d['frac'], 'traffic': None}
+                    'frac': d['frac'], 'traffic': pmc_traffic(dominant, a)}
 
     rays_per_step = a.n_rand * world
     out = {

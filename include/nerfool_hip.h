@@ -209,16 +209,20 @@ int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* 
  *   act 0 none / 1 ReLU / 2 ELU; y_padded [N,C,H+2p,W+2p]; mean, rstd [N*C] out (saved for the backward).
  * Backward: dy_padded (nullable) = gradient w.r.t. y_padded, d_extra (nullable, [N,C,H,W]) = additional gradient w.r.t.
  * the unpadded activated output (residual / skip consumers); d_res (nullable out) = gradient of the residual input;
+ * y_n_stride / dy_n_stride: elements between consecutive images of y_padded / dy_padded (0 = packed); lets the C planes
+ * be a channel slice of a wider tensor (the decoder's skip concatenation is written / folded slice by slice, no torch.cat).
+ * d_extra_sub (nullable, [N,C,ceil(H/2),ceil(W/2)]): gradient of a stride-2 consumer of the unpadded output (the 1x1
+ * downsample convolution), added at the even rows / columns.
  * beta (nullable): when given and no residual went into the activation, its derivative is recomputed from x and
  * y_padded is not read (may be NULL);
  * dx [N,C,H,W] = gradient of x.   scratch: 512 bytes per (image, channel) plane (fp64 partial sums of up to 32 workgroups; no atomics).
  * ---------------------------------------------------------------------------------------------------------------- */
 int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W, const float* gamma, const float* beta, float eps,
                       const float* res, int64_t rs_n, int64_t rs_c, int64_t rs_h, int64_t rs_w, int act, int pad,
-                      float* y_padded, float* mean, float* rstd, void* scratch, nf_stream_t stream);
+                      float* y_padded, int64_t y_n_stride, float* mean, float* rstd, void* scratch, nf_stream_t stream);
 int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, const float* y_padded, const float* x, int n_img, int C,
                       int H, int W, const float* gamma, const float* beta, const float* mean, const float* rstd, int act, int pad,
-                      float* d_res, float* dx, void* scratch, nf_stream_t stream);
+                      float* d_res, float* dx, void* scratch, int64_t dy_n_stride, const float* d_extra_sub, nf_stream_t stream);
 
 #ifdef __cplusplus
 }

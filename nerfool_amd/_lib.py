@@ -56,8 +56,9 @@ _PROTOTYPES = {
     'nf_gnt_mfma_supported': (c_int, [c_int, c_int]),
     'nf_gnt_fwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'nf_in_act_pad_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_int64, c_int64, c_int64, c_int64,
-                                  c_int, c_int, _P, _P, _P, _P, _P]),
-    'nf_in_act_pad_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+                                  c_int, c_int, _P, c_int64, _P, _P, _P, _P]),
+    'nf_in_act_pad_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64,
+                                  _P, _P]),
     'nf_upsample2x_pad_fwd': (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, _P]),
     'nf_project_perturb': (c_int, [_P, _P, c_int64, c_float, c_float, c_float, _P]),
     'nf_pgd_adam_step': (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float,

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_fwd(const float* __
                                                                  const float* __restrict__ res, int64_t rs_n, int64_t rs_c,
                                                                  int64_t rs_h, int64_t rs_w, int act, int pad,
                                                                  float* __restrict__ yp, float* __restrict__ mean_out,
-                                                                 float* __restrict__ rstd_out) {
+                                                                 float* __restrict__ rstd_out, int64_t y_n_stride) {
     const int64_t p = blockIdx.y;
     const int n = (int)(p / C), c = (int)(p - (int64_t)n * C);
     const int HW = H * W;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_fwd(const float* __
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     const float* xp = x + p * HW;
     const float* rp = res ? res + n * rs_n + c * rs_c : nullptr;
-    float* out = yp + p * (int64_t)Hp * Wp;
+    float* out = yp + n * y_n_stride + c * (int64_t)Hp * Wp;
     // one work item = 4 consecutive interior columns of one padded row (16-byte accesses; the padded rows are only
     // 4-byte aligned, hence the unaligned vector type); the items next to the left / right border also fill the pad columns
     const int G = (W + 3) >> 2, total = Hp * G;
@@ -255,10 +255,16 @@ __device__ __forceinline__ nf_f4u fold_item(const float* __restrict__ gp, int h,
 // d_pre of an item = (d_extra + folded padded gradient) * activation'(.), and the item of x (zeros beyond nvalid)
 __device__ __forceinline__ void item_d_pre(const float* __restrict__ gp, const float* __restrict__ ep, const float* __restrict__ yq,
                                            const float* __restrict__ xq, int h, int w0, int nvalid, int H, int W, int pad, int Wp,
-                                           int act, bool from_x, float mean, float rstd, float ga, float be, nf_f4u& d, nf_f4u& xv) {
+                                           int act, bool from_x, float mean, float rstd, float ga, float be, nf_f4u& d, nf_f4u& xv,
+                                           const float* __restrict__ es) {
     const int i0 = h * W + w0;
     d = ep ? load_item(ep + i0, nvalid) : nf_f4u{0.f, 0.f, 0.f, 0.f};
     if (gp) d += fold_item(gp, h, w0, nvalid, H, W, pad, Wp);
+    if (es && !(h & 1)) {       // gradient of a stride-2 consumer of the unpadded output (1x1 downsample): even rows / columns
+        const float* er = es + (h >> 1) * ((W + 1) >> 1) + (w0 >> 1);      // w0 is a multiple of 4
+        if (nvalid > 0) d[0] += er[0];
+        if (nvalid > 2) d[2] += er[1];
+    }
     xv = xq ? load_item(xq + i0, nvalid) : nf_f4u{0.f, 0.f, 0.f, 0.f};
     if (from_x) {
 #pragma unroll
@@ -278,13 +284,15 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd1(const float* _
                                                                   const float* __restrict__ rstd_in, int has_norm, int act, int pad,
                                                                   float* __restrict__ d_res, float* __restrict__ dx,
                                                                   double* __restrict__ sums, int from_x, int C,
-                                                                  const float* __restrict__ gamma, const float* __restrict__ beta) {
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int64_t dy_n_stride, const float* __restrict__ d_extra_sub) {
     const int64_t p = blockIdx.y;
     // from_x: the activation derivative is recomputed from x (no residual went into the activation), y_padded is not read
     const float ga = from_x ? gamma[p % C] : 1.f, be = from_x ? beta[p % C] : 0.f;
     const int HW = H * W, Hp = H + 2 * pad, Wp = W + 2 * pad;
-    const float* gp = dyp ? dyp + p * (int64_t)Hp * Wp : nullptr;
+    const float* gp = dyp ? dyp + (p / C) * dy_n_stride + (p % C) * (int64_t)Hp * Wp : nullptr;
     const float* ep = d_extra ? d_extra + p * HW : nullptr;
+    const float* es = d_extra_sub ? d_extra_sub + p * (int64_t)((H + 1) >> 1) * ((W + 1) >> 1) : nullptr;
     const float* yq = yp ? yp + p * (int64_t)Hp * Wp : nullptr;
     const float* xq = has_norm ? x + p * HW : nullptr;
     float* dxp = dx + p * HW;
@@ -300,7 +308,7 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_in_act_pad_bwd1(const float* _
     for (int idx = lo + threadIdx.x; idx < hi; idx += blockDim.x) {
         const int h = idx / G, w0 = (idx - h * G) << 2, nvalid = min(4, W - w0), i0 = h * W + w0;
         nf_f4u d, xv;
-        item_d_pre(gp, ep, yq, xq, h, w0, nvalid, H, W, pad, Wp, act, from_x != 0, mean, rstd, ga, be, d, xv);
+        item_d_pre(gp, ep, yq, xq, h, w0, nvalid, H, W, pad, Wp, act, from_x != 0, mean, rstd, ga, be, d, xv, es);
         if (drp) store_item(drp + i0, d, nvalid);
         if (store_dx) store_item(dxp + i0, d, nvalid);
         if (has_norm) {
@@ -386,7 +394,7 @@ __global__ void __launch_bounds__(NT) k_plane_fwd(const float* __restrict__ x, i
                                                   const float* __restrict__ beta, float eps, const float* __restrict__ res,
                                                   int64_t rs_n, int64_t rs_c, int64_t rs_h, int64_t rs_w, int act, int pad,
                                                   float* __restrict__ yp, float* __restrict__ mean_out,
-                                                  float* __restrict__ rstd_out) {
+                                                  float* __restrict__ rstd_out, int64_t y_n_stride) {
     const int64_t p = blockIdx.x;
     const int n = (int)(p / C), c = (int)(p - (int64_t)n * C);
     const int HW = H * W, Hp = H + 2 * pad, Wp = W + 2 * pad;
@@ -416,7 +424,7 @@ __global__ void __launch_bounds__(NT) k_plane_fwd(const float* __restrict__ x, i
         rstd_out[p] = rstd;
     }
     const float* rp = res ? res + n * rs_n + c * rs_c : nullptr;
-    float* out = yp + p * (int64_t)Hp * Wp;
+    float* out = yp + n * y_n_stride + c * (int64_t)Hp * Wp;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const int idx = threadIdx.x + k * NT;
@@ -467,15 +475,17 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
                                                   const float* __restrict__ yp, const float* __restrict__ x, int C, int H, int W,
                                                   const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                   const float* __restrict__ rstd_in, int act, int pad, float* __restrict__ d_res,
-                                                  float* __restrict__ dx, const float* __restrict__ beta) {
+                                                  float* __restrict__ dx, const float* __restrict__ beta, int64_t dy_n_stride,
+                                                  const float* __restrict__ d_extra_sub) {
     const int64_t p = blockIdx.x;
     const int c = (int)(p % C);
     const bool from_x = beta != nullptr;        // activation derivative recomputed from x, y_padded not read
     const float ga = gamma[c], be = from_x ? beta[c] : 0.f;
     const int HW = H * W, Hp = H + 2 * pad, Wp = W + 2 * pad;
     const int G = (W + 3) >> 2, total = H * G;
-    const float* gp = dyp ? dyp + p * (int64_t)Hp * Wp : nullptr;
+    const float* gp = dyp ? dyp + (p / C) * dy_n_stride + c * (int64_t)Hp * Wp : nullptr;
     const float* ep = d_extra ? d_extra + p * HW : nullptr;
+    const float* es = d_extra_sub ? d_extra_sub + p * (int64_t)((H + 1) >> 1) * ((W + 1) >> 1) : nullptr;
     const float* yq = yp ? yp + p * (int64_t)Hp * Wp : nullptr;
     const float* xq = x + p * HW;
     const float mean = mean_in[p], rstd = rstd_in[p];
@@ -489,7 +499,7 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
         const int h = idx / G, w0 = (idx - h * G) << 2, nvalid = idx < total ? min(4, W - w0) : 0;
         nf_f4u xv;
         if (nvalid > 0) {
-            item_d_pre(gp, ep, yq, xq, h, w0, nvalid, H, W, pad, Wp, act, from_x, mean, rstd, ga, be, dv[k], xv);
+            item_d_pre(gp, ep, yq, xq, h, w0, nvalid, H, W, pad, Wp, act, from_x, mean, rstd, ga, be, dv[k], xv, es);
         } else {
             dv[k] = nf_f4u{0.f, 0.f, 0.f, 0.f};
             xv = nf_f4u{mean, mean, mean, mean};
@@ -599,17 +609,18 @@ __global__ void __launch_bounds__(NF_CNN_BLOCK) k_upsample2x_pad(const float* __
 
 extern "C" int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W, const float* gamma, const float* beta, float eps,
                                  const float* res, int64_t rs_n, int64_t rs_c, int64_t rs_h, int64_t rs_w, int act, int pad,
-                                 float* y_padded, float* mean, float* rstd, void* scratch, nf_stream_t stream) {
+                                 float* y_padded, int64_t y_n_stride, float* mean, float* rstd, void* scratch, nf_stream_t stream) {
     NF_REQUIRE(n_img >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad < H && pad < W && act >= 0 && act <= 2,
                "nf_in_act_pad_fwd: bad arguments (N %d C %d H %d W %d pad %d act %d)", n_img, C, H, W, pad, act);
     hipStream_t st = (hipStream_t)stream;
     const int planes = n_img * C, HW = H * W, HWp = (H + 2 * pad) * (W + 2 * pad);
+    if (y_n_stride == 0) y_n_stride = (int64_t)C * HWp;       // packed [N,C,Hp,Wp]
     int variant = gamma ? nf_plane_variant(H, W) : 0;
     if (variant == 3) variant = 0;      // one 1024-thread workgroup per CU serialises load / reduce / store: two passes are faster
     if (variant) {
 #define NF_PLANE_FWD(NT, EPT)                                                                                                   \
     hipLaunchKernelGGL((k_plane_fwd<NT, EPT>), dim3((unsigned)planes), dim3(NT), 0, st, x, C, H, W, gamma, beta, eps, res, rs_n, \
-                       rs_c, rs_h, rs_w, act, pad, y_padded, mean, rstd)
+                       rs_c, rs_h, rs_w, act, pad, y_padded, mean, rstd, y_n_stride)
         if (variant == 1) NF_PLANE_FWD(256, 3);
         else if (variant == 2) NF_PLANE_FWD(1024, 3);
         else NF_PLANE_FWD(1024, 12);
@@ -626,20 +637,22 @@ extern "C" int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W,
     }
     hipLaunchKernelGGL(k_in_act_pad_fwd, dim3(nf_apply_splits(planes, HWp, 1024), (unsigned)planes), dim3(NF_CNN_BLOCK), 0, st, x, C, H, W,
                        gamma, beta, eps, (const double*)scratch, (int)stat_splits, res, rs_n, rs_c, rs_h, rs_w, act, pad, y_padded, mean,
-                       rstd);
+                       rstd, y_n_stride);
     NF_LAUNCH_CHECK("nf_in_act_pad_fwd");
     return 0;
 }
 
 extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, const float* y_padded, const float* x, int n_img,
                                  int C, int H, int W, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                 int act, int pad, float* d_res, float* dx, void* scratch, nf_stream_t stream) {
+                                 int act, int pad, float* d_res, float* dx, void* scratch, int64_t dy_n_stride,
+                                 const float* d_extra_sub, nf_stream_t stream) {
     NF_REQUIRE(n_img >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad < H && pad < W && act >= 0 && act <= 2 &&
-                   (dy_padded || d_extra),
+                   (dy_padded || d_extra || d_extra_sub),
                "nf_in_act_pad_bwd: bad arguments");
+    if (dy_n_stride == 0) dy_n_stride = (int64_t)C * (H + 2 * pad) * (W + 2 * pad);
     // without a residual input the pre-activation is a function of x alone: its derivative is recomputed, y_padded stays unread
     const bool from_x = gamma && beta && !d_res && act != 0;
-    NF_REQUIRE(from_x || y_padded, "nf_in_act_pad_bwd: y_padded is required (residual input, or no beta given)");
+    NF_REQUIRE(from_x || y_padded || act == 0, "nf_in_act_pad_bwd: y_padded is required (residual input, or no beta given)");
     hipStream_t st = (hipStream_t)stream;
     const int planes = n_img * C, HW = H * W;
     int variant = gamma ? nf_plane_variant(H, W) : 0;
@@ -648,7 +661,7 @@ extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, c
     if (variant) {
 #define NF_PLANE_BWD(NT, EPT, KEEP)                                                                                            \
     hipLaunchKernelGGL((k_plane_bwd<NT, EPT, KEEP>), dim3((unsigned)planes), dim3(NT), 0, st, dy_padded, d_extra, y_padded, x, C, H, W, \
-                       gamma, mean, rstd, act, pad, d_res, dx, from_x ? beta : nullptr)
+                       gamma, mean, rstd, act, pad, d_res, dx, from_x ? beta : nullptr, dy_n_stride, d_extra_sub)
         if (variant == 1) NF_PLANE_BWD(256, 3, true);
         else if (variant == 2) NF_PLANE_BWD(1024, 3, true);
         else NF_PLANE_BWD(1024, 12, false);
@@ -661,7 +674,7 @@ extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, c
     }
     dim3 grid(nf_apply_splits(planes, HW), (unsigned)planes);
     hipLaunchKernelGGL(k_in_act_pad_bwd1, grid, dim3(NF_CNN_BLOCK), 0, st, dy_padded, d_extra, y_padded, x, H, W, mean, rstd,
-                       gamma ? 1 : 0, act, pad, d_res, dx, (double*)scratch, from_x ? 1 : 0, C, gamma, beta);
+                       gamma ? 1 : 0, act, pad, d_res, dx, (double*)scratch, from_x ? 1 : 0, C, gamma, beta, dy_n_stride, d_extra_sub);
     NF_LAUNCH_CHECK("nf_in_act_pad_bwd (fold)");
     if (gamma) {
         hipLaunchKernelGGL(k_in_act_pad_bwd2, grid, dim3(NF_CNN_BLOCK), 0, st, x, C, HW, gamma, mean, rstd, (const double*)scratch,

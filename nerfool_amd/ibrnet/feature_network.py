@@ -155,10 +155,10 @@ class _Slot:
 class _Act:
     """an activation written by the fused kernel: padded storage, gradient w.r.t. the padded tensor (from the next
     convolution) and w.r.t. its interior (residual / skip / upsample consumers)"""
-    __slots__ = ('yp', 'pad', 'gp', 'gi')
+    __slots__ = ('yp', 'pad', 'gp', 'gi', 'gs')
 
     def __init__(self, yp, pad):
-        self.yp, self.pad, self.gp, self.gi = yp, pad, None, None
+        self.yp, self.pad, self.gp, self.gi, self.gs = yp, pad, None, None, None
 
     def interior(self):
         p = self.pad
@@ -169,6 +169,9 @@ class _Act:
 
     def add_i(self, g):
         self.gi = g if self.gi is None else self.gi + g
+
+    def add_s(self, g):          # gradient of a stride-2 consumer of the interior (1x1 downsample): even rows / columns
+        self.gs = g if self.gs is None else self.gs + g
 
 
 def _conv(tape, inp, w, stride, sink, bias=None):
@@ -191,11 +194,11 @@ def _fuse(tape, xs, norm, res, act, pad):
 
     def bwd():
         dx, d_res = ops.in_act_pad_bwd(a.gp, a.gi, yp, xs.v if norm is not None else None, gamma, mean, rstd, act, pad,
-                                       res is not None, beta=beta)
+                                       res is not None, beta=beta, d_extra_sub=a.gs)
         xs.add(dx)
         if res is not None:
             res.add_i(d_res)
-        a.gp = a.gi = None
+        a.gp = a.gi = a.gs = None
     tape.append(bwd)
     return a
 
@@ -207,7 +210,12 @@ def _resblock(tape, blk, xin):
     a1 = _fuse(tape, t1, blk.bn1, None, ops.ACT_RELU, 1)
     t2 = _conv(tape, a1.yp, blk.conv2.weight, 1, a1.add_p)
     if blk.downsample is not None:
-        d = _conv(tape, xin.interior(), blk.downsample[0].weight, stride, xin.add_i)
+        # 1x1 stride-s convolution == 1x1 stride-1 convolution of the subsampled activation: a quarter of the bytes to gather,
+        # and the gradient comes back subsampled (the fused backward adds it at the even positions)
+        if stride == 2:
+            d = _conv(tape, xin.interior()[:, :, ::2, ::2].contiguous(), blk.downsample[0].weight, 1, xin.add_s)
+        else:
+            d = _conv(tape, xin.interior(), blk.downsample[0].weight, stride, xin.add_i)
         res = _fuse(tape, d, blk.downsample[1], None, ops.ACT_NONE, 0)
     else:
         res = xin
@@ -230,18 +238,27 @@ def _upsample_pad(tape, a, pad):
     return up
 
 
-def _join_tape(tape, enc, dec):
-    """cat([dec, zero-pad(enc)], dim=1) with the gradient split back (dec: _Act with pad 0, enc: _Act)."""
+def _join_pad(tape, enc, dec, pad):
+    """reflect_pad(cat([dec, zero-pad(enc)], dim=1), pad) written slice by slice into one buffer (no torch.cat), and the
+    backward folded slice by slice out of the convolution's input gradient (dec: _Act with pad 0, enc: _Act)."""
     e, d = enc.interior(), dec.interior()
     dy, dx = d.shape[2] - e.shape[2], d.shape[3] - e.shape[3]
     top, left = dy // 2, dx // 2
-    out = _Slot(torch.cat([d, F.pad(e, (left, dx - left, top, dy - top))], dim=1))
-    cd, eh, ew = d.shape[1], e.shape[2], e.shape[3]
+    ez = F.pad(e, (left, dx - left, top, dy - top)) if (dy or dx) else e
+    N, cd, H, W = d.shape
+    ce, eh, ew = e.shape[1], e.shape[2], e.shape[3]
+    buf = torch.empty(N, cd + ce, H + 2 * pad, W + 2 * pad, dtype=d.dtype, device=d.device)
+    ops.in_act_pad_fwd(d, None, None, None, ops.ACT_NONE, pad, out=buf, c_off=0)
+    ops.in_act_pad_fwd(ez, None, None, None, ops.ACT_NONE, pad, out=buf, c_off=cd)
+    out = _Act(buf, pad)
 
     def bwd():
-        dec.add_i(out.g[:, :cd].contiguous())
-        enc.add_i(out.g[:, cd:, top:top + eh, left:left + ew].contiguous())
-        out.g = None
+        g = out.gp
+        dd, _ = ops.in_act_pad_bwd(g[:, :cd], None, None, None, None, None, None, ops.ACT_NONE, pad, False, shape=(N, cd, H, W))
+        de, _ = ops.in_act_pad_bwd(g[:, cd:], None, None, None, None, None, None, ops.ACT_NONE, pad, False, shape=(N, ce, H, W))
+        dec.add_i(dd)
+        enc.add_i(de[:, :, top:top + eh, left:left + ew] if (dy or dx) else de)
+        out.gp = None
     tape.append(bwd)
     return out
 
@@ -264,8 +281,7 @@ def fused_forward(net, x):
         up_p = _upsample_pad(tape, src, 1)
         t = _conv(tape, up_p.yp, up.conv.conv.weight, 1, up_p.add_p)
         dec = _fuse(tape, t, up.conv.bn, None, ops.ACT_ELU, 0)
-        j = _join_tape(tape, enc, dec)
-        jp = _fuse(tape, j, None, None, ops.ACT_NONE, 1)
+        jp = _join_pad(tape, enc, dec, 1)
         t = _conv(tape, jp.yp, iconv.conv.weight, 1, jp.add_p)
         return _fuse(tape, t, iconv.bn, None, ops.ACT_ELU, 0)
 

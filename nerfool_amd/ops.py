@@ -331,11 +331,21 @@ def pgd_sign_step_(delta, grad, src, alpha, epsilon, lower=0.0, upper=1.0):
 ACT_NONE, ACT_RELU, ACT_ELU = 0, 1, 2
 
 
-def in_act_pad_fwd(x, gamma, beta, res, act, pad, eps=1e-5):
-    """y_padded = reflect_pad(act(instance_norm(x) * gamma + beta + res), pad); res may be any strided [N,C,H,W] view."""
+def in_act_pad_fwd(x, gamma, beta, res, act, pad, eps=1e-5, out=None, c_off=0):
+    """y_padded = reflect_pad(act(instance_norm(x) * gamma + beta + res), pad); res may be any strided [N,C,H,W] view.
+    out / c_off: write the C planes into channels [c_off, c_off + C) of a preallocated contiguous [N,Ctot,H+2p,W+2p] tensor
+    (concatenation without torch.cat)."""
     x = _c(x, 'x')
     N, C, H, W = x.shape
-    yp = torch.empty(N, C, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=x.device)
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    if out is None:
+        yp = torch.empty(N, C, Hp, Wp, dtype=torch.float32, device=x.device)
+        y_ptr, y_ns = yp.data_ptr(), 0
+    else:
+        if not out.is_contiguous() or tuple(out.shape[2:]) != (Hp, Wp) or out.shape[0] != N or c_off + C > out.shape[1]:
+            raise ValueError('out must be a contiguous [N, Ctot, H+2p, W+2p] tensor holding channels c_off .. c_off+C')
+        yp = out
+        y_ptr, y_ns = out.data_ptr() + 4 * c_off * Hp * Wp, out.shape[1] * Hp * Wp
     mean = rstd = scratch = None
     if gamma is not None:
         mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
@@ -349,25 +359,44 @@ def in_act_pad_fwd(x, gamma, beta, res, act, pad, eps=1e-5):
         rs = res.stride()
     with prof.launch('nf_in_act_pad_fwd', x, n=x.numel()):
         _lib.check(_lib.lib().nf_in_act_pad_fwd(_ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta), float(eps), _ptr(res), rs[0], rs[1],
-                                                rs[2], rs[3], int(act), int(pad), _ptr(yp), _ptr(mean), _ptr(rstd), _ptr(scratch),
-                                                _stream(x)),
+                                                rs[2], rs[3], int(act), int(pad), y_ptr, y_ns, _ptr(mean), _ptr(rstd),
+                                                _ptr(scratch), _stream(x)),
                    'nf_in_act_pad_fwd')
     return yp, mean, rstd
 
 
-def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res, beta=None):
-    N, C, Hp, Wp = yp.shape
-    H, W = Hp - 2 * pad, Wp - 2 * pad
+def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res, beta=None, d_extra_sub=None, shape=None):
+    """dyp may be a channel slice [:, c0:c1] of a contiguous padded tensor (folded in place, no copy); d_extra_sub is the
+    gradient of a stride-2 consumer; shape = (N, C, H, W) of the unpadded output when yp is not given."""
+    if shape is None:
+        N, C, Hp, Wp = yp.shape
+        H, W = Hp - 2 * pad, Wp - 2 * pad
+    else:
+        N, C, H, W = shape
+        Hp, Wp = H + 2 * pad, W + 2 * pad
+    dy_ns = 0
     if dyp is not None:
-        dyp = _c(dyp, 'dy_padded')
+        _f32(dyp, 'dy_padded')
+        if tuple(dyp.shape) != (N, C, Hp, Wp):
+            raise ValueError('dy_padded shape %s does not match %s' % (tuple(dyp.shape), (N, C, Hp, Wp)))
+        if dyp.stride()[1:] == (Hp * Wp, Wp, 1) and (N == 1 or dyp.stride(0) >= C * Hp * Wp):
+            dy_ns = dyp.stride(0)
+        else:
+            dyp = dyp.contiguous()
     if d_extra is not None:
         d_extra = _c(d_extra, 'd_extra')
-    dx = torch.empty(N, C, H, W, dtype=torch.float32, device=yp.device)
+    if d_extra_sub is not None:
+        d_extra_sub = _c(d_extra_sub, 'd_extra_sub')
+        if tuple(d_extra_sub.shape) != (N, C, (H + 1) // 2, (W + 1) // 2):
+            raise ValueError('d_extra_sub shape %s' % (tuple(d_extra_sub.shape),))
+    ref = dyp if dyp is not None else (d_extra if d_extra is not None else d_extra_sub)
+    dx = torch.empty(N, C, H, W, dtype=torch.float32, device=ref.device)
     d_res = torch.empty_like(dx) if want_d_res else None
-    scratch = torch.empty(N * C * 64, dtype=torch.float64, device=yp.device) if gamma is not None else None
-    with prof.launch('nf_in_act_pad_bwd', yp, n=dx.numel()):
-        _lib.check(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta), _ptr(mean),
-                                                _ptr(rstd), int(act), int(pad), _ptr(d_res), _ptr(dx), _ptr(scratch), _stream(yp)),
+    scratch = torch.empty(N * C * 64, dtype=torch.float64, device=ref.device) if gamma is not None else None
+    with prof.launch('nf_in_act_pad_bwd', ref, n=dx.numel()):
+        _lib.check(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta),
+                                                _ptr(mean), _ptr(rstd), int(act), int(pad), _ptr(d_res), _ptr(dx), _ptr(scratch),
+                                                dy_ns, _ptr(d_extra_sub), _stream(ref)),
                    'nf_in_act_pad_bwd')
     return dx, d_res
 

@@ -361,6 +361,35 @@ def check_fused_cnn_glue(dev):
         assert_close(dx, grads[0], 1e-3, 1e-4 * float(grads[0].abs().max()), 'fused glue d x')
         if use_res:
             assert_close(d_res, grads[1], 1e-4, 1e-5, 'fused glue d residual')
+    # skip concatenation written / folded slice by slice, and the subsampled gradient of a stride-2 consumer
+    N, C1, C2, H, W, pad = 2, 3, 2, 7, 10, 1
+    a_, b_ = torch.randn(N, C1, H, W, generator=gen), torch.randn(N, C2, H, W, generator=gen)
+    cat = torch.cat([a_, b_], 1).requires_grad_(True)
+    ref = F.pad(cat, (pad,) * 4, mode='reflect')
+    buf = torch.empty(N, C1 + C2, H + 2 * pad, W + 2 * pad).to(dev)
+    ops.in_act_pad_fwd(a_.to(dev), None, None, None, ops.ACT_NONE, pad, out=buf, c_off=0)
+    ops.in_act_pad_fwd(b_.to(dev), None, None, None, ops.ACT_NONE, pad, out=buf, c_off=C1)
+    assert_close(buf, ref, 1e-6, 1e-6, 'concatenation by slices')
+    g = torch.randn(ref.shape, generator=gen)
+    gcat, = torch.autograd.grad(ref, cat, g)
+    gd = g.to(dev)
+    da, _ = ops.in_act_pad_bwd(gd[:, :C1], None, None, None, None, None, None, ops.ACT_NONE, pad, False, shape=(N, C1, H, W))
+    db, _ = ops.in_act_pad_bwd(gd[:, C1:], None, None, None, None, None, None, ops.ACT_NONE, pad, False, shape=(N, C2, H, W))
+    assert_close(da, gcat[:, :C1], 1e-5, 1e-5, 'fold of a channel slice (first)')
+    assert_close(db, gcat[:, C1:], 1e-5, 1e-5, 'fold of a channel slice (second)')
+    for (H, W) in ((7, 10), (8, 9)):
+        x = torch.randn(N, C1, H, W, generator=gen)
+        gamma, beta = 1 + 0.3 * torch.randn(C1, generator=gen), 0.2 * torch.randn(C1, generator=gen)
+        xr = x.clone().requires_grad_(True)
+        t = F.relu(F.instance_norm(xr, weight=gamma, bias=beta, eps=1e-5))
+        ref_y = F.pad(t, (1,) * 4, mode='reflect')
+        dyp = torch.randn(ref_y.shape, generator=gen)
+        dsub = torch.randn(N, C1, (H + 1) // 2, (W + 1) // 2, generator=gen)
+        gx, = torch.autograd.grad([ref_y, t[:, :, ::2, ::2]], [xr], [dyp, dsub])
+        yp, mean, rstd = ops.in_act_pad_fwd(x.to(dev), gamma.to(dev), beta.to(dev), None, ops.ACT_RELU, 1)
+        dx, _ = ops.in_act_pad_bwd(dyp.to(dev), None, yp, x.to(dev), gamma.to(dev), mean, rstd, ops.ACT_RELU, 1, False,
+                                   d_extra_sub=dsub.to(dev))
+        assert_close(dx, gx, 1e-3, 1e-4 * float(gx.abs().max()), 'gradient of a stride-2 consumer')
     # decoder: x2 bilinear upsampling (align_corners) fused with the reflect padding, from contiguous and strided sources
     for (N, C, h, w, pad, strided) in ((2, 3, 5, 7, 1, False), (1, 4, 6, 4, 1, True), (1, 2, 1, 3, 0, False)):
         store = torch.randn(N, C, h + 2, w + 2, generator=gen)
