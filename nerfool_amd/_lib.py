@@ -9,6 +9,10 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
 
+# torch first: it ships its own libamdhip64 / libhsa-runtime64, and the library below must bind to THAT runtime (same SONAME:
+# whichever is loaded first serves both).  Loading the system runtime first leaves torch without a visible device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libnerfool_hip.so')
 ABI_VERSION = 1
