@@ -240,7 +240,7 @@ def main():
             elif name == 'nf_project_gather_bwd':
                 b = meta['n_pts'] * meta['V'] * ((3 + meta['C']) * 4 + 4 * meta['C'] * 4)
                 per_launch.append(('hbm', b / (ms * 1e-3) / 1e9))
-            elif name in ('nf_gnt_fwd', 'nf_gnt_fwd_mfma', 'nf_gnt_bwd'):
+            elif name in ('nf_gnt_fwd', 'nf_gnt_fwd_mfma', 'nf_gnt_bwd', 'nf_gnt_bwd_mfma'):
                 fl = 2.0 * meta['R'] * meta['S'] * (meta['V'] * (6336 + meta['depth'] * 9760)
                                                     + meta['depth'] * 98304 + ((meta['depth'] + 1) // 2) * 16256)
                 per_launch.append(('mfma', fl / (ms * 1e-3) / 1e12))

@@ -200,6 +200,8 @@ int nf_gnt_mfma_supported(int n_samples, int n_views);
 int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
                     const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
                     float* workspace, nf_stream_t stream);
+int nf_gnt_bwd_mfma(const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples, int n_views,
+                    int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a14 (glue only)  ResUNet: InstanceNorm + affine + residual + ReLU/ELU + reflect padding fused into one pass over a

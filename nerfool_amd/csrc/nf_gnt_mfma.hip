@@ -48,9 +48,22 @@ enum { MF_LNW = 0, MF_LNB = 64, MF_W = 128, MF_B = 320, GM_FINAL_FLOATS = 324 };
 
 NF_HD inline int64_t gm_layer_base(int i) { return GM_STEM_FLOATS + (int64_t)i * GM_LAYER_FLOATS; }
 
-extern "C" int64_t nf_gnt_mfma_blob_floats(int depth) {
-    return GM_STEM_FLOATS + (int64_t)depth * GM_LAYER_FLOATS + GM_FINAL_FLOATS + GM_BLOB_PAD;
-}
+// ---- backward section (behind the forward section): transposed records (dX^T = W^T dY^T) in the order the backward
+//      consumes them, layers stored in forward order but walked from the last to the first
+enum {
+    BG_ATT0T = 0, BG_STREAM = 16,      // 8 records of attn_fc.0^T (64 <- 8), then the stream (units: records)
+    BS_RFF = 0, BS_ROUT = 512, BS_RQ = 576, BS_RK = 640, BS_RV = 704, BS_Q2 = 768, BS_Q0 = 832, BS_VFF = 896, BS_VOUT = 1408,
+    BS_VIEW = 1472,                    // attn_fc.2^T (8 <- 64: one tile), v_fc^T, k_fc^T = 32 + 64 + 64 records
+    BS_VQ = 1632, BS_END = 1696,
+    BG_LAYER_RECORDS = BG_STREAM + BS_END,
+    BSTEM_RECORDS = 128                // rgbfeat_fc.2^T (64 <- 64), rgbfeat_fc.0^T (35 <- 64: two tiles)
+};
+static constexpr int64_t GM_BWD_LAYER_FLOATS = (int64_t)BG_LAYER_RECORDS * 64;
+NF_HD inline int64_t gm_fwd_floats(int depth) { return GM_STEM_FLOATS + (int64_t)depth * GM_LAYER_FLOATS + GM_FINAL_FLOATS + GM_BLOB_PAD; }
+NF_HD inline int64_t gm_bwd_layer_base(int depth, int i) { return gm_fwd_floats(depth) + (int64_t)i * GM_BWD_LAYER_FLOATS; }
+NF_HD inline int64_t gm_bwd_stem_base(int depth) { return gm_bwd_layer_base(depth, depth); }
+
+extern "C" int64_t nf_gnt_mfma_blob_floats(int depth) { return gm_bwd_stem_base(depth) + BSTEM_RECORDS * 64 + GM_BLOB_PAD; }
 
 extern "C" int nf_gnt_mfma_supported(int n_samples, int n_views) {
     return n_samples >= 32 && n_samples <= 128 && n_samples % 32 == 0 && n_views >= 1 && n_views <= 64;
@@ -172,6 +185,49 @@ extern "C" int nf_gnt_pack_mfma(int depth, const float* nat, float* out) {
         gm_vec_tiles(fo + MF_LNB, F + 64, 64);
         for (int c = 0; c < 3; ++c) gm_vec_tiles(fo + MF_W + c * 64, F + 320 + c * 64, 64);      // native W [3][64]
         for (int c = 0; c < 3; ++c) fo[MF_B + c] = F[512 + c];
+    }
+    // ================= backward section: M = W^T, i.e. the blob's [in][out] arrays =================
+    for (int i = 0; i < depth; ++i) {
+        const float* L = nat + gnt_layer_base(i);
+        float* base = out + gm_bwd_layer_base(depth, i);
+        float* rec = base;
+        for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_wt(GV_ATT0), 64, 8, nt, 0, 4);
+        rec = base + BG_STREAM * 64;
+        float* st0 = rec;
+        for (int pass = 0; pass < 2; ++pass) {      // ray FF first (the backward walks a layer from its end), then view FF
+            const int l1 = pass == 0 ? GR_FF1 : GV_FF1, l2 = pass == 0 ? GR_FF2 : GV_FF2;
+            if (rec - st0 != (pass == 0 ? BS_RFF : BS_VFF) * 64) return 6;
+            for (int j = 0; j < 8; ++j) {
+                gm_frag(rec, L + gnt_wt(l2), 256, 64, j, 0, 16);       // d hidden tile j  <- d out (64)
+                gm_frag(rec, L + gnt_wt(l2), 256, 64, j, 32, 16);
+                for (int nt = 0; nt < 2; ++nt) gm_frag(rec, L + gnt_wt(l1), 64, 256, nt, 32 * j, 16);      // d y += W1^T d hidden_j
+            }
+            if (pass == 0) {
+                gm_lin64(rec, L + gnt_wt(GR_OUT), 64, 64);
+                gm_lin64(rec, L + gnt_wt(GR_Q), 64, 64);
+                gm_lin64(rec, L + gnt_wt(GR_K), 64, 64);
+                gm_lin64(rec, L + gnt_wt(GR_V), 64, 64);
+                if ((i & 1) == 0) {
+                    gm_lin64(rec, L + gnt_wt(GQ_2), 64, 64);
+                    gm_lin64(rec, L + gnt_wt(GQ_0), 64, 64);           // rows 0..63 of the [190][64] array: d of the 64 current features
+                } else {
+                    rec += 128 * 64;
+                }
+            } else {
+                gm_lin64(rec, L + gnt_wt(GV_OUT), 64, 64);
+                gm_lin64(rec, L + gnt_wt(GV_ATT2), 8, 64);
+                gm_lin64(rec, L + gnt_wt(GV_V), 64, 64);
+                gm_lin64(rec, L + gnt_wt(GV_K), 64, 64);
+                gm_lin64(rec, L + gnt_wt(GV_Q), 64, 64);
+            }
+        }
+        if (rec - st0 != BS_END * 64) return 7;
+    }
+    {
+        float* rec = out + gm_bwd_stem_base(depth);
+        gm_lin64(rec, nat + GNT_STEM1, 64, 64);                        // rgbfeat_fc.2 [in][out]
+        gm_lin64(rec, nat, 35, 64);                                    // rgbfeat_fc.0 [in = 35][out = 64]: two output tiles
+        if (rec - (out + gm_bwd_stem_base(depth)) != BSTEM_RECORDS * 64) return 8;
     }
     return 0;
 }
@@ -696,6 +752,337 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// backward on the matrix cores: d rgb [R,3] -> d rgb_feat [R,S,V,35], from the activations a forward with save != 0 left in
+// the workspace.  Same decomposition as the forward (one workgroup per ray, one wave per 32 samples, register-chained
+// transposed GEMMs dX^T = W^T dY^T, weight stream).  The ray attention is differentiated head by head with seven record
+// sets in LDS: scores are formed in BOTH orientations -- keys on rows (lane = query) for dQ, queries on rows (lane = key)
+// for dK / dV -- so that every contraction runs over MFMA rows and no cross-lane reduction is needed.
+// Follows oracle/gnt_manual_bwd.py and k_gnt_bwd (nf_gnt.hip), which stays the reference implementation for other shapes.
+// ---------------------------------------------------------------------------------------------------------------
+// 64 -> 64 transposed linear through the stream; jump (nullable) redirects the stream behind this GEMM
+__device__ __forceinline__ V64 gm_lin64_sj(GmW& w, int lane, const V64& x, const V64* init, const float* jump) {
+    V64 y;
+    y.t[0] = gm_tile_s(w, lane, x, init ? init->t[0] : gm_zero());
+    if (jump) w.p = jump;
+    y.t[1] = gm_tile_s(w, lane, x, init ? init->t[1] : gm_zero());
+    return y;
+}
+
+// LayerNorm backward: returns rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dy w   (w in fragment order)
+__device__ __forceinline__ V64 gm_ln_bwd(const GmCtx& c, const V64& dy, const float* __restrict__ w, int xh_slot, int rstd_slot) {
+    const V64 xh = gm_load_smp(c, xh_slot);
+    const float rstd = gm_smp_at(c, rstd_slot)[c.s];
+    V64 dxh;
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dxh.t[t][r] = dy.t[t][r] * w[t * 32 + c.h * 16 + r];
+            m1 += dxh.t[t][r];
+            m2 += dxh.t[t][r] * xh.t[t][r];
+        }
+    m1 = gm_half_sum(m1) / 64.f;
+    m2 = gm_half_sum(m2) / 64.f;
+    V64 o;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o.t[t][r] = rstd * (dxh.t[t][r] - m1 - xh.t[t][r] * m2);
+    return o;
+}
+
+// feed-forward backward: d(FF input y) = W1^T (relu'(F) . W2^T d out); F read from f_slot; stream: 8 x [fc2^T tile j | fc1^T k-tile j]
+__device__ __forceinline__ V64 gm_ff_bwd(const GmCtx& c, GmW& w, int lane, const V64& dout, int f_slot) {
+    V64 dy;
+    dy.t[0] = dy.t[1] = gm_zero();
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+        g16 df = gm_tile_s(w, lane, dout, gm_zero());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) df[r] = gm_smp_at(c, f_slot + 32 * j + gm_nidx(r, 0))[c.smp_lane] > 0.f ? df[r] : 0.f;
+        dy.t[0] = gm_take_a(w, lane, df, dy.t[0]);
+        dy.t[1] = gm_take_b(w, lane, df, dy.t[1]);
+    }
+    return dy;
+}
+
+template <int NW> struct GmBwdLds {
+    static constexpr int REC = NW * 8 * 64;                    // rows x dims record set (K, V, Q, dO)
+    static constexpr int TREC = NW * 16 * GM_VT_STRIDE;        // dims x rows record set (K^T, Q^T, dO^T)
+    static constexpr int SCAL = 32 * NW;                       // per-query scalars (max, 1 / sum, D)
+    static constexpr int FLOATS = 4 * REC + 3 * TREC + 3 * SCAL;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restrict__ wb, const float* __restrict__ mask_all,
+                                                          const float* __restrict__ d_rgb, int V, int depth,
+                                                          float* __restrict__ d_rgb_feat, float* __restrict__ ws,
+                                                          int64_t row_floats, int64_t smp_floats) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    constexpr int S = 32 * NW;
+    float* Kr = lds;
+    float* Vr = Kr + GmBwdLds<NW>::REC;
+    float* Qr = Vr + GmBwdLds<NW>::REC;
+    float* Gr = Qr + GmBwdLds<NW>::REC;
+    float* Kt = Gr + GmBwdLds<NW>::REC;
+    float* Qt = Kt + GmBwdLds<NW>::TREC;
+    float* Gt = Qt + GmBwdLds<NW>::TREC;
+    float* Ms = Gt + GmBwdLds<NW>::TREC;
+    float* Ls = Ms + GmBwdLds<NW>::SCAL;
+    float* Ds = Ls + GmBwdLds<NW>::SCAL;
+    const int64_t ray = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    GmCtx c;
+    c.S = S; c.V = V; c.s = wave * 32 + m; c.h = h;
+    c.smp_lane = (unsigned)(4 * h * S + c.s);
+    c.row_lane = (unsigned)(4 * h * V * S + c.s);
+    const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;
+    c.ws_row = ws + ray * per_ray;
+    c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
+    const float* mask = mask_all + ray * S * V;
+
+    // ---- rgb_fc, mean over the samples, final LayerNorm
+    V64 dcur;
+    {
+        const float* F = wb + gm_layer_base(depth);
+        const float* g = d_rgb + ray * 3;
+        V64 dm;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int at = t * 32 + h * 16 + r;
+                dm.t[t][r] = (F[MF_W + at] * g[0] + F[MF_W + 64 + at] * g[1] + F[MF_W + 128 + at] * g[2]) / (float)S;
+            }
+        dcur = gm_ln_bwd(c, dm, F + MF_LNW, SW_XHF, SW_RSTDF);
+    }
+    // d X_v accumulators start at zero
+    {
+        V64 z;
+        z.t[0] = z.t[1] = gm_zero();
+        for (int v = 0; v < V; ++v) gm_store_row(c, RW_DX, v, z);
+    }
+    GmW w;
+    gm_w_start(w, wb + gm_bwd_layer_base(depth, depth - 1) + BG_STREAM * 64, lane);
+    for (int i = depth - 1; i >= 0; --i) {
+        const float* Lf = wb + gm_layer_base(i);
+        const float* tb = Lf + (size_t)MG_LAYER_RECORDS * 64;                       // forward tables (LayerNorm weights)
+        const float* Bl = wb + gm_bwd_layer_base(depth, i);
+        const float* Bst = Bl + BG_STREAM * 64;
+        const float* after = i > 0 ? wb + gm_bwd_layer_base(depth, i - 1) + BG_STREAM * 64 : wb + gm_bwd_stem_base(depth);
+        const int ls = SW_BASE + i * SW_LAYER;
+        const int lr = RW_BASE + i * RW_LAYER;
+        // ================= ray transformer backward =================
+        {
+            const V64 dy = gm_ff_bwd(c, w, lane, dcur, ls + SL_F2);
+            const V64 dl = gm_ln_bwd(c, dy, tb + MB_LN + 384, ls + SL_RXH2, ls + SL_RRSTD2);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
+        }
+        V64 dq, dk, dv;
+        {
+            const V64 go = gm_lin64_sj(w, lane, dcur, nullptr, nullptr);            // d (attention output)
+            const int rk = ((m & 3) | ((m >> 3) << 2)), hk = (m >> 2) & 1;          // inverse of n(r, hh) for sample m
+#pragma unroll
+            for (int hd = 0; hd < 4; ++hd) {
+                const int tt = hd >> 1, r0 = 8 * (hd & 1);
+                // ---- this wave's 32 samples -> the seven record sets of head hd, and the per-query scalars; the head's 16
+                //      dims of q, k, v are re-read from the workspace (features 16 hd + n(j, h)) instead of being held
+                float qh[8], kh[8], vh[8];
+                float D = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f0 = 16 * hd + gm_nidx(j, 0);
+                    qh[j] = gm_smp_at(c, ls + SL_QH + f0)[c.smp_lane] * 0.25f;
+                    kh[j] = gm_smp_at(c, ls + SL_KH + f0)[c.smp_lane];
+                    vh[j] = gm_smp_at(c, ls + SL_VH + f0)[c.smp_lane];
+                    const float gv = go.t[tt][r0 + j];
+                    const int ar = (wave * 8 + j) * 64 + lane;
+                    const int at = (wave * 16 + rk) * GM_VT_STRIDE + gm_nidx(j, h) + 32 * hk;
+                    Kr[ar] = kh[j];
+                    Vr[ar] = vh[j];
+                    Qr[ar] = qh[j];
+                    Gr[ar] = gv;
+                    Kt[at] = kh[j];
+                    Qt[at] = qh[j];
+                    Gt[at] = gv;
+                    D = fmaf(gv, gm_smp_at(c, ls + SL_OUTA + f0)[c.smp_lane], D);
+                }
+                D = gm_half_sum(D);
+                const float mxq = gm_smp_at(c, ls + SL_ML + hd)[c.s], rlq = 1.f / gm_smp_at(c, ls + SL_ML + 4 + hd)[c.s];
+                if (h == 0) {
+                    Ms[c.s] = mxq;
+                    Ls[c.s] = rlq;
+                    Ds[c.s] = D;
+                }
+                __syncthreads();
+                // ---- orientation A: keys on rows, lane = query (own sample) -> dQ
+                g16 dqa = gm_zero();
+#pragma unroll 1
+                for (int kt = 0; kt < NW; ++kt) {
+                    g16 sT = gm_zero(), dPT = gm_zero();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        sT = GM_MFMA(Kr[(kt * 8 + j) * 64 + lane], qh[j], sT);
+                        dPT = GM_MFMA(Vr[(kt * 8 + j) * 64 + lane], go.t[tt][r0 + j], dPT);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pT = __expf(sT[r] - mxq) * rlq;
+                        sT[r] = pT * (dPT[r] - D);                              // d S^T
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float av = (lane & 31) < 16 ? Kt[(kt * 16 + r) * GM_VT_STRIDE + (lane & 31) + 32 * h] : 0.f;
+                        dqa = GM_MFMA(av, sT[r], dqa);
+                    }
+                }
+                // ---- orientation B: queries on rows, lane = key (own sample) -> dK, dV
+                g16 dka = gm_zero(), dva = gm_zero();
+#pragma unroll 1
+                for (int qt = 0; qt < NW; ++qt) {
+                    g16 sc = gm_zero(), dP = gm_zero();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        sc = GM_MFMA(Qr[(qt * 8 + j) * 64 + lane], kh[j], sc);
+                        dP = GM_MFMA(Gr[(qt * 8 + j) * 64 + lane], vh[j], dP);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int qi = qt * 32 + gm_nidx(r, h);
+                        const float pr = __expf(sc[r] - Ms[qi]) * Ls[qi];
+                        dP[r] = pr * (dP[r] - Ds[qi]);                          // d S
+                        sc[r] = pr;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool on = (lane & 31) < 16;
+                        const int at = (qt * 16 + r) * GM_VT_STRIDE + (lane & 31) + 32 * h;
+                        dka = GM_MFMA(on ? Qt[at] : 0.f, dP[r], dka);
+                        dva = GM_MFMA(on ? Gt[at] : 0.f, sc[r], dva);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dq.t[tt][r0 + j] = dqa[j] * 0.25f;
+                    dk.t[tt][r0 + j] = dka[j];
+                    dv.t[tt][r0 + j] = dva[j];
+                }
+                __syncthreads();
+            }
+        }
+        {
+            V64 dx = gm_lin64_sj(w, lane, dq, nullptr, nullptr);
+            dx = gm_lin64_sj(w, lane, dk, &dx, nullptr);
+            dx = gm_lin64_sj(w, lane, dv, &dx, (i & 1) ? Bst + BS_VFF * 64 : nullptr);      // odd layers: no positional MLP records
+            const V64 dl = gm_ln_bwd(c, dx, tb + MB_LN + 256, ls + SL_RXH1, ls + SL_RRSTD1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
+        }
+        // ================= positional MLP backward (even layers): q = W2 relu(W0 [q | pe] + b0) + b2, no residual =================
+        if ((i & 1) == 0) {
+            V64 dg = gm_lin64_sj(w, lane, dcur, nullptr, nullptr);
+            const V64 gsv = gm_load_smp(c, ls + SL_G);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dg.t[t][r] = gsv.t[t][r] > 0.f ? dg.t[t][r] : 0.f;
+            dcur = gm_lin64_sj(w, lane, dg, nullptr, nullptr);
+        }
+        // ================= view transformer backward =================
+        {
+            const V64 dy = gm_ff_bwd(c, w, lane, dcur, ls + SL_F);
+            const V64 dl = gm_ln_bwd(c, dy, tb + MB_LN + 128, ls + SL_XH2, ls + SL_RSTD2);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
+        }
+        {
+            const V64 du = gm_lin64_sj(w, lane, dcur, nullptr, nullptr);
+            V64 sp, dqs;
+            sp.t[0] = sp.t[1] = dqs.t[0] = dqs.t[1] = gm_zero();
+            for (int v = 0; v < V; ++v) {
+                const V64 pr = gm_load_row(c, lr + RWL_PROB, v), vp = gm_load_row(c, lr + RWL_VP, v);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sp.t[t][r] = fmaf(pr.t[t][r] * vp.t[t][r], du.t[t][r], sp.t[t][r]);
+            }
+            for (int v = 0; v < V; ++v) {
+                const float* Bs = Bst;
+                const float* Bsmall = Bl;
+                GM_LAUNDER(Bs);
+                GM_LAUNDER(Bsmall);
+                const float mk = mask[(size_t)c.s * V + v];
+                V64 dlg, dvv;
+                {
+                    const V64 pr = gm_load_row(c, lr + RWL_PROB, v), vp = gm_load_row(c, lr + RWL_VP, v);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            dlg.t[t][r] = mk == 0.f ? 0.f : pr.t[t][r] * (vp.t[t][r] * du.t[t][r] - sp.t[t][r]);
+                            dvv.t[t][r] = pr.t[t][r] * du.t[t][r];
+                        }
+                }
+                g16 dh = gm_tile_s(w, lane, dlg, gm_zero());                       // attn_fc.2^T: 8 <- 64
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dh[r] = gm_row_at(c, lr + RWL_H + r, v)[c.row_lane] > 0.f ? dh[r] : 0.f;
+                V64 da;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    da.t[t] = gm_gemm<4>(Bsmall + (BG_ATT0T + 4 * t) * 64, lane, dh, gm_zero());      // attn_fc.0^T: 64 <- 8
+                    dqs.t[t] += da.t[t];
+                }
+                const V64 dK = gm_lin64_sj(w, lane, dvv, &da, nullptr);            // d K = d a + Wv^T d Vv
+                const V64 acc = gm_load_row(c, RW_DX, v);
+                const V64 dxv = gm_lin64_sj(w, lane, dK, &acc, v + 1 < V ? Bs + BS_VIEW * 64 : nullptr);      // d X_v += Wk^T d K
+                gm_store_row(c, RW_DX, v, dxv);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dqs.t[t][r] = -dqs.t[t][r];          // d Q = - sum_v d a_v
+            const V64 dx = gm_lin64_sj(w, lane, dqs, nullptr, after);
+            const V64 dl = gm_ln_bwd(c, dx, tb + MB_LN, ls + SL_XH1, ls + SL_RSTD1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
+        }
+    }
+    // ---- q0 = max over the views routes its gradient to the arg-max view of every channel; then the stem
+    {
+        const V64 am = gm_load_smp(c, SW_AMAX);
+        const float* St = wb + gm_bwd_stem_base(depth);
+        for (int v = 0; v < V; ++v) {
+            const float* Sv = St;
+            GM_LAUNDER(Sv);
+            V64 dxv = gm_load_row(c, RW_DX, v);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((int)am.t[t][r] == v) dxv.t[t][r] += dcur.t[t][r];
+            V64 dr = gm_lin64_sj(w, lane, dxv, nullptr, nullptr);                  // rgbfeat_fc.2^T
+            const V64 r1 = gm_load_row(c, RW_R1, v);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dr.t[t][r] = r1.t[t][r] > 0.f ? dr.t[t][r] : 0.f;
+            const V64 df = gm_lin64_sj(w, lane, dr, nullptr, v + 1 < V ? Sv : nullptr);      // rgbfeat_fc.0^T: 35 <- 64
+            float* o = d_rgb_feat + ((ray * S + c.s) * V + v) * 35;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[gm_nidx(r, h)] = df.t[0][r];
+            if (h == 0) {
+                o[32] = df.t[1][0];
+                o[33] = df.t[1][1];
+                o[34] = df.t[1][2];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
 template <int NW>
@@ -738,5 +1125,38 @@ extern "C" int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, co
         case 2: return gm_launch<2>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
         case 3: return gm_launch<3>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
         default: return gm_launch<4>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
+    }
+}
+
+template <int NW>
+static int gm_launch_bwd(const float* mblob, const float* mask, const float* d_rgb, int64_t n_rays, int V, int depth,
+                         float* d_rgb_feat, float* workspace, hipStream_t st) {
+    static bool configured = false;
+    const size_t smem = GmBwdLds<NW>::FLOATS * sizeof(float);
+    if (!configured && smem > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)k_gnt_bwd_mfma<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            nf_set_error("nf_gnt_bwd_mfma: cannot reserve %zu bytes of LDS", smem);
+            return 1;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_gnt_bwd_mfma<NW>, dim3((unsigned)n_rays), dim3(64 * NW), smem, st, mblob, mask, d_rgb, V, depth, d_rgb_feat,
+                       workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1));
+    NF_LAUNCH_CHECK("nf_gnt_bwd_mfma");
+    return 0;
+}
+
+/* Same contract as nf_gnt_bwd: `workspace` is the buffer a forward (either one) with save != 0 filled. */
+extern "C" int nf_gnt_bwd_mfma(const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
+                               int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream) {
+    NF_REQUIRE(nf_gnt_mfma_supported(n_samples, n_views) && depth >= 1 && depth <= 16 && n_rays >= 0,
+               "nf_gnt_bwd_mfma: S must be 32, 64, 96 or 128 and 1 <= V <= 64 (got S %d V %d depth %d)", n_samples, n_views, depth);
+    if (n_rays == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_samples / 32) {
+        case 1: return gm_launch_bwd<1>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, st);
+        case 2: return gm_launch_bwd<2>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, st);
+        case 3: return gm_launch_bwd<3>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, st);
+        default: return gm_launch_bwd<4>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, st);
     }
 }

@@ -61,16 +61,20 @@ class _GNTFunction(torch.autograd.Function):
         ctx.depth = depth
         ctx.shape = tuple(rgb_feat.shape[:3])
         ctx.have_ws = ws is not None
+        ctx.use_mfma = mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])
         if ws is not None:
-            ctx.save_for_backward(ray_diff, mask, blob, ws)
+            ctx.save_for_backward(ray_diff, mask, blob, ws, mfma_blob if ctx.use_mfma else None)
         return rgb
 
     @staticmethod
     def backward(ctx, d_rgb):
         if not ctx.have_ws:
             raise RuntimeError('GNT forward ran without saved activations (input did not require grad)')
-        ray_diff, mask, blob, ws = ctx.saved_tensors
-        d_rgb_feat = ops.gnt_bwd(blob, ray_diff, mask, d_rgb, ws, ctx.shape, ctx.depth)
+        ray_diff, mask, blob, ws, mfma_blob = ctx.saved_tensors
+        if ctx.use_mfma:
+            d_rgb_feat = ops.gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, ctx.shape, ctx.depth)
+        else:
+            d_rgb_feat = ops.gnt_bwd(blob, ray_diff, mask, d_rgb, ws, ctx.shape, ctx.depth)
         return d_rgb_feat, None, None, None, None, None, None, None
 
 

@@ -481,6 +481,16 @@ def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save):
     return rgb, (ws if save else None)
 
 
+def gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, shape, depth):
+    R, S, V = shape
+    mask, d_rgb = _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
+    d_rgb_feat = torch.empty(R, S, V, 35, dtype=torch.float32, device=d_rgb.device)
+    with prof.launch('nf_gnt_bwd_mfma', d_rgb, R=R, S=S, V=V, depth=depth):
+        _lib.check(_lib.lib().nf_gnt_bwd_mfma(_ptr(mfma_blob), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat), _ptr(ws),
+                                              _stream(d_rgb)), 'nf_gnt_bwd_mfma')
+    return d_rgb_feat
+
+
 def gnt_bwd(blob, ray_diff, mask, d_rgb, ws, shape, depth):
     R, S, V = shape
     ray_diff, mask, d_rgb = _c(ray_diff, 'ray_diff'), _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
