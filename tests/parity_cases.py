@@ -294,6 +294,25 @@ def check_render_single_image(dev, rows=None):
         assert abs(ib.mse2psnr(mse) - float(g.np('image/psnr_fine'))) < 1e-2, 'PSNR'
 
 
+def check_evaluate_view(dev):
+    """eval_views.evaluate_view (the evaluation loop of eval.py / eval_adv.py:861-905) on the attack fixture: adversarial
+    render with the reference's final delta -> the reference's fine PSNR; delta = 0 equals the clean render."""
+    from nerfool_amd import eval_views as ev
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    n_adam = dims[6]
+    model.switch_to_eval = lambda: None
+    args.white_bkgd = False
+    m = ev.evaluate_view(args, model, Projector(dev), data, delta=g.t('adam/delta_%d' % n_adam, dev), device=dev)
+    fine = m['ret']['outputs_fine']['rgb']
+    mse = float(torch.mean((fine - g.t('in/rgb')[0]) ** 2))          # the reference's own (unclipped, +1e-6) figure
+    assert abs(ib.mse2psnr(mse) - float(g.np('image/psnr_fine'))) < 1e-2, 'PSNR of the adversarial render'
+    assert abs(m['fine_psnr'] - ev.psnr(fine.clamp(0, 1), g.t('in/rgb')[0])) < 1e-9
+    assert -1.0 <= m['fine_ssim'] <= 1.0 and -1.0 <= m['coarse_ssim'] <= 1.0      # random-weight renders: any sign
+    clean = ev.evaluate_view(args, model, Projector(dev), data, device=dev)
+    zero = ev.evaluate_view(args, model, Projector(dev), data, delta=torch.zeros_like(g.t('in/delta0', dev)), device=dev)
+    assert abs(clean['fine_psnr'] - zero['fine_psnr']) < 1e-6
+
+
 def check_hybrid_and_sample_pdf(dev):
     """render_rays_hybrid (clean colour / clean density) and the stand-alone sample_pdf against the reference."""
     from nerfool_amd.synthetic import smooth_featmaps

@@ -196,3 +196,7 @@ def test_full_size_properties():
 @pytest.mark.parametrize('shape', [(3, 32, 4, 2), (2, 64, 10, 3), (2, 96, 3, 2), (2, 128, 5, 2)])
 def test_gnt_matrix_core_forward_matches_generic(shape):
     pc.check_gnt_mfma_vs_generic('cuda', shapes=(shape,))
+
+
+def test_evaluate_view_metrics():
+    pc.check_evaluate_view('cuda')
