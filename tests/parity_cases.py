@@ -310,7 +310,7 @@ def check_evaluate_view(dev):
     assert -1.0 <= m['fine_ssim'] <= 1.0 and -1.0 <= m['coarse_ssim'] <= 1.0      # random-weight renders: any sign
     clean = ev.evaluate_view(args, model, Projector(dev), data, device=dev)
     zero = ev.evaluate_view(args, model, Projector(dev), data, delta=torch.zeros_like(g.t('in/delta0', dev)), device=dev)
-    assert abs(clean['fine_psnr'] - zero['fine_psnr']) < 1e-6
+    assert abs(clean['fine_psnr'] - zero['fine_psnr']) < 1e-3, (clean['fine_psnr'], zero['fine_psnr'])
 
 
 def check_hybrid_and_sample_pdf(dev):
