@@ -179,7 +179,8 @@ int nf_pgd_sign_step(float* delta, const float* grad, const float* src, int64_t 
  * a15  GNT.forward (ret_alpha = False, eval mode)      ref: gnt/transformer_network.py:270-309 (+ :55-89, :93-113,
  * :121-171, :175-202).  Parameters as one blob whose layout nf_gnt_blob_entry enumerates (HOST; an empty name marks a
  * slot without parameters, e.g. q_fcs on odd layers).  rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V],
- * pts [R,S,3], ray_d [R,3] -> rgb [R,3].  save != 0 keeps all activations in `workspace`
+ * pts [R,S,3], ray_d [R,3] -> rgb [R,3]; alpha (nullable, [R,S]): the `ret_alpha` output, the attention row of the first
+ * sample in the last ray transformer averaged over the heads (:196-200, :303-309).  save != 0 keeps all activations in `workspace`
  * (nf_gnt_workspace_floats(R,S,V,depth,1) floats) for nf_gnt_bwd: d_rgb [R,3] -> d_rgb_feat [R,S,V,35].
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t nf_gnt_blob_floats(int depth);
@@ -187,7 +188,7 @@ int nf_gnt_blob_entry(int depth, int idx, char* name, int name_cap, int64_t* off
 int64_t nf_gnt_workspace_floats(int64_t n_rays, int n_samples, int n_views, int depth, int save);
 int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
                const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
-               float* workspace, nf_stream_t stream);
+               float* alpha, float* workspace, nf_stream_t stream);
 int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
                int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 
@@ -199,7 +200,7 @@ int nf_gnt_pack_mfma(int depth, const float* natural_blob_host, float* mfma_blob
 int nf_gnt_mfma_supported(int n_samples, int n_views);
 int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
                     const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
-                    float* workspace, nf_stream_t stream);
+                    float* alpha, float* workspace, nf_stream_t stream);
 int nf_gnt_bwd_mfma(const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples, int n_views,
                     int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 

@@ -53,12 +53,12 @@ _PROTOTYPES = {
     'nf_gnt_blob_entry': (c_int, [c_int, c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int),
                                   POINTER(c_int)]),
     'nf_gnt_workspace_floats': (c_int64, [c_int64, c_int, c_int, c_int, c_int]),
-    'nf_gnt_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_gnt_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     'nf_gnt_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_gnt_mfma_blob_floats': (c_int64, [c_int]),
     'nf_gnt_pack_mfma': (c_int, [c_int, _P, _P]),
     'nf_gnt_mfma_supported': (c_int, [c_int, c_int]),
-    'nf_gnt_fwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_gnt_fwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     'nf_gnt_bwd_mfma': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_in_act_pad_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_int64, c_int64, c_int64, c_int64,
                                   c_int, c_int, _P, c_int64, _P, _P, _P, _P]),

@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob
                                                   const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                   const float* __restrict__ pts, const float* __restrict__ ray_d, int S, int V,
                                                   int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
-                                                  int64_t row_floats, int64_t smp_floats) {
+                                                  int64_t row_floats, int64_t smp_floats, float* __restrict__ alpha_out) {
     __shared__ float mean_h[64];
     GNT_SETUP()
     c.rgb_feat = rgb_feat_all + ray * S * V * 35;
@@ -390,8 +390,21 @@ __global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob
             }
             SMP(ls + SL_ML, c.part) = mx;
             SMP(ls + SL_ML, 4 + c.part) = l;
+            // ret_alpha (transformer_network.py:196-200, :303-309): attention of the LAST ray transformer, row of sample 0,
+            // averaged over the heads -- head `part` parks its row at SW_T + part, summed below
+            if (alpha_out && i == depth - 1 && c.s == 0)
+                for (int k = 0; k < S; ++k) c.ws_smp[(size_t)(SW_T + c.part) * S + k] = expf(gnt_score(Kb, (size_t)S, k, q) - mx) / l;
         }
         STAGE_END
+        if (alpha_out && i == depth - 1) {
+            STAGE_BEGIN
+            if (c.part == 0) {
+                float t = 0.f;
+                for (int hd = 0; hd < 4; ++hd) t += c.ws_smp[(size_t)(SW_T + hd) * S + c.s];
+                alpha_out[ray * S + c.s] = t / 4.f;
+            }
+            STAGE_END
+        }
         STAGE_BEGIN
         float o[16];
         gnt_slice(L + gnt_wt(GR_OUT), 64, P0, L + gnt_b(GR_OUT), 64, SMPP(SW_U), (size_t)c.S, o);
@@ -634,7 +647,7 @@ static int gnt_check(const char* who, int64_t R, int S, int V, int depth) {
  * save != 0 keeps the activations of ALL rays in `workspace` (nf_gnt_workspace_floats(R,S,V,depth,1)) for nf_gnt_bwd. */
 extern "C" int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
                           const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
-                          float* workspace, nf_stream_t stream) {
+                          float* alpha, float* workspace, nf_stream_t stream) {
     if (gnt_check("nf_gnt_fwd", n_rays, n_samples, n_views, depth)) return 1;
     const int S = n_samples, V = n_views;
     const int threads = GNT_PARTS * (((S + 15) / 16) * 16);       // 4 lanes per sample, multiple of 64
@@ -645,7 +658,7 @@ extern "C" int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float*
         int64_t nr = n_rays - r0 < step ? n_rays - r0 : step;
         hipLaunchKernelGGL(k_gnt_fwd, dim3((unsigned)nr), dim3(threads), 0, (hipStream_t)stream, blob, rgb_feat + r0 * S * V * 35,
                            ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, S, V, depth, save ? 1 : 0,
-                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf);
+                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf, alpha ? alpha + r0 * S : nullptr);
         NF_LAUNCH_CHECK("nf_gnt_fwd");
     }
     return 0;

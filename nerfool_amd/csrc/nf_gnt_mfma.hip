@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                                                           const float* __restrict__ ray_diff_all, const float* __restrict__ mask_all,
                                                           const float* __restrict__ pts, const float* __restrict__ ray_d, int V,
                                                           int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
-                                                          int64_t row_floats, int64_t smp_floats) {
+                                                          int64_t row_floats, int64_t smp_floats, float* __restrict__ alpha_out) {
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int S = 32 * NW;
     float* Kl = lds;
@@ -697,6 +697,17 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                         l += sc[kt][r];
                     }
                 l = gm_half_sum(l);
+                // ret_alpha: attention row of sample 0 in the LAST ray transformer, averaged over the heads; the lanes of
+                // query 0 (wave 0, m == 0) hold it -- keys 32 kt + n(r, h) -- and accumulate straight into the output
+                if (alpha_out && i == depth - 1 && wave == 0 && m == 0) {
+#pragma unroll
+                    for (int kt = 0; kt < NW; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float* ap = alpha_out + ray * S + 32 * kt + gm_nidx(r, h);
+                            *ap = (hd == 0 ? 0.f : *ap) + sc[kt][r] / l * 0.25f;
+                        }
+                }
                 g16 o = gm_zero();
 #pragma unroll
                 for (int kt = 0; kt < NW; ++kt)
@@ -1087,7 +1098,8 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
 // ---------------------------------------------------------------------------------------------------------------
 template <int NW>
 static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
-                     const float* ray_d, int64_t n_rays, int V, int depth, int save, float* rgb, float* workspace, hipStream_t st) {
+                     const float* ray_d, int64_t n_rays, int V, int depth, int save, float* rgb, float* alpha, float* workspace,
+                     hipStream_t st) {
     constexpr int S = 32 * NW;
     static bool configured = false;
     const size_t smem = GmLds<NW>::FLOATS * sizeof(float);
@@ -1105,7 +1117,7 @@ static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray
         const int64_t nr = n_rays - r0 < step ? n_rays - r0 : step;
         hipLaunchKernelGGL(k_gnt_fwd_mfma<NW>, dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
                            ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, V, depth, save ? 1 : 0,
-                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf);
+                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf, alpha ? alpha + r0 * S : nullptr);
         NF_LAUNCH_CHECK("nf_gnt_fwd_mfma");
     }
     return 0;
@@ -1115,16 +1127,16 @@ static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray
  * layout of nf_gnt_pack_mfma.  S must satisfy nf_gnt_mfma_supported. */
 extern "C" int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
                                const float* pts, const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save,
-                               float* rgb, float* workspace, nf_stream_t stream) {
+                               float* rgb, float* alpha, float* workspace, nf_stream_t stream) {
     NF_REQUIRE(nf_gnt_mfma_supported(n_samples, n_views) && depth >= 1 && depth <= 16 && n_rays >= 0,
                "nf_gnt_fwd_mfma: S must be 32, 64, 96 or 128 and 1 <= V <= 64 (got S %d V %d depth %d)", n_samples, n_views, depth);
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     switch (n_samples / 32) {
-        case 1: return gm_launch<1>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
-        case 2: return gm_launch<2>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
-        case 3: return gm_launch<3>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
-        default: return gm_launch<4>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, workspace, st);
+        case 1: return gm_launch<1>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, st);
+        case 2: return gm_launch<2>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, st);
+        case 3: return gm_launch<3>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, st);
+        default: return gm_launch<4>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, st);
     }
 }
 

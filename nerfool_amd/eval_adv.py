@@ -78,7 +78,8 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
         ret = gnt_render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
                               N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
                               det=getattr(args, 'det', True), white_bkgd=args.white_bkgd,
-                              ret_alpha=getattr(args, 'ret_alpha', False), args=args, src_ray_batch=src_ray_batch)
+                              ret_alpha=getattr(args, 'ret_alpha', False), single_net=getattr(args, 'single_net', True),
+                              args=args, src_ray_batch=src_ray_batch)
     else:
         crit = criterion if criterion is not None else globals()['criterion']
         ret = render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,

@@ -14,14 +14,17 @@ class GNTModel(object):
         if device is None:
             device = torch.device('cuda:%d' % getattr(args, 'local_rank', 0))
         self.device = torch.device(device)
-        if not getattr(args, 'single_net', True):
-            raise NotImplementedError('only single_net = True (the released GNT configurations) is built')
+        single_net = bool(getattr(args, 'single_net', True))
         self.net_coarse = GNT(args, in_feat_ch=getattr(args, 'coarse_feat_dim', 32), posenc_dim=63, viewenc_dim=63,
                               ret_alpha=getattr(args, 'ret_alpha', False)).to(self.device)
-        self.net_fine = None
+        # single_net: one network serves the coarse and the fine pass (gnt/model.py:29-39)
+        self.net_fine = None if single_net else GNT(args, in_feat_ch=getattr(args, 'fine_feat_dim', 32), posenc_dim=63,
+                                                    viewenc_dim=63, ret_alpha=True).to(self.device)
         self.feature_net = ResUNet(coarse_out_ch=getattr(args, 'coarse_feat_dim', 32), fine_out_ch=getattr(args, 'fine_feat_dim', 32),
-                                   single_net=True).to(self.device)
-        for net in (self.net_coarse, self.feature_net):
+                                   single_net=single_net).to(self.device)
+        for net in (self.net_coarse, self.net_fine, self.feature_net):
+            if net is None:
+                continue
             for p in net.parameters():
                 p.requires_grad_(False)
         self.start_step = 0
@@ -29,6 +32,8 @@ class GNTModel(object):
         if ckpt and os.path.isfile(ckpt) and not getattr(args, 'no_reload', False):
             to_load = torch.load(ckpt, map_location=self.device)
             self.net_coarse.load_state_dict(to_load['net_coarse'])
+            if self.net_fine is not None and 'net_fine' in to_load:
+                self.net_fine.load_state_dict(to_load['net_fine'])
             self.feature_net.load_state_dict(to_load['feature_net'])
             try:
                 self.start_step = int(ckpt[-10:-4])
@@ -37,6 +42,8 @@ class GNTModel(object):
 
     def switch_to_eval(self):
         self.net_coarse.eval()
+        if self.net_fine is not None:
+            self.net_fine.eval()
         self.feature_net.eval()
 
     def switch_to_train(self):

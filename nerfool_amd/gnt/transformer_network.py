@@ -51,23 +51,28 @@ class _TransformerParams(nn.Module):
 
 class _GNTFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, mfma_blob, depth):
+    def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, mfma_blob, depth, ret_alpha):
         need_grad = rgb_feat.requires_grad
         if mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2]):
             # same workspace layout as the generic forward: the backward below consumes either
-            rgb, ws = ops.gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad)
+            out = ops.gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha)
         else:
-            rgb, ws = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad)
+            out = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha)
+        rgb, ws = out[0], out[1]
+        alpha = out[2] if ret_alpha else rgb.new_zeros(0)
         ctx.depth = depth
         ctx.shape = tuple(rgb_feat.shape[:3])
         ctx.have_ws = ws is not None
         ctx.use_mfma = mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])
         if ws is not None:
             ctx.save_for_backward(ray_diff, mask, blob, ws, mfma_blob if ctx.use_mfma else None)
-        return rgb
+        # the attention-derived weights feed depth maps and the fine resampling only (both detached in the reference's rgb-loss
+        # path, gnt/render_ray.py:256): no gradient is propagated through them
+        ctx.mark_non_differentiable(alpha)
+        return rgb, alpha
 
     @staticmethod
-    def backward(ctx, d_rgb):
+    def backward(ctx, d_rgb, _d_alpha=None):
         if not ctx.have_ws:
             raise RuntimeError('GNT forward ran without saved activations (input did not require grad)')
         ray_diff, mask, blob, ws, mfma_blob = ctx.saved_tensors
@@ -75,14 +80,12 @@ class _GNTFunction(torch.autograd.Function):
             d_rgb_feat = ops.gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, ctx.shape, ctx.depth)
         else:
             d_rgb_feat = ops.gnt_bwd(blob, ray_diff, mask, d_rgb, ws, ctx.shape, ctx.depth)
-        return d_rgb_feat, None, None, None, None, None, None, None
+        return d_rgb_feat, None, None, None, None, None, None, None, None
 
 
 class GNT(nn.Module):
     def __init__(self, args, in_feat_ch=32, posenc_dim=3, viewenc_dim=3, ret_alpha=False):
         super().__init__()
-        if ret_alpha:
-            raise NotImplementedError('ret_alpha (attention-derived depth) is not built; the released configs use False')
         if args.netwidth != 64 or in_feat_ch != 32:
             raise ValueError('the HIP GNT kernels are built for netwidth 64 and 32 feature channels')
         w = args.netwidth
@@ -111,7 +114,9 @@ class GNT(nn.Module):
         return self._blob, self._mfma_blob
 
     def forward(self, rgb_feat, ray_diff, mask, pts, ray_d):
-        """rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V,1], pts [R,S,3], ray_d [R,3] -> rgb [R,3]"""
+        """rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V,1], pts [R,S,3], ray_d [R,3] -> rgb [R,3] (or [R,3+S])"""
         blob, mfma_blob = self._packed(rgb_feat.device)
-        return _GNTFunction.apply(rgb_feat, ray_diff, mask[..., 0], pts.detach(), ray_d.detach(), blob, mfma_blob,
-                                  self.trans_depth)
+        rgb, alpha = _GNTFunction.apply(rgb_feat, ray_diff, mask[..., 0], pts.detach(), ray_d.detach(), blob, mfma_blob,
+                                        self.trans_depth, bool(self.ret_alpha))
+        # ret_alpha: [R, 3 + S] = colour | attention of the first sample in the last ray transformer, mean over heads (:303-309)
+        return torch.cat([rgb, alpha], dim=1) if self.ret_alpha else rgb

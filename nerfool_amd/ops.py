@@ -438,7 +438,7 @@ def pack_gnt_blob(state, depth, device):
     return blob.to(device)
 
 
-def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save):
+def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=False):
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     pts, ray_d = _c(pts, 'pts'), _c(ray_d, 'ray_d')
     R, S, V, F = rgb_feat.shape
@@ -447,9 +447,12 @@ def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save):
     L = _lib.lib()
     ws = torch.empty(L.nf_gnt_workspace_floats(R, S, V, depth, int(bool(save))), dtype=torch.float32, device=rgb_feat.device)
     rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
+    alpha = torch.empty(R, S, dtype=torch.float32, device=rgb_feat.device) if want_alpha else None
     with prof.launch('nf_gnt_fwd', rgb, R=R, S=S, V=V, depth=depth):
         _lib.check(L.nf_gnt_fwd(_ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V, depth,
-                                int(bool(save)), _ptr(rgb), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd')
+                                int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd')
+    if want_alpha:
+        return rgb, (ws if save else None), alpha
     return rgb, (ws if save else None)
 
 
@@ -466,7 +469,7 @@ def gnt_mfma_supported(n_samples, n_views):
     return bool(_lib.lib().nf_gnt_mfma_supported(int(n_samples), int(n_views)))
 
 
-def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save):
+def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=False):
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     pts, ray_d = _c(pts, 'pts'), _c(ray_d, 'ray_d')
     R, S, V, F = rgb_feat.shape
@@ -475,9 +478,12 @@ def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save):
     L = _lib.lib()
     ws = torch.empty(L.nf_gnt_workspace_floats(R, S, V, depth, int(bool(save))), dtype=torch.float32, device=rgb_feat.device)
     rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
+    alpha = torch.empty(R, S, dtype=torch.float32, device=rgb_feat.device) if want_alpha else None
     with prof.launch('nf_gnt_fwd_mfma', rgb, R=R, S=S, V=V, depth=depth):
         _lib.check(L.nf_gnt_fwd_mfma(_ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
-                                     depth, int(bool(save)), _ptr(rgb), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd_mfma')
+                                     depth, int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd_mfma')
+    if want_alpha:
+        return rgb, (ws if save else None), alpha
     return rgb, (ws if save else None)
 
 

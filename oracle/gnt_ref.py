@@ -50,8 +50,9 @@ def view_transformer(p, pre, q, X, ray_diff, mask):
     return y + x
 
 
-def ray_transformer(p, pre, q, n_heads=4):
-    """Transformer (attn_mode 'qk'): pre-LN multi-head self-attention over the S samples of a ray, no mask."""
+def ray_transformer(p, pre, q, n_heads=4, ret_attn=False):
+    """Transformer (attn_mode 'qk'): pre-LN multi-head self-attention over the S samples of a ray, no mask.
+    ret_attn: also the attention row of sample 0 averaged over the heads (transformer_network.py:196-200)."""
     a = pre + '.attn'
     R, S, C = q.shape
     x = _ln(p, pre + '.attn_norm', q, 1e-6)
@@ -62,11 +63,13 @@ def ray_transformer(p, pre, q, n_heads=4):
     x = _lin(p, a + '.out_fc', out) + q
     y = _ln(p, pre + '.ff_norm', x, 1e-6)
     y = _lin(p, pre + '.ff.fc2', F.relu(_lin(p, pre + '.ff.fc1', y)))
+    if ret_attn:
+        return y + x, att.mean(dim=1)[:, 0]
     return y + x
 
 
-def gnt_forward(p, rgb_feat, ray_diff, mask, pts, ray_d, trans_depth):
-    """ref: gnt/transformer_network.py:270-309 (ret_alpha = False) -> rgb [R,3]."""
+def gnt_forward(p, rgb_feat, ray_diff, mask, pts, ray_d, trans_depth, ret_alpha=False):
+    """ref: gnt/transformer_network.py:270-309 -> rgb [R,3], or [R,3+S] with ret_alpha (attention of the last ray transformer)."""
     viewdirs = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
     view_emb = posenc(viewdirs.reshape(-1, 3).float())                        # [R,63]
     pts_emb = posenc(pts.reshape(-1, 3).float()).reshape(list(pts.shape[:-1]) + [63])
@@ -78,9 +81,12 @@ def gnt_forward(p, rgb_feat, ray_diff, mask, pts, ray_d, trans_depth):
         if i % 2 == 0:
             q = torch.cat((q, pts_emb, view_emb), dim=-1)
             q = _lin(p, 'q_fcs.%d.2' % i, F.relu(_lin(p, 'q_fcs.%d.0' % i, q)))
-        q = ray_transformer(p, 'view_selftrans.%d' % i, q)
+        q = ray_transformer(p, 'view_selftrans.%d' % i, q, ret_attn=ret_alpha)
+        if ret_alpha:
+            q, attn = q
     h = _ln(p, 'norm', q, 1e-5)
-    return _lin(p, 'rgb_fc', h.mean(dim=1))
+    out = _lin(p, 'rgb_fc', h.mean(dim=1))
+    return torch.cat([out, attn], dim=1) if ret_alpha else out
 
 
 def random_gnt_params(trans_depth, seed, width=64):
@@ -122,14 +128,27 @@ def random_gnt_params(trans_depth, seed, width=64):
     return p
 
 
-def render_rays(ray_batch, params, featmaps, N_samples, trans_depth, inv_uniform=False, det=False, src_ray_batch=None):
-    """ref: gnt/render_ray.py:196-258 with N_importance = 0, ret_alpha = False: {'rgb', 'weights': None, 'depth': None}."""
+def render_rays(ray_batch, params, featmaps, N_samples, trans_depth, inv_uniform=False, det=False, src_ray_batch=None,
+                N_importance=0, ret_alpha=False):
+    """ref: gnt/render_ray.py:196-279 (single_net): {'rgb', 'weights', 'depth'} per level; the fine pass resamples on the
+    detached attention weights of the coarse pass (sample_fine_pts :164-193 == the IBRNet fine-sample assembly)."""
     src = ray_batch if src_ray_batch is None else src_ray_batch
     pts, z_vals = ib.sample_along_camera_ray(ray_batch['ray_o'], ray_batch['ray_d'], ray_batch['depth_range'], N_samples,
                                              inv_uniform=inv_uniform, det=det)
-    rgb_feat, ray_diff, mask = ib.projector_compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'], featmaps[0])
-    rgb = gnt_forward(params, rgb_feat, ray_diff, mask, pts, ray_batch['ray_d'], trans_depth)
-    return {'outputs_coarse': {'rgb': rgb, 'weights': None, 'depth': None}, 'outputs_fine': None}
+
+    def level(pts, z_vals, fm, with_alpha):
+        rgb_feat, ray_diff, mask = ib.projector_compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'], fm)
+        out = gnt_forward(params, rgb_feat, ray_diff, mask, pts, ray_batch['ray_d'], trans_depth, ret_alpha=with_alpha)
+        if not with_alpha:
+            return {'rgb': out, 'weights': None, 'depth': None}
+        return {'rgb': out[:, :3], 'weights': out[:, 3:], 'depth': torch.sum(out[:, 3:] * z_vals, dim=-1)}
+
+    ret = {'outputs_coarse': level(pts, z_vals, featmaps[0], ret_alpha), 'outputs_fine': None}
+    if N_importance > 0:
+        z_vals = ib.fine_depths(z_vals, ret['outputs_coarse']['weights'].clone().detach(), N_importance, inv_uniform, det)
+        pts = z_vals[..., None] * ray_batch['ray_d'][:, None, :] + ray_batch['ray_o'][:, None, :]
+        ret['outputs_fine'] = level(pts, z_vals, featmaps[1], True)
+    return ret
 
 
 def criterion(outputs, ray_batch):

@@ -76,6 +76,47 @@ def case(name, H, W, V, R, S, depth, seed, tilt=0.0):
     print('   %.1f KB' % (os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024.))
 
 
+def alpha_case(name, H, W, V, R, S, N_imp, depth, seed, tilt=0.0):
+    """ret_alpha = True (attention-derived weights / depth) and hierarchical sampling with a single network
+    (gnt/render_ray.py:249-277): colour, weights, depth of both passes and the gradient of the summed loss."""
+    torch.manual_seed(seed)
+    data = make_scene(H, W, V, seed=seed, tilt=tilt)
+    Hf, Wf = max(6, H // 4), max(8, W // 4)
+    fm = smooth_featmaps(V, 32, Hf, Wf, seed=seed).requires_grad_(True)
+    params = random_gnt_params(depth, seed=60 + seed)
+    net = GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=True)
+    net.load_state_dict(params, strict=True)
+    net.eval()
+    model = SimpleNamespace(net_coarse=net, net_fine=None)
+    ref_sample_ray.rng.seed(234)
+    sampler = ref_sample_ray.RaySamplerSingleImage(data, 'cpu')
+    batch = sampler.random_sample(R, sample_mode='uniform', center_ratio=0.8)
+    ret = render_rays(batch, model, (fm, fm), Projector(device='cpu'), S, inv_uniform=True, N_importance=N_imp, det=True,
+                      ret_alpha=True, single_net=True)
+    loss = sum(torch.mean((ret[k]['rgb'] - batch['rgb']) ** 2) for k in ('outputs_coarse', 'outputs_fine'))
+    grad, = torch.autograd.grad(loss, fm)
+    out = {'cfg': np.array([H, W, V, R, S, depth, Hf, Wf, N_imp], dtype=np.int64)}
+    for k in ('rgb', 'camera', 'src_rgbs', 'src_cameras', 'depth_range'):
+        out['in/' + k] = npy(data[k])
+    out['in/featmap'] = npy(fm)
+    out['in/ray_o'] = npy(batch['ray_o'])
+    out['in/ray_d'] = npy(batch['ray_d'])
+    out['in/gt_rgb'] = npy(batch['rgb'])
+    for k, v in params.items():
+        out['net/' + k] = npy(v)
+    for lvl in ('outputs_coarse', 'outputs_fine'):
+        for k in ('rgb', 'weights', 'depth'):
+            out['%s/%s' % (lvl, k)] = npy(ret[lvl][k])
+    out['loss'] = npy(loss)
+    out['grad/featmap'] = npy(grad)
+    print('%-24s loss %.6f  weights sum %.4f' % (name, float(loss), float(ret['outputs_coarse']['weights'].sum(-1).mean())))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('   %.1f KB' % (os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024.))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'alpha':
+        alpha_case('gnt_alpha_d2_v3', 32, 48, 3, 10, 32, 32, 2, seed=3, tilt=0.3)
+        sys.exit(0)
     case('gnt_tiny_d2_v4', 32, 48, 4, 12, 8, 2, seed=0, tilt=0.4)
     case('gnt_tiny_d3_v5', 32, 48, 5, 10, 12, 3, seed=1, tilt=0.3)

@@ -512,6 +512,46 @@ def check_gnt(case, dev):
     assert_close(grad, gref, 1e-2, 2e-3 * float(np.abs(gref).max()), 'GNT d loss / d featmap', frac_ok=2e-3)
 
 
+def check_gnt_alpha(dev, kernel_path=None):
+    """ret_alpha = True (attention weights, depth) and hierarchical sampling with one network, against the reference capture:
+    both passes (32 and 32 + 32 samples) run through whichever forward the shape selects."""
+    from nerfool_amd.gnt import transformer_network as tn
+    from nerfool_amd.gnt.criterion import Criterion as GntCriterion
+    from nerfool_amd.gnt.render_ray import render_rays as gnt_render_rays
+    g = Golden('gnt_alpha_d2_v3')
+    H, W, V, R, S, depth, Hf, Wf, N_imp = [int(x) for x in g.np('cfg')]
+    saved = tn.KERNEL_PATH
+    if kernel_path is not None:
+        tn.KERNEL_PATH = kernel_path
+    try:
+        net = tn.GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=True)
+        net.load_state_dict(g.params('net'), strict=True)
+        for p in net.parameters():
+            p.requires_grad_(False)
+        net = net.to(dev).eval()
+        fm = g.t('in/featmap', dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        rb = {'ray_o': g.t('in/ray_o', dev), 'ray_d': g.t('in/ray_d', dev), 'rgb': g.t('in/gt_rgb', dev),
+              'camera': g.t('in/camera', dev), 'depth_range': g.t('in/depth_range', dev), 'src_rgbs': g.t('in/src_rgbs', dev),
+              'src_cameras': g.t('in/src_cameras', dev)}
+        ret = gnt_render_rays(rb, SimpleNamespace(net_coarse=net, net_fine=None), (fm, fm), Projector(dev), S, inv_uniform=True,
+                              N_importance=N_imp, det=True, ret_alpha=True, single_net=True)
+        for lvl in ('outputs_coarse', 'outputs_fine'):
+            ref_rgb = g.np(lvl + '/rgb')
+            assert_close(ret[lvl]['rgb'], ref_rgb, 1e-3, 1e-3 * float(np.abs(ref_rgb).max()), lvl + ' rgb', frac_ok=0.05 if 'fine' in lvl else 0)
+            assert_close(ret[lvl]['weights'], g.np(lvl + '/weights'), 1e-3, 1e-5, lvl + ' attention weights', frac_ok=0.02 if 'fine' in lvl else 0)
+            assert_close(ret[lvl]['depth'], g.np(lvl + '/depth'), 1e-3, 1e-4, lvl + ' depth', frac_ok=0.1 if 'fine' in lvl else 0)
+            assert float((ret[lvl]['weights'].sum(-1) - 1).abs().max()) < 1e-4
+        crit = GntCriterion()
+        loss = crit(ret['outputs_coarse'], rb, None)[0] + crit(ret['outputs_fine'], rb, None)[0]
+        assert abs(float(loss) - float(g.np('loss'))) <= 2e-3 * abs(float(g.np('loss')))
+        grad, = torch.autograd.grad(loss, fm)
+        ref = g.t('grad/featmap')
+        err = float((grad.cpu() - ref).norm() / ref.norm())
+        assert err < 2e-2, 'd loss / d featmap: relative L2 error %.3e' % err
+    finally:
+        tn.KERNEL_PATH = saved
+
+
 def check_gnt_mfma_vs_generic(dev, shapes=((2, 32, 3, 2),)):
     """Matrix-core GNT forward vs the shape-generic forward on random weights / inputs: the colour, and the gradient the
     (shared) backward kernel derives from the activations each forward saved -- which checks every saved slot."""
@@ -538,8 +578,11 @@ def check_gnt_mfma_vs_generic(dev, shapes=((2, 32, 3, 2),)):
         rgb_a, ws_a = ops.gnt_fwd(blob, *args, save=True)
         rgb_b, ws_b = ops.gnt_fwd_mfma(mblob, *args, save=True)
         assert_close(rgb_b, rgb_a, 1e-4, 1e-4 * float(rgb_a.abs().max()), 'GNT rgb (matrix cores vs generic)')
-        rgb_c, _ = ops.gnt_fwd_mfma(mblob, *args, save=False)
+        rgb_c, _, al_c = ops.gnt_fwd_mfma(mblob, *args, save=False, want_alpha=True)
         assert_close(rgb_c, rgb_a, 1e-4, 1e-4 * float(rgb_a.abs().max()), 'GNT rgb (matrix cores, no save)')
+        _, _, al_a = ops.gnt_fwd(blob, *args, save=False, want_alpha=True)
+        assert_close(al_c, al_a, 1e-4, 1e-6, 'GNT ret_alpha weights (matrix cores vs generic)')
+        assert float((al_a.sum(-1) - 1).abs().max()) < 1e-5
         d_rgb = torch.randn(R, 3, generator=gen).to(dev)
         ga = ops.gnt_bwd(blob, args[1], args[2], d_rgb, ws_a, (R, S, V), depth)
         gb = ops.gnt_bwd(blob, args[1], args[2], d_rgb, ws_b, (R, S, V), depth)

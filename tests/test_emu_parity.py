@@ -127,3 +127,9 @@ def test_render_rays_through_mfma_kernels():
 
 def test_gnt_matrix_core_forward_matches_generic():
     pc.check_gnt_mfma_vs_generic('cpu', shapes=((2, 32, 3, 2),))
+
+
+def test_gnt_ret_alpha_and_hierarchical_sampling():
+    # shape-generic kernels here (4 s); the matrix-core kernels take 4 minutes to emulate on this case: their ret_alpha output
+    # is compared with the generic one in test_gnt_matrix_core_forward_matches_generic, the full case runs on the GPU
+    pc.check_gnt_alpha('cpu', kernel_path='generic')

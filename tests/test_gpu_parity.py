@@ -200,3 +200,8 @@ def test_gnt_matrix_core_forward_matches_generic(shape):
 
 def test_evaluate_view_metrics():
     pc.check_evaluate_view('cuda')
+
+
+@pytest.mark.parametrize('path', ['generic', 'mfma'])
+def test_gnt_ret_alpha_and_hierarchical_sampling(path):
+    pc.check_gnt_alpha('cuda', kernel_path=path)

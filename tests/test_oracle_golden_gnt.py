@@ -33,3 +33,21 @@ def test_gnt_network_and_renderer_match_reference(case):
     grad, = torch.autograd.grad(loss, fm)
     ref = g.np('grad/featmap')
     assert_close(grad, ref, 1e-3, 1e-4 * float(np.abs(ref).max()), 'd loss / d featmap')
+
+
+def test_gnt_ret_alpha_and_hierarchical_sampling_match_reference():
+    """ret_alpha = True + N_importance > 0 with a single network (gnt/render_ray.py:249-277, transformer_network.py:196-200)."""
+    g = Golden('gnt_alpha_d2_v3')
+    H, W, V, R, S, depth, Hf, Wf, N_imp = [int(x) for x in g.np('cfg')]
+    fm = g.t('in/featmap').requires_grad_(True)
+    rb = gnt_batch(g)
+    ret = gr.render_rays(rb, g.params('net'), (fm, fm), S, depth, inv_uniform=True, det=True, N_importance=N_imp, ret_alpha=True)
+    for lvl in ('outputs_coarse', 'outputs_fine'):
+        assert_close(ret[lvl]['rgb'], g.np(lvl + '/rgb'), 1e-4, 2e-5, lvl + ' rgb')
+        assert_close(ret[lvl]['weights'], g.np(lvl + '/weights'), 1e-4, 1e-6, lvl + ' weights')
+        assert_close(ret[lvl]['depth'], g.np(lvl + '/depth'), 1e-4, 1e-5, lvl + ' depth')
+    loss = gr.criterion(ret['outputs_coarse'], rb) + gr.criterion(ret['outputs_fine'], rb)
+    assert_close(loss, g.np('loss'), 1e-5, 1e-7, 'loss')
+    grad, = torch.autograd.grad(loss, fm)
+    ref = g.np('grad/featmap')
+    assert_close(grad, ref, 1e-3, 1e-4 * float(np.abs(ref).max()), 'd loss / d featmap')
