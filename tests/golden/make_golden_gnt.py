@@ -19,7 +19,7 @@ import _refimport  # noqa: E402
 _refimport.install('gnt')
 
 from gnt.projection import Projector  # noqa: E402
-from gnt.render_ray import render_rays  # noqa: E402
+from gnt.render_ray import render_rays, render_rays_hybrid  # noqa: E402
 from gnt.transformer_network import GNT  # noqa: E402
 import gnt.sample_ray as ref_sample_ray  # noqa: E402
 
@@ -109,6 +109,17 @@ def alpha_case(name, H, W, V, R, S, N_imp, depth, seed, tilt=0.0):
             out['%s/%s' % (lvl, k)] = npy(ret[lvl][k])
     out['loss'] = npy(loss)
     out['grad/featmap'] = npy(grad)
+    # clean-colour / clean-density ablation (gnt/render_ray.py:282-387): the same network on perturbed and on clean feature maps
+    fm_clean = smooth_featmaps(V, 32, Hf, Wf, seed=seed + 50)
+    out['in/featmap_clean'] = npy(fm_clean)
+    with torch.no_grad():
+        for tag in ('clean_color', 'clean_density'):
+            a = SimpleNamespace(use_clean_color=tag == 'clean_color', use_clean_density=tag == 'clean_density')
+            h = render_rays_hybrid(batch, model, (fm, fm), Projector(device='cpu'), S, inv_uniform=True, N_importance=N_imp, det=True,
+                                   ret_alpha=True, single_net=True, args=a, featmaps_clean=(fm_clean, fm_clean))
+            for lvl in ('outputs_coarse', 'outputs_fine'):
+                for k in ('rgb', 'weights', 'depth'):
+                    out['hybrid/%s/%s/%s' % (tag, lvl, k)] = npy(h[lvl][k])
     print('%-24s loss %.6f  weights sum %.4f' % (name, float(loss), float(ret['outputs_coarse']['weights'].sum(-1).mean())))
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     print('   %.1f KB' % (os.path.getsize(os.path.join(HERE, name + '.npz')) / 1024.))

@@ -541,6 +541,20 @@ def check_gnt_alpha(dev, kernel_path=None):
             assert_close(ret[lvl]['weights'], g.np(lvl + '/weights'), 1e-3, 1e-5, lvl + ' attention weights', frac_ok=0.02 if 'fine' in lvl else 0)
             assert_close(ret[lvl]['depth'], g.np(lvl + '/depth'), 1e-3, 1e-4, lvl + ' depth', frac_ok=0.1 if 'fine' in lvl else 0)
             assert float((ret[lvl]['weights'].sum(-1) - 1).abs().max()) < 1e-4
+        # clean-colour / clean-density ablation of the GNT flavour
+        from nerfool_amd.gnt.render_ray import render_rays_hybrid as gnt_hybrid
+        fmc = g.t('in/featmap_clean', dev).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            for tag in ('clean_color', 'clean_density'):
+                a = SimpleNamespace(use_clean_color=tag == 'clean_color', use_clean_density=tag == 'clean_density')
+                h = gnt_hybrid(rb, SimpleNamespace(net_coarse=net, net_fine=None), (fm.detach(), fm.detach()), Projector(dev), S,
+                               inv_uniform=True, N_importance=N_imp, det=True, ret_alpha=True, single_net=True, args=a,
+                               featmaps_clean=(fmc, fmc))
+                for k in ('rgb', 'weights', 'depth'):
+                    ref_v = g.np('hybrid/%s/outputs_coarse/%s' % (tag, k))
+                    assert_close(h['outputs_coarse'][k], ref_v, 1e-3, 1e-3 * max(float(np.abs(ref_v).max()), 1e-3), tag + ' coarse ' + k)
+                ref_v = g.np('hybrid/%s/outputs_fine/rgb' % tag)
+                assert_close(h['outputs_fine']['rgb'], ref_v, 1e-3, 1e-3 * float(np.abs(ref_v).max()), tag + ' fine rgb', frac_ok=0.05)
         crit = GntCriterion()
         loss = crit(ret['outputs_coarse'], rb, None)[0] + crit(ret['outputs_fine'], rb, None)[0]
         assert abs(float(loss) - float(g.np('loss'))) <= 2e-3 * abs(float(g.np('loss')))
