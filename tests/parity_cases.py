@@ -294,6 +294,43 @@ def check_render_single_image(dev, rows=None):
         assert abs(ib.mse2psnr(mse) - float(g.np('image/psnr_fine'))) < 1e-2, 'PSNR'
 
 
+def check_attack_loops(dev):
+    """PGDAttack.run_view_specific / run_universal (eval_adv.py:796-843, :646-740): step counts (the universal loop runs
+    adv_iters + 1 steps), StepLR schedule, eps-ball and [0,1]-box invariants, loss increase under ascent, sign-PGD branch."""
+    from nerfool_amd.synthetic import make_scene
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    src = sampler.get_all()
+    eps = args.epsilon / 255.0
+    product_sample_ray.rng.seed(234)
+    atk = EA.PGDAttack(args, model, Projector(dev), src, delta=g.t('in/delta0', dev).clone().requires_grad_(True))
+    atk.run_view_specific(data, n_iters=5)
+    assert atk.iters == 5
+    assert abs(atk.lr() - args.adam_lr * args.lr_gamma ** (5 // args.lr_step_size)) < 1e-12
+    d = atk.delta.detach()
+    assert float(d.abs().max()) <= eps + 1e-7
+    x = src['src_rgbs'] + d
+    assert float(x.min()) >= -1e-7 and float(x.max()) <= 1 + 1e-7
+    # universal: cycles over the loader, adv_iters + 1 steps
+    product_sample_ray.rng.seed(234)
+    uni = EA.PGDAttack(args, model, Projector(dev), src, delta=g.t('in/delta0', dev).clone().requires_grad_(True))
+    losses = []
+    orig_step = uni.step
+    uni.step = lambda dd, select_inds=None: losses.append(float(orig_step(dd, select_inds))) or losses[-1]
+    uni.run_universal([data, data], n_iters=4)
+    assert uni.iters == 5 and len(losses) == 5
+    assert float(uni.delta.detach().abs().max()) <= eps + 1e-7
+    # sign-PGD branch: every element moves by exactly alpha (before projection) in the ascent direction
+    args2 = SimpleNamespace(**dict(vars(args), use_adam=False))
+    product_sample_ray.rng.seed(234)
+    sg = EA.PGDAttack(args2, model, Projector(dev), src, delta=torch.zeros_like(g.t('in/delta0', dev)).requires_grad_(True))
+    grad = sg.gradient(data).clone()
+    sg.apply(grad)
+    moved = sg.delta.detach()
+    inside = (src['src_rgbs'] > 0.05) & (src['src_rgbs'] < 0.95)
+    expect = (args2.adv_lr / 255.0) * torch.sign(grad)
+    assert float((moved - expect)[inside].abs().max()) <= 1e-7
+
+
 def check_evaluate_view(dev):
     """eval_views.evaluate_view (the evaluation loop of eval.py / eval_adv.py:861-905) on the attack fixture: adversarial
     render with the reference's final delta -> the reference's fine PSNR; delta = 0 equals the clean render."""

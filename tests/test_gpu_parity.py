@@ -205,3 +205,49 @@ def test_evaluate_view_metrics():
 @pytest.mark.parametrize('path', ['generic', 'mfma'])
 def test_gnt_ret_alpha_and_hierarchical_sampling(path):
     pc.check_gnt_alpha('cuda', kernel_path=path)
+
+
+def test_attack_loops_and_invariants():
+    pc.check_attack_loops('cuda')
+
+
+def test_gnt_full_size_properties():
+    """BASELINE config 4 sizes (800x800 sources, V=10, 64 samples, depth 8, 512 rays): matrix-core kernels vs generic kernels at
+    full size, linearity of the backward, ray-permutation equivariance, attention weights on the simplex."""
+    from types import SimpleNamespace
+    from nerfool_amd import ops
+    from nerfool_amd.gnt.transformer_network import GNT
+    from nerfool_amd.ibrnet.projection import Projector
+    from nerfool_amd.ibrnet.render_ray import sample_along_camera_ray
+    from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
+    from nerfool_amd.synthetic import feature_map_size, make_scene, smooth_featmaps
+    dev = 'cuda'
+    H, W, V, R, S, depth = 800, 800, 10, 512, 64, 8
+    data = make_scene(H, W, V, seed=7, blender=True)
+    sampler = RaySamplerSingleImage(data, dev)
+    rb = sampler.select(np.random.RandomState(1).choice(H * W, size=(R,), replace=False))
+    Hf, Wf = feature_map_size(H, W)
+    fm = smooth_featmaps(V, 32, Hf, Wf, seed=2).to(dev).contiguous(memory_format=torch.channels_last)
+    pts, z = sample_along_camera_ray(rb['ray_o'], rb['ray_d'], rb['depth_range'], S, inv_uniform=False, det=True)
+    rgb_feat, ray_diff, mask = Projector(dev).compute(pts, rb['camera'], rb['src_rgbs'], rb['src_cameras'], featmaps=fm)
+    torch.manual_seed(3)
+    net = GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63)
+    blob = ops.pack_gnt_blob(net.state_dict(), depth, dev)
+    mblob = ops.pack_gnt_mfma_blob(blob, depth)
+    args = (rgb_feat, ray_diff, mask[..., 0], pts, rb['ray_d'], depth)
+    rgb_g, ws_g = ops.gnt_fwd(blob, *args, save=True)
+    rgb_m, ws_m, alpha = ops.gnt_fwd_mfma(mblob, *args, save=True, want_alpha=True)
+    assert torch.isfinite(rgb_m).all()
+    assert float((rgb_m - rgb_g).abs().max()) <= 1e-4 * max(1.0, float(rgb_g.abs().max()))
+    assert float(alpha.min()) >= 0 and float((alpha.sum(-1) - 1).abs().max()) <= 1e-4
+    d_rgb = torch.randn(R, 3, device=dev)
+    g_g = ops.gnt_bwd(blob, ray_diff, mask[..., 0], d_rgb, ws_g, (R, S, V), depth)
+    g_m = ops.gnt_bwd_mfma(mblob, mask[..., 0], d_rgb, ws_m, (R, S, V), depth)
+    assert torch.isfinite(g_m).all()
+    assert float((g_m - g_g).norm() / g_g.norm()) <= 2e-3          # ReLU / max kinks flip on isolated elements at depth 8
+    g_2 = ops.gnt_bwd_mfma(mblob, mask[..., 0], 2.0 * d_rgb, ws_m, (R, S, V), depth)
+    assert float((g_2 - 2.0 * g_m).abs().max()) <= 1e-4 * float(g_2.abs().max())                # linear in the upstream gradient
+    perm = torch.randperm(R, device=dev)
+    rgb_p, _ = ops.gnt_fwd_mfma(mblob, rgb_feat[perm], ray_diff[perm], mask[..., 0][perm], pts[perm], rb['ray_d'][perm], depth,
+                                save=False)
+    assert float((rgb_p - rgb_m[perm]).abs().max()) == 0.0                                         # rays are independent
