@@ -159,6 +159,20 @@ int nf_upsample2x_pad_fwd(const float* x, int64_t planes, int64_t xs_plane, int6
                           float* y_padded, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * a14  ResUNet 1x1 convolutions (out_conv with bias, the stride-2 downsample branches) as fp32 MFMA GEMMs over the pixels.
+ *      ref: ibrnet/feature_network.py:196-203, :62-70.
+ *   y[n, co, r, c] = bias[co] + sum_ci M[co][ci] x[n, ci, r, c] on an H x W pixel grid; x and y are addressed with element
+ *   strides (image, channel, row, column): NCHW, NHWC and stride-2 subsampled views are the same call.  `records` =
+ *   nf_conv1x1_pack(weight [c_out][c_in]) (HOST pointers); with transposed != 0 the records hold weight^T and the call
+ *   nf_conv1x1(..., c_in := c_out, c_out := c_in) is the backward-data pass.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int64_t nf_conv1x1_pack_floats(int c_out, int c_in);
+int nf_conv1x1_pack(const float* weight_host, int c_out, int c_in, int transposed, float* records_host);
+int nf_conv1x1(const float* records, const float* bias, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w,
+               float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, int n_img, int H, int W, int c_in, int c_out,
+               nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * a11/a13  perturbation update             ref: eval/ibrnet/eval_adv.py:28-29, :248-254, :805-839
  * All tensors flat [n] (delta, grad, exp_avg, exp_avg_sq, src all shaped [1,V,H,W,3]).
  *   nf_project_perturb : delta = max(min(delta, eps), -eps) (skipped if eps < 0); delta = max(min(delta, hi-src), lo-src)

@@ -186,6 +186,25 @@ def _conv(tape, inp, w, stride, sink, bias=None):
     return out
 
 
+def _conv1x1(tape, inp, conv, sink, channels_last_out=False):
+    """1x1 convolution (downsample branch, out_conv) as an MFMA GEMM over the pixels (csrc/nf_conv1x1.hip): `inp` may be any
+    strided view -- the stride-2 subsampling is read in place -- and out_conv writes the channels-last maps directly."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    cache = getattr(conv, '_nf_records', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.conv1x1_pack(w, False, w.device), ops.conv1x1_pack(w, True, w.device))
+        conv._nf_records = cache
+    c_out, c_in = w.shape[0], w.shape[1]
+    out = _Slot(ops.conv1x1(cache[1], conv.bias, inp, c_out, channels_last_out))
+
+    def bwd():
+        sink(ops.conv1x1(cache[2], None, out.g, c_in))
+        out.g = None
+    tape.append(bwd)
+    return out
+
+
 def _fuse(tape, xs, norm, res, act, pad):
     gamma, beta = (norm.weight, norm.bias) if norm is not None else (None, None)
     yp, mean, rstd = ops.in_act_pad_fwd(xs.v, gamma, beta, None if res is None else res.interior(), act, pad,
@@ -213,9 +232,9 @@ def _resblock(tape, blk, xin):
         # 1x1 stride-s convolution == 1x1 stride-1 convolution of the subsampled activation: a quarter of the bytes to gather,
         # and the gradient comes back subsampled (the fused backward adds it at the even positions)
         if stride == 2:
-            d = _conv(tape, xin.interior()[:, :, ::2, ::2].contiguous(), blk.downsample[0].weight, 1, xin.add_s)
+            d = _conv1x1(tape, xin.interior()[:, :, ::2, ::2], blk.downsample[0], xin.add_s)
         else:
-            d = _conv(tape, xin.interior(), blk.downsample[0].weight, stride, xin.add_i)
+            d = _conv1x1(tape, xin.interior(), blk.downsample[0], xin.add_i)
         res = _fuse(tape, d, blk.downsample[1], None, ops.ACT_NONE, 0)
     else:
         res = xin
@@ -287,7 +306,7 @@ def fused_forward(net, x):
 
     y = decoder_stage(x3, net.upconv3, net.iconv3, x2)
     y = decoder_stage(y, net.upconv2, net.iconv2, x1)
-    out = _conv(tape, y.yp, net.out_conv.weight, 1, y.add_p, bias=net.out_conv.bias)
+    out = _conv1x1(tape, y.yp, net.out_conv, y.add_p, channels_last_out=True)
     return out, tape, xin
 
 
@@ -300,7 +319,7 @@ class _FusedResUNet(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        ctx.out.g = d_out.contiguous()           # NCHW for the convolution backward
+        ctx.out.g = d_out                        # any layout: the 1x1 backward addresses it by strides
         for step in reversed(ctx.tape):
             step()
         g = ctx.xin.g

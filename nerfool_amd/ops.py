@@ -401,6 +401,31 @@ def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res,
     return dx, d_res
 
 
+def conv1x1_pack(weight, transposed, device):
+    """weight [c_out, c_in(, 1, 1)] -> MFMA records of nf_conv1x1 (transposed: the backward-data GEMM)"""
+    L = _lib.lib()
+    w = weight.detach().to('cpu', torch.float32).reshape(weight.shape[0], weight.shape[1]).contiguous()
+    out = torch.empty(L.nf_conv1x1_pack_floats(w.shape[0], w.shape[1]), dtype=torch.float32)
+    _lib.check(L.nf_conv1x1_pack(w.data_ptr(), w.shape[0], w.shape[1], int(bool(transposed)), out.data_ptr()), 'nf_conv1x1_pack')
+    return out.to(device)
+
+
+def conv1x1(records, bias, x, c_out, channels_last_out=False):
+    """1x1 convolution of x [N, c_in, H, W] (ANY strides: NCHW, channels-last, subsampled views) -> [N, c_out, H, W]
+    contiguous, or channels-last when channels_last_out."""
+    _f32(x, 'x')
+    N, c_in, H, W = x.shape
+    if channels_last_out:
+        y = torch.empty(N, H, W, c_out, dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+    else:
+        y = torch.empty(N, c_out, H, W, dtype=torch.float32, device=x.device)
+    xs, ys = x.stride(), y.stride()
+    with prof.launch('nf_conv1x1', x, n=y.numel()):
+        _lib.check(_lib.lib().nf_conv1x1(_ptr(records), _ptr(bias), _ptr(x), xs[0], xs[1], xs[2], xs[3], _ptr(y), ys[0], ys[1], ys[2],
+                                         ys[3], N, H, W, c_in, c_out, _stream(x)), 'nf_conv1x1')
+    return y
+
+
 def upsample2x_pad_fwd(x, pad):
     """reflect_pad(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True), pad); x [N,C,h,w] may be the
     interior view of a padded tensor (unit column stride, planes laid out like a contiguous [N,C] grid)."""

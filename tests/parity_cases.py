@@ -446,6 +446,23 @@ def check_fused_cnn_glue(dev):
         dx, _ = ops.in_act_pad_bwd(dyp.to(dev), None, yp, x.to(dev), gamma.to(dev), mean, rstd, ops.ACT_RELU, 1, False,
                                    d_extra_sub=dsub.to(dev))
         assert_close(dx, gx, 1e-3, 1e-4 * float(gx.abs().max()), 'gradient of a stride-2 consumer')
+    # 1x1 convolutions as MFMA GEMMs over the pixels: subsampled / strided input, bias, channels-last output, backward-data
+    for (N, ci, co, H, W, sub, cl) in ((2, 64, 64, 5, 7, False, True), (1, 64, 128, 6, 9, True, False), (1, 32, 40, 4, 5, False, False)):
+        wgt = torch.randn(co, ci, 1, 1, generator=gen) * 0.2
+        bias = torch.randn(co, generator=gen) if cl else None
+        store = torch.randn(N, ci, 2 * H + 2, 2 * W + 2, generator=gen)
+        xv = store[:, :, 1:-1:2, 1:-1:2][:, :, :H, :W] if sub else store[:, :, :H, :W].contiguous()
+        ref = F.conv2d(xv, wgt, bias)
+        sd = store.to(dev)
+        xd = sd[:, :, 1:-1:2, 1:-1:2][:, :, :H, :W] if sub else xv.to(dev)
+        got = ops.conv1x1(ops.conv1x1_pack(wgt, False, dev), None if bias is None else bias.to(dev), xd, co, channels_last_out=cl)
+        assert_close(got, ref, 1e-5, 1e-5, '1x1 convolution')
+        assert got.stride(1) == (1 if cl else H * W)
+        gy = torch.randn(ref.shape, generator=gen)
+        gref = F.conv_transpose2d(gy, wgt)
+        gyd = gy.to(dev).contiguous(memory_format=torch.channels_last) if cl else gy.to(dev)
+        ggot = ops.conv1x1(ops.conv1x1_pack(wgt, True, dev), None, gyd, ci)
+        assert_close(ggot, gref, 1e-5, 1e-5, '1x1 convolution backward-data')
     # decoder: x2 bilinear upsampling (align_corners) fused with the reflect padding, from contiguous and strided sources
     for (N, C, h, w, pad, strided) in ((2, 3, 5, 7, 1, False), (1, 4, 6, 4, 1, True), (1, 2, 1, 3, 0, False)):
         store = torch.randn(N, C, h + 2, w + 2, generator=gen)
