@@ -22,8 +22,8 @@ def parse_camera(params):
 
 
 class RaySamplerSingleImage(object):
-    _cache_key = None
-    _cache_val = None
+    _cache = {}            # insertion-ordered: oldest first
+    _cache_max = 32        # ~65 MB of rays + images per 756x1008 view
 
     def __init__(self, data, device, resize_factor=1, render_stride=1, load_gt_depth=False):
         if resize_factor != 1:
@@ -32,6 +32,7 @@ class RaySamplerSingleImage(object):
             raise NotImplementedError('ground-truth depth (auxiliary depth losses) is outside the attack path')
         self.render_stride = render_stride
         self.device = torch.device(device)
+        self._source = data          # keeps the batch dict alive while this sampler sits in the cache (its id / pointers are the key)
         self.camera = data['camera']
         self.rgb_path = data.get('rgb_path')
         self.depth_range = data['depth_range']
@@ -52,10 +53,13 @@ class RaySamplerSingleImage(object):
         """Same object for the same batch dict (identity of its tensors): the attack loop calls this every iteration."""
         key = (id(data), str(device), tuple(sorted(kw.items())),
                tuple(v.data_ptr() for v in data.values() if torch.is_tensor(v)))
-        if cls._cache_key != key:
-            cls._cache_val = cls(data, device, **kw)
-            cls._cache_key = key
-        return cls._cache_val
+        hit = cls._cache.pop(key, None)           # small LRU: the universal loop cycles over the training views
+        if hit is None:
+            hit = cls(data, device, **kw)
+            while len(cls._cache) >= cls._cache_max:
+                cls._cache.pop(next(iter(cls._cache)))
+        cls._cache[key] = hit
+        return hit
 
     def get_rays_single_image(self, H, W, intrinsics, c2w):
         """rays_d = R * K^-1 * (u, v, 1) without half-pixel offset; rays_o = camera centre (sample_ray.py:98-116)."""
