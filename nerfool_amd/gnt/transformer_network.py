@@ -69,6 +69,7 @@ class _GNTFunction(torch.autograd.Function):
         # the attention-derived weights feed depth maps and the fine resampling only (both detached in the reference's rgb-loss
         # path, gnt/render_ray.py:256): no gradient is propagated through them
         ctx.mark_non_differentiable(alpha)
+        ctx.set_materialize_grads(False)
         return rgb, alpha
 
     @staticmethod

@@ -15,10 +15,13 @@ class _ProjectGather(torch.autograd.Function):
         ctx.save_for_backward(xyz, cam_ws)
         ctx.geom = (src_rgbs.shape[0], src_rgbs.shape[1], src_rgbs.shape[2], tuple(featmaps.shape))
         ctx.mark_non_differentiable(ray_diff, mask)
+        ctx.set_materialize_grads(False)
         return rgb_feat, ray_diff, mask
 
     @staticmethod
     def backward(ctx, d_rgb_feat, _d_ray_diff, _d_mask):
+        if d_rgb_feat is None:
+            return None, None, None, None
         xyz, cam_ws = ctx.saved_tensors
         V, H, W, feat_shape = ctx.geom
         d_feat = ops.project_gather_bwd(xyz, cam_ws, V, H, W, d_rgb_feat, feat_shape)

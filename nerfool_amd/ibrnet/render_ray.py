@@ -30,11 +30,14 @@ class _Composite(torch.autograd.Function):
         ctx.save_for_backward(raw, z_vals)
         ctx.white_bkgd = white_bkgd
         ctx.mark_non_differentiable(ray_mask)
+        ctx.set_materialize_grads(False)          # unused outputs arrive as None instead of freshly zero-filled tensors
         return rgb, depth, weights, alpha, ray_mask
 
     @staticmethod
     def backward(ctx, d_rgb, d_depth, d_weights, d_alpha, _d_mask):
         raw, z_vals = ctx.saved_tensors
+        if d_rgb is None:
+            d_rgb = torch.zeros(raw.shape[0], 3, dtype=raw.dtype, device=raw.device)
         d_raw = ops.composite_bwd(raw, z_vals, ctx.white_bkgd, d_rgb, d_depth, d_weights, d_alpha)
         return d_raw, None, None, None
 
