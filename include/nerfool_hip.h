@@ -173,6 +173,21 @@ int nf_conv1x1(const float* records, const float* bias, const float* x, int64_t 
                nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * a14  ResUNet 3x3 stride-1 convolutions as Winograd F(2x2, 3x3) on the fp32 matrix cores.
+ *      ref: ibrnet/feature_network.py:28-36, 38-78, 127-151 (reflect padding is already in the input, see nf_in_act_pad_fwd).
+ *   y[n, k, oy, ox] = sum_c sum_{a,b<3} x[n, c, oy + a - pad, ox + b - pad] W[k][c][a][b], zeros outside x, output Ho x Wo.
+ *   forward: pad = 0, Ho = Hi - 2; backward-data: x = d y, pad = 2, Ho = Hi + 2, records packed with backward != 0.
+ *   `records` = nf_wino_pack(weight [c_out][c_in][3][3], ..., k_per_group in {32, 64}) (HOST pointers).
+ *   tile_blocks: 1 or 2 blocks of 32 Winograd tiles per wave (8 x 16 or 16 x 16 output pixels per workgroup), 0 = choose.
+ *   x, y: element strides (image, channel, row), unit column stride.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int64_t nf_wino_pack_floats(int c_out, int c_in, int k_per_group);
+int nf_wino_pack(const float* weight_host, int c_out, int c_in, int backward, int k_per_group, float* records_host);
+int nf_conv3x3_wino(const float* records, int k_per_group, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi,
+                    int pad, float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out,
+                    int tile_blocks, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * a11/a13  perturbation update             ref: eval/ibrnet/eval_adv.py:28-29, :248-254, :805-839
  * All tensors flat [n] (delta, grad, exp_avg, exp_avg_sq, src all shaped [1,V,H,W,3]).
  *   nf_project_perturb : delta = max(min(delta, eps), -eps) (skipped if eps < 0); delta = max(min(delta, hi-src), lo-src)

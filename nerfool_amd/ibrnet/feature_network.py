@@ -174,7 +174,69 @@ class _Act:
         self.gs = g if self.gs is None else self.gs + g
 
 
+# 3x3 stride-1 convolutions: 'auto' times MIOpen against the Winograd matrix-core kernel (csrc/nf_wino.hip) once per
+# (shape, direction) on first use and keeps the faster one; 'wino' / 'miopen' force a side (NERFOOL_CONV3X3)
+CONV3X3 = os.environ.get('NERFOOL_CONV3X3', 'auto')
+_CONV_CHOICE = {}
+
+
+def _time_us(fn, iters=3):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def _pick(key, miopen_fn, wino_fn):
+    """which implementation runs this convolution: decided once per key"""
+    if CONV3X3 in ('wino', 'miopen'):
+        return CONV3X3
+    if key not in _CONV_CHOICE:
+        _CONV_CHOICE[key] = 'wino' if _time_us(wino_fn) < _time_us(miopen_fn) else 'miopen'
+    return _CONV_CHOICE[key]
+
+
+def _wino_records(conv_w):
+    key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
+    cache = _WINO_CACHE.get(id(conv_w))
+    if cache is None or cache[0] != key:
+        cache = (key, ops.wino_pack(conv_w, False, conv_w.device), ops.wino_pack(conv_w, True, conv_w.device))
+        _WINO_CACHE[id(conv_w)] = cache
+    return cache
+
+
+_WINO_CACHE = {}
+
+
+def _conv3x3(tape, inp, w, sink):
+    """3x3 stride-1 convolution on a pre-padded activation (padding 0) and its backward-data pass"""
+    c_out, c_in = w.shape[0], w.shape[1]
+    use_gpu_timing = inp.is_cuda
+    rec = _wino_records(w)
+    mio_f = lambda: _aten.convolution(inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+    win_f = lambda: ops.conv3x3_wino(rec[1], inp, c_out, 0)
+    how_f = _pick(('f', c_in, c_out) + tuple(inp.shape), mio_f, win_f) if use_gpu_timing else ('wino' if CONV3X3 != 'miopen' else 'miopen')
+    out = _Slot(win_f() if how_f == 'wino' else mio_f())
+
+    def bwd():
+        g_out = out.g
+        mio_b = lambda: _aten.convolution_backward(g_out, inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                   [True, False, False])[0]
+        win_b = lambda: ops.conv3x3_wino(rec[2], g_out, c_in, 2)
+        how_b = _pick(('b', c_in, c_out) + tuple(inp.shape), mio_b, win_b) if use_gpu_timing else ('wino' if CONV3X3 != 'miopen' else 'miopen')
+        sink(win_b() if how_b == 'wino' else mio_b())
+        out.g = None
+    tape.append(bwd)
+    return out
+
+
 def _conv(tape, inp, w, stride, sink, bias=None):
+    if stride == 1 and bias is None and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 32 == 0:
+        return _conv3x3(tape, inp, w, sink)
     out = _Slot(_aten.convolution(inp, w, bias, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1))
 
     def bwd():

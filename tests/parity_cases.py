@@ -446,6 +446,17 @@ def check_fused_cnn_glue(dev):
         dx, _ = ops.in_act_pad_bwd(dyp.to(dev), None, yp, x.to(dev), gamma.to(dev), mean, rstd, ops.ACT_RELU, 1, False,
                                    d_extra_sub=dsub.to(dev))
         assert_close(dx, gx, 1e-3, 1e-4 * float(gx.abs().max()), 'gradient of a stride-2 consumer')
+    # 3x3 stride-1 convolutions as Winograd F(2x2,3x3) on the matrix cores: forward (padding 0) and backward-data, ragged sizes
+    for (N, ci, co, H, W) in ((1, 16, 32, 9, 18), (2, 32, 64, 7, 21), (1, 48, 96, 16, 16)):
+        wgt = torch.randn(co, ci, 3, 3, generator=gen) * 0.2
+        xin = torch.randn(N, ci, H + 2, W + 2, generator=gen)
+        ref = F.conv2d(xin, wgt)
+        got = ops.conv3x3_wino(ops.wino_pack(wgt, False, dev), xin.to(dev), co, 0)
+        assert_close(got, ref, 1e-4, 1e-4 * float(ref.abs().max()), 'Winograd 3x3 forward')
+        gy = torch.randn(ref.shape, generator=gen)
+        gref = F.conv_transpose2d(gy, wgt)
+        ggot = ops.conv3x3_wino(ops.wino_pack(wgt, True, dev), gy.to(dev), ci, 2)
+        assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'Winograd 3x3 backward-data')
     # 1x1 convolutions as MFMA GEMMs over the pixels: subsampled / strided input, bias, channels-last output, backward-data
     for (N, ci, co, H, W, sub, cl) in ((2, 64, 64, 5, 7, False, True), (1, 64, 128, 6, 9, True, False), (1, 32, 40, 4, 5, False, False)):
         wgt = torch.randn(co, ci, 1, 1, generator=gen) * 0.2

@@ -1,0 +1,56 @@
+"""3x3 stride-1 convolutions of the ResUNet at BASELINE config 2 sizes: MIOpen (aten.convolution / convolution_backward on the
+pre-padded activation) vs the Winograd matrix-core kernel (csrc/nf_wino.hip).  usage: python tools/bench_conv3x3.py [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nerfool_amd import ops                                   # noqa: E402
+
+aten = torch.ops.aten
+
+
+def timed(fn, iters):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3, out
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    tot_m = tot_w = 0.0
+    #        cin cout   H    W   count (forward + backward pairs per PGD step)
+    for (ci, co, H, W, count) in ((64, 64, 189, 252, 6), (128, 128, 95, 126, 7), (256, 256, 48, 63, 11), (256, 128, 96, 126, 2),
+                                  (128, 64, 192, 252, 2)):
+        x = torch.randn(4, ci, H + 2, W + 2, device=dev)
+        w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+        rf, rb = ops.wino_pack(w, False, dev), ops.wino_pack(w, True, dev)
+        t_mf, y = timed(lambda: aten.convolution(x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1), iters)
+        g = torch.randn_like(y)
+        t_mb, dx = timed(lambda: aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0], iters)
+        t_wf, y2 = timed(lambda: ops.conv3x3_wino(rf, x, co, 0), iters)
+        t_wb, dx2 = timed(lambda: ops.conv3x3_wino(rb, g, ci, 2), iters)
+        t1 = [timed(lambda: ops.conv3x3_wino(rf, x, co, 0, tb), iters)[0] for tb in (1, 2)] + [timed(lambda: ops.conv3x3_wino(rb, g, ci, 2, tb), iters)[0] for tb in (1, 2)]
+        fl = 2.0 * 4 * H * W * ci * co * 9
+        err_f = float((y - y2).abs().max() / y.abs().max())
+        err_b = float((dx - dx2).abs().max() / dx.abs().max())
+        tot_m += count * (t_mf + t_mb)
+        tot_w += count * (t_wf + t_wb)
+        print('      tile blocks 1 / 2: fwd %.1f / %.1f us, bwd %.1f / %.1f us' % tuple(t1))
+        print('%3d->%3d %3dx%3d: MIOpen fwd %6.1f us (%5.1f TF) bwd %6.1f us | Winograd MFMA fwd %6.1f us (%5.1f TF) bwd %6.1f us | rel err %.1e %.1e  x%d'
+              % (ci, co, H, W, t_mf, fl / t_mf / 1e6, t_mb, t_wf, fl / t_wf / 1e6, t_wb, err_f, err_b, count), flush=True)
+    print('weighted per step: MIOpen %.2f ms, Winograd MFMA %.2f ms' % (tot_m / 1e3, tot_w / 1e3))
+
+
+if __name__ == '__main__':
+    main()
