@@ -28,6 +28,15 @@ const char* nf_last_error(void);
 int nf_device_cu_count(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * a1  random pixel pick of one PGD iteration    ref: ibrnet/sample_ray.py:12 (RandomState(234)), :149-171
+ *     (`rng.choice(H*W, size=(N_rand,), replace=False)`).  HOST-only, no GPU work, safe to call from any thread.
+ * out[0..size) = numpy.random.RandomState.choice(pop, size, replace=False) for the MT19937 state (key[624], *pos) --
+ * i.e. permutation(pop)[:size] -- and the state is advanced in place exactly as numpy advances it.
+ * All pointers are HOST pointers; scratch holds pop int64.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int nf_legacy_choice(uint32_t* key, int32_t* pos, int64_t pop, int64_t size, int64_t* out, int64_t* scratch);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * a2  sample_along_camera_ray            ref: ibrnet/render_ray.py:73-116
  * depth_range: device [2] = (near, far).  t_rand: nullable [R,S] uniform numbers (det=False stratified jitter).
  * Writes z_vals [R,S] and pts [R,S,3].

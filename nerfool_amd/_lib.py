@@ -73,6 +73,7 @@ _PROTOTYPES = {
     'nf_in_act_pad_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64,
                                   _P, _P]),
     'nf_upsample2x_pad_fwd': (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, _P]),
+    'nf_legacy_choice': (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     'nf_project_perturb': (c_int, [_P, _P, c_int64, c_float, c_float, c_float, _P]),
     'nf_pgd_adam_step': (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float,
                                  c_float, c_float, c_float, _P]),

@@ -50,20 +50,22 @@ def _is_gnt(model):
 
 
 def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, return_loss=True, select_inds=None,
-                         shard=None, criterion=None):
+                         shard=None, criterion=None, lookahead=False):
     """One loss evaluation of the attack (eval_adv.py:258-310,512-519): draw N_rand rays of the target view `data`,
     features from the PERTURBED source images, colours from the CLEAN ones, masked MSE on coarse + fine.
 
     select_inds: optional explicit pixel indices (otherwise drawn from the reference's RandomState(234) stream).
     shard: optional `RayShard` -- this rank renders its slice of the drawn rays and the loss denominators are the
-    all-reduced mask counts."""
+    all-reduced mask counts.
+    lookahead: the caller is a PGD loop that will draw again -- the next iteration's pixel pick is prepared on a helper
+    thread (same RandomState stream, see ibrnet/sample_ray.py)."""
     _reject_out_of_scope(args)
     device = delta.device
     sampler = RaySamplerSingleImage.cached(data, device)
     if select_inds is None:
         n_draw = args.N_rand * (shard.world if shard is not None else 1)
         select_inds = sampler.sample_random_pixel(n_draw, getattr(args, 'sample_mode', 'uniform'),
-                                                  getattr(args, 'center_ratio', 0.8))
+                                                  getattr(args, 'center_ratio', 0.8), lookahead=lookahead)
         if shard is not None:
             select_inds = select_inds[shard.rank::shard.world]
     train_ray_batch = sampler.select(select_inds)
@@ -220,10 +222,10 @@ class PGDAttack:
         gamma = getattr(self.args, 'lr_gamma', 0.5)
         return self.args.adam_lr * gamma ** (self.iters // step_size)     # StepLR stepped after every opt.step()
 
-    def gradient(self, data, select_inds=None):
+    def gradient(self, data, select_inds=None, lookahead=True):
         self.delta.grad = None
         loss, _ = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data,
-                                       return_loss=True, select_inds=select_inds, shard=self.shard)
+                                       return_loss=True, select_inds=select_inds, shard=self.shard, lookahead=lookahead)
         loss.backward()
         grad = self.delta.grad
         if self.shard is not None:
@@ -241,8 +243,10 @@ class PGDAttack:
             self.iters += 1
             ops.pgd_sign_step_(self.delta.data, grad, src, self.alpha, self.epsilon)
 
-    def step(self, data, select_inds=None):
-        self.apply(self.gradient(data, select_inds))
+    def step(self, data, select_inds=None, lookahead=True):
+        """lookahead: prepare the next step's pixel pick off-thread (harmless if no next step follows: the RandomState(234)
+        stream only advances when a pick is consumed)."""
+        self.apply(self.gradient(data, select_inds, lookahead))
         return self.last_loss
 
     def run_view_specific(self, data, n_iters=None):

@@ -6,11 +6,60 @@ Host-side component.  Differences from the reference, none observabl
   * the pixel grid / ray directions are built on `device` once and can be re-used across PGD iterations through
     `RaySamplerSingleImage.cached(data, device)`, instead of re-running meshgrid + H*W bmm on the CPU and re-uploading
     the source images every iteration (eval/ibrnet/eval_adv.py:264),
-  * pixel picks come from the same module-global `RandomState(234)` stream (`rng`)."""
+  * pixel picks come from the same module-global `RandomState(234)` stream (`rng`); with `lookahead=True` the pick of the
+    NEXT call is computed ahead on a helper thread by the library's restatement of numpy's legacy choice
+    (nf_legacy_choice, csrc/nf_pixel_draw.hip) on a copy of the generator state, and adopted -- state included -- only if
+    that next call asks for the same draw and nobody touched `rng` in between: the stream any caller observes is unchanged."""
+import ctypes
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
+from .. import _lib
+
 rng = np.random.RandomState(234)
+
+_pool = None
+_ahead = None            # (pop, size, generator object, its state when the job was queued, future)
+_scratch = {}            # helper-thread scratch per population size
+
+
+def legacy_choice(state, pop, size):
+    """RandomState.choice(pop, size=(size,), replace=False) computed by the library for the generator state `state`
+    (a `RandomState.get_state()` tuple, not modified): returns (picks, advanced state tuple)."""
+    key = np.array(state[1], dtype=np.uint32)
+    pos = ctypes.c_int32(int(state[2]))
+    out = np.empty((size,), dtype=np.int64)
+    scratch = _scratch.get(pop)
+    if scratch is None:
+        _scratch.clear()
+        scratch = _scratch[pop] = np.empty((pop,), dtype=np.int64)
+    _lib.check(_lib.lib().nf_legacy_choice(key.ctypes.data, ctypes.byref(pos), pop, size, out.ctypes.data, scratch.ctypes.data),
+               'nf_legacy_choice')
+    return out, (state[0], key, pos.value) + tuple(state[3:])
+
+
+def _choice(pop, size, lookahead):
+    """The next `rng.choice(pop, size=(size,), replace=False)` of the stream; lookahead=True also queues the one after it."""
+    global _pool, _ahead
+    pick = None
+    if _ahead is not None:
+        a_pop, a_size, gen, st, fut = _ahead
+        _ahead = None
+        ahead_pick, ahead_state = fut.result()
+        cur = rng.get_state()
+        if gen is rng and (a_pop, a_size) == (pop, size) and cur[2] == st[2] and np.array_equal(cur[1], st[1]):
+            rng.set_state(ahead_state)
+            pick = ahead_pick
+    if pick is None:
+        pick = rng.choice(pop, size=(size,), replace=False)
+    if lookahead:
+        if _pool is None:
+            _pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='nerfool-pixel-draw')
+        st = rng.get_state()
+        _ahead = (pop, size, rng, st, _pool.submit(legacy_choice, st, pop, size))
+    return pick
 
 
 def parse_camera(params):
@@ -83,24 +132,29 @@ class RaySamplerSingleImage(object):
         ret.update(self._common())
         return ret
 
-    def sample_random_pixel(self, N_rand, sample_mode, center_ratio=0.8):
+    def sample_random_pixel(self, N_rand, sample_mode, center_ratio=0.8, lookahead=False):
+        """lookahead=True: the caller will ask for the same draw again (a PGD loop); the next pick is prepared off-thread."""
         if sample_mode == 'center':
             border_H = int(self.H * (1 - center_ratio) / 2.)
             border_W = int(self.W * (1 - center_ratio) / 2.)
             u, v = np.meshgrid(np.arange(border_H, self.H - border_H), np.arange(border_W, self.W - border_W))
             u, v = u.reshape(-1), v.reshape(-1)
-            pick = rng.choice(u.shape[0], size=(N_rand,), replace=False)
+            pick = _choice(u.shape[0], N_rand, lookahead)
             return v[pick] + self.W * u[pick]
         if sample_mode == 'uniform':
-            return rng.choice(self.H * self.W, size=(N_rand,), replace=False)
+            return _choice(self.H * self.W, N_rand, lookahead)
         raise Exception('unknown sample mode!')
 
-    def random_sample(self, N_rand, sample_mode, center_ratio=0.8):
-        select_inds = self.sample_random_pixel(N_rand, sample_mode, center_ratio)
+    def random_sample(self, N_rand, sample_mode, center_ratio=0.8, lookahead=False):
+        select_inds = self.sample_random_pixel(N_rand, sample_mode, center_ratio, lookahead)
         return self.select(select_inds)
 
     def select(self, select_inds):
-        idx = torch.as_tensor(np.asarray(select_inds), dtype=torch.long, device=self.device)
+        host = torch.from_numpy(np.ascontiguousarray(select_inds, dtype=np.int64))
+        if self.device.type == 'cuda':      # pinned staging + stream-ordered copy: the host does not wait for the GPU queue
+            idx = host.pin_memory().to(self.device, non_blocking=True)
+        else:
+            idx = host.to(self.device)
         ret = {'ray_o': self.rays_o[idx], 'ray_d': self.rays_d[idx], 'rgb': None if self.rgb is None else self.rgb[idx],
                'selected_inds': select_inds, 'depth': None}
         ret.update(self._common())

@@ -12,9 +12,13 @@ _active = None
 
 
 class KernelTimer:
-    def __init__(self):
+    def __init__(self, only=None):
+        """only: iterable of entry-point names to time (None = every launch).  Two event records cost ~6 us of host time,
+        which matters once a step is ~250 launches and close to launch-bound: bench.py times only the kernels its roofline
+        table prices inside the timed region."""
         self.pairs = defaultdict(list)
         self.meta = defaultdict(list)
+        self.only = None if only is None else frozenset(only)
 
     def summary(self):
         """name -> (launches, mean ms, total ms, list of per-launch metadata) -- synchronises once."""
@@ -40,7 +44,7 @@ def timing(timer):
 @contextlib.contextmanager
 def launch(name, tensor, **meta):
     """Bracket one C-ABI call; a no-op unless a timer is active and `tensor` lives on a GPU."""
-    if _active is None or not tensor.is_cuda:
+    if _active is None or not tensor.is_cuda or (_active.only is not None and name not in _active.only):
         yield
         return
     a = torch.cuda.Event(enable_timing=True)

@@ -71,3 +71,53 @@ def test_cpu_tensor_is_rejected_without_gpu(monkeypatch):
     monkeypatch.setattr(_lib, '_emulated', False)
     with pytest.raises(RuntimeError, match='GPU only'):
         ops.sample_along_ray(torch.zeros(4, 3), torch.ones(4, 3), torch.tensor([[2., 6.]]), 8, True)
+
+
+def test_legacy_choice_matches_numpy(built_library):
+    """Host-only ABI call: nf_legacy_choice consumes an MT19937 stream exactly like RandomState.choice(replace=False)
+    (the reference's pixel pick, ibrnet/sample_ray.py:149-171), picks and advanced generator state bit for bit."""
+    import numpy as np
+    from nerfool_amd import _lib
+    from nerfool_amd.ibrnet import sample_ray
+    if _lib._lib is None:
+        _lib.use_library_for_tests(built_library, emulated=False)
+    gen = np.random.RandomState(234)
+    for pop, size in ((756 * 1008, 512), (1, 1), (2, 2), (97, 0), (4096, 4096), (604 * 806, 4096), (65537, 300)):
+        for _ in range(3):
+            state = gen.get_state()
+            mine, after = sample_ray.legacy_choice(state, pop, size)
+            want = gen.choice(pop, size=(size,), replace=False)
+            assert mine.dtype == want.dtype and np.array_equal(mine, want), (pop, size)
+            now = gen.get_state()
+            assert after[2] == now[2] and np.array_equal(after[1], now[1]) and after[3:] == now[3:]
+            gen.random_sample(5)        # move the position around between the draws, including across refills
+    handle = _lib.lib()
+    key = np.zeros(624, np.uint32)
+    pos = ctypes.c_int32(0)
+    out = np.zeros(4, np.int64)
+    assert handle.nf_legacy_choice(key.ctypes.data, ctypes.byref(pos), 3, 4, out.ctypes.data, out.ctypes.data) != 0
+    assert b'without replacement' in handle.nf_last_error()
+
+
+def test_pixel_lookahead_keeps_the_stream(built_library):
+    """The look-ahead draw is invisible in the RandomState(234) stream: same picks as plain draws, also when the next call
+    asks for something else, when somebody reseeds in between, and when a queued pick is never consumed."""
+    import numpy as np
+    from nerfool_amd import _lib
+    from nerfool_amd.ibrnet import sample_ray
+    if _lib._lib is None:
+        _lib.use_library_for_tests(built_library, emulated=False)
+    plain = np.random.RandomState(234)
+    sample_ray.rng.seed(234)
+    for pop, size, ahead in ((5000, 64, True), (5000, 64, True), (5000, 64, True), (7000, 64, True), (7000, 32, False),
+                             (7000, 32, True)):
+        got = sample_ray._choice(pop, size, ahead)
+        assert np.array_equal(got, plain.choice(pop, size=(size,), replace=False))
+    assert sample_ray._ahead is not None
+    sample_ray.rng.seed(234)                      # a queued pick from the old state must not survive a reseed
+    plain.seed(234)
+    assert np.array_equal(sample_ray._choice(7000, 32, True), plain.choice(7000, size=(32,), replace=False))
+    assert np.array_equal(sample_ray.rng.random_sample(3), plain.random_sample(3))      # direct use while a pick is queued
+    assert np.array_equal(sample_ray._choice(7000, 32, False), plain.choice(7000, size=(32,), replace=False))
+    assert sample_ray._ahead is None
+    assert np.array_equal(sample_ray.rng.get_state()[1], plain.get_state()[1])
