@@ -10,15 +10,26 @@
 // 4x4 transformed tile (xi = (w, nu), nu = 0..3): it builds ITS rows of B^T d B straight from the raw input patch in LDS
 // (two patch rows, one 4-wide column transform: 8 adds per 4 B operands) -- V never exists in memory -- and keeps
 // 4 x KB accumulator tiles.  The column half of A^T M A is local to a wave, the row half crosses the waves through LDS.
-// 2.25x fewer multiplies than the direct form.  The weight records run through a four-deep register ring (three steps in
-// flight); the next chunk's input window is fetched into registers half a chunk ahead and committed to the second LDS buffer
-// behind the current chunk's multiplications (one barrier per chunk); two workgroups per CU.
-// Measured and dropped (tools/bench_conv3x3.py, 64 -> 64 at 189 x 252: 100 us for this form): two tile blocks per wave at one
-// workgroup per CU (130 us), B operands loaded straight from global memory without LDS (152 us), deeper weight ring (no change).
+// 2.25x fewer multiplies than the direct form.
+// Data movement: the accumulators take 128 of a lane's registers, so nothing else may live in registers for long.
+//   * weights: every wave streams ITS records from L2 into a private LDS ring by LDS-DMA (global_load_lds_dwordx4: 1 KB per
+//     instruction, no register in between), WN_SLOTS - 2 = 4 steps ahead, and reads a step's A operands back with ds_read_b128;
+//   * input: the next chunk's raw window is fetched into 12 registers at the top of a chunk and committed to the second LDS
+//     buffer at its end (one barrier per chunk).
+//   Both streams share the wave's in-order VM counter.  The DMA is issued from inline asm and waited for with exact counted
+//   s_waitcnt vmcnt(N) (the window fetch is a FIXED six loads per wave, see fetch_seg), so a weight wait never has to sit out the
+//   HBM latency of the window fetch issued behind it -- with the earlier register ring that coupling cost 12-23 % (measured by
+//   dropping the fetch).  Two workgroups per CU (78 KB of LDS each).
+// Measured and dropped (tools/bench_conv3x3.py, 64 -> 64 at 189 x 252): two tile blocks per wave at one workgroup per CU
+// (+30 %), B operands loaded straight from global memory without LDS (+50 %), weights through a four-deep register ring (the
+// previous form of this kernel).
 #include "nf_common.h"
+
+#include <type_traits>
 
 typedef float w16 __attribute__((ext_vector_type(16)));
 typedef float w2f __attribute__((ext_vector_type(2), aligned(4)));
+typedef float w4f __attribute__((ext_vector_type(4)));
 #define WN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 __host__ __device__ constexpr int wn_nidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -31,7 +42,7 @@ extern "C" int64_t nf_wino_pack_floats(int c_out, int c_in, int k_per_group) {
     return (int64_t)groups * 4 * chunks * 8 * 4 * (k_per_group / 32) * 64 + 4096;      // + room for the last prefetch past the end
 }
 
-/* HOST: weight [c_out][c_in][3][3] -> U = G g G^T in record order [group][wave][chunk][step][nu][kb][64 lanes].
+/* HOST: weight [c_out][c_in][3][3] -> U = G g G^T as the four waves' streams [group][wave][chunk][step][piece][lane][4].
  * backward != 0 packs the backward-data convolution: g'[c][k][a][b] = g[k][c][2-a][2-b], roles of c_out / c_in swapped
  * (the records then describe a convolution with `c_in` OUTPUT channels). */
 extern "C" int nf_wino_pack(const float* weight, int c_out, int c_in, int backward, int k_per_group, float* out) {
@@ -41,13 +52,15 @@ extern "C" int nf_wino_pack(const float* weight, int c_out, int c_in, int backwa
     const int KB = k_per_group / 32, groups = (N + k_per_group - 1) / k_per_group, chunks = (C + WN_CC - 1) / WN_CC;
     const int64_t total = nf_wino_pack_floats(N, C, k_per_group);
     for (int64_t i = total - 4096; i < total; ++i) out[i] = 0.f;
-    float* rec = out;
+    // a step's 4 * KB records (index i = nu * KB + kb) travel as KB pieces of 1 KB: piece p = records 4p .. 4p + 3, lane-major
+    // ([lane][4]) -- one global_load_lds_dwordx4 moves a piece, one ds_read_b128 hands a lane its four A operands
+    float* step = out;
     for (int g = 0; g < groups; ++g)
         for (int w = 0; w < 4; ++w)
             for (int ch = 0; ch < chunks; ++ch)
-                for (int s = 0; s < 8; ++s)
+                for (int s = 0; s < 8; ++s, step += 4 * KB * 64)
                     for (int nu = 0; nu < 4; ++nu)
-                        for (int kb = 0; kb < KB; ++kb, rec += 64)
+                        for (int kb = 0; kb < KB; ++kb)
                             for (int lane = 0; lane < 64; ++lane) {
                                 const int k = g * k_per_group + kb * 32 + (lane & 31), c = ch * WN_CC + 2 * s + (lane >> 5);
                                 float u = 0.f;
@@ -59,78 +72,129 @@ extern "C" int nf_wino_pack(const float* weight, int c_out, int c_in, int backwa
                                             u += G[w][a] * gv * G[nu][b];
                                         }
                                 }
-                                rec[lane] = u;
+                                const int i = nu * KB + kb;
+                                step[((i >> 2) * 64 + lane) * 4 + (i & 3)] = u;
                             }
     return 0;
 }
 
 struct WnTensor { int64_t ns, cs, rs; };        // element strides: image, channel, row (unit column stride)
 
+// Ring slots per wave.  A step's records are issued WN_SLOTS - 2 steps before they are used, into the slot that was read TWO
+// steps earlier: the wait of the step in between also retires the wave's LDS reads (lgkmcnt(0)), so a refill can never
+// overtake a read of the slot it overwrites.  (Refilling the slot read ONE step earlier -- a distance of WN_SLOTS - 1 --
+// corrupted a few outputs per launch on the large layers: an L2-hit DMA can land within ~250 cycles, before a read still
+// queued behind the neighbour workgroup's LDS traffic has executed.)
+#define WN_SLOTS 6
+#define WN_FETCH_OPS 6      // VM instructions one window fetch issues per wave (two segments x three 8-byte loads)
+
+// ---- the three device-only primitives of the weight ring (their host forms keep the file compilable in the host pass)
+// wave-uniform value in a scalar register
+__device__ __forceinline__ int wn_uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+// LDS-DMA of one piece: lane l moves 16 bytes from gsrc + 4 l (floats) to dst + 4 l; no VGPR destination, counted on vmcnt
+__device__ __forceinline__ void wn_dma16(const float* gsrc, float* dst, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned keep;
+    const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane * 16), "s"(lds), "s"(gsrc)
+                 : "memory");
+#else
+    for (int j = 0; j < 4; ++j) dst[4 * lane + j] = gsrc[4 * lane + j];
+#endif
+}
+// wait until at most N of this wave's VM operations are outstanding (they retire in issue order) and all its LDS reads returned
+template <int N>
+__device__ __forceinline__ void wn_wait_vm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+#endif
+}
+
 template <int KB>
 __global__ void __launch_bounds__(256, 2) k_wino3x3(const float* __restrict__ rec, const float* __restrict__ x, WnTensor xi, int Hi, int Wi,
                                                     int pad, float* __restrict__ y, WnTensor yo, int Ho, int Wo, int C, int K, int groups) {
-    // two buffers of the raw input window of a 16-channel chunk; after the last chunk the same memory carries the row half of
-    // the output transform from wave to wave
+    // LDS: two buffers of the raw input window of a 16-channel chunk | one weight ring per wave; after the last chunk the same
+    // memory carries the row half of the output transform from wave to wave
     constexpr int WN_PR = 10, WN_CH = WN_PR * WN_PS, WN_BUF = WN_CC * WN_CH;
-    __shared__ float smem[(KB * 8192 > 2 * WN_BUF) ? KB * 8192 : 2 * WN_BUF];
+    constexpr int STEP = 4 * KB * 64;                 // floats of one step's records = KB pieces of 256
+    constexpr int DIST = WN_SLOTS - 2;
+    HIP_DYNAMIC_SHARED(float, smem)
     float* ex = smem;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wn_uniform(threadIdx.x >> 6);
     const int t = lane & 31, hh = lane >> 5, tr = t >> 3, tc = t & 7;
     const int n = blockIdx.z / groups, grp = blockIdx.z - n * groups;
     const int oy0 = blockIdx.y * 8, ox0 = blockIdx.x * 16;
     const int iy0 = oy0 - pad, ix0 = ox0 - pad;
     const int chunks = (C + WN_CC - 1) / WN_CC;
     const float* xn = x + n * xi.ns;
-    // this wave's weight stream: [chunk][step][nu][kb] records, consumed strictly in order
-    const float* wr = rec + ((size_t)(grp * 4 + w) * chunks) * (8 * 4 * KB * 64) + lane;
+    // this wave's weight stream: [chunk][step] x STEP floats, consumed strictly in order
+    const float* wsrc = rec + ((size_t)(grp * 4 + w) * chunks) * (8 * STEP);
+    float* ring = smem + 2 * WN_BUF + w * (WN_SLOTS * STEP);
     // B^T d B, row w: which two window rows, and the sign of the second
     const int ra = w == 0 ? 0 : (w == 2 ? 2 : 1), rb = w == 0 ? 2 : (w == 1 ? 2 : (w == 2 ? 1 : 3));
     const float sb = w == 1 ? 1.f : -1.f;
     const int lbase = (2 * tr) * WN_PS + 2 * tc;
 
     // staging: the 160 rows (16 channels x 10) of a chunk's window are cut into 480 segments of 6 floats; thread j owns segments
-    // j and j + 256: three 8-byte loads each when the segment lies inside the image, element-wise with zero fill at the border.
-    // Fetched into registers half a chunk ahead, committed to the OTHER buffer behind the chunk's multiplications.
+    // j and j + 256.  A segment is ALWAYS three 8-byte loads (the weight ring counts on it): a pair that straddles or leaves the
+    // image is read from the nearest in-image pair position and its elements are picked / zeroed afterwards.
     const int seg_a = threadIdx.x, seg_b = threadIdx.x + 256;
     const bool has_b = seg_b < WN_CC * WN_PR * 3;
     float pre[2][6];
-    auto fetch_seg = [&](int chunk, int sg, float (&dst)[6]) {
+    // where a segment's three pairs come from / which of their elements are real (recomputed at commit time: nothing but the
+    // raw pairs stays in registers while the loads are in flight, and nothing touches them before the commit)
+    auto seg_geom = [&](int chunk, int sg, int& c, int& gy, int& gx0, bool& row_ok) {
         const int j = sg / 3, part = sg - 3 * j;
         const int ch = j / WN_PR, pr = j - ch * WN_PR;
-        const int c = chunk * WN_CC + ch, gy = iy0 + pr, gx0 = ix0 + 6 * part;
-        const bool row_ok = c < C && gy >= 0 && gy < Hi;
+        c = chunk * WN_CC + ch, gy = iy0 + pr, gx0 = ix0 + 6 * part;
+        row_ok = c < C && gy >= 0 && gy < Hi;
+    };
+    auto fetch_seg = [&](int chunk, int sg, float (&raw)[6]) {
+        int c, gy, gx0;
+        bool row_ok;
+        seg_geom(chunk, sg, c, gy, gx0, row_ok);
         const float* src = xn + (row_ok ? c : 0) * xi.cs + (row_ok ? gy : 0) * xi.rs;
-        if (row_ok && gx0 >= 0 && gx0 + 6 <= Wi) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const w2f v = *reinterpret_cast<const w2f*>(src + gx0 + 2 * q);
-                dst[2 * q] = v[0];
-                dst[2 * q + 1] = v[1];
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int gx = gx0 + q;
-                const bool ok = row_ok && gx >= 0 && gx < Wi;
-                const float v = src[ok ? gx : 0];
-                dst[q] = ok ? v : 0.f;
-            }
+        for (int q = 0; q < 3; ++q) {
+            const int a = gx0 + 2 * q;
+            const int start = a < 0 ? 0 : (a > Wi - 2 ? Wi - 2 : a);
+            const w2f v = *reinterpret_cast<const w2f*>(src + start);
+            raw[2 * q] = v[0];
+            raw[2 * q + 1] = v[1];
         }
     };
-    auto commit_seg = [&](int buf, int sg, const float (&src)[6]) {
+    auto commit_seg = [&](int chunk, int sg, const float (&raw)[6]) {
+        int c, gy, gx0;
+        bool row_ok;
+        seg_geom(chunk, sg, c, gy, gx0, row_ok);
         const int j = sg / 3, part = sg - 3 * j;
         const int ch = j / WN_PR, pr = j - ch * WN_PR;
-        float* dst = smem + buf * WN_BUF + ch * WN_CH + pr * WN_PS + 6 * part;
+        float* dst = smem + (chunk & 1) * WN_BUF + ch * WN_CH + pr * WN_PS + 6 * part;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<w2f*>(dst + 2 * q) = w2f{src[2 * q], src[2 * q + 1]};
+        for (int q = 0; q < 3; ++q) {
+            const int a = gx0 + 2 * q;
+            const bool same = a >= 0 && a <= Wi - 2;          // the pair was read where it lies
+            const bool ok0 = row_ok && a >= 0 && a < Wi, ok1 = row_ok && a + 1 >= 0 && a + 1 < Wi;
+            const float v0 = ok0 ? (same ? raw[2 * q] : raw[2 * q + 1]) : 0.f;
+            const float v1 = ok1 ? (same ? raw[2 * q + 1] : raw[2 * q]) : 0.f;
+            *reinterpret_cast<w2f*>(dst + 2 * q) = w2f{v0, v1};
+        }
     };
     auto fetch = [&](int chunk) {
         fetch_seg(chunk, seg_a, pre[0]);
         if (has_b) fetch_seg(chunk, seg_b, pre[1]);
     };
-    auto commit = [&](int buf) {
-        commit_seg(buf, seg_a, pre[0]);
-        if (has_b) commit_seg(buf, seg_b, pre[1]);
+    auto commit = [&](int chunk) {          // into buffer chunk & 1
+        commit_seg(chunk, seg_a, pre[0]);
+        if (has_b) commit_seg(chunk, seg_b, pre[1]);
     };
 
     w16 acc[4][KB];
@@ -141,26 +205,45 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3(const float* __restrict__ re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][kb][r] = 0.f;
 
-    // weight ring: four steps in registers, three in flight (each step = 4 KB records feeding 4 KB MFMAs)
-    float wb[4][4 * KB];
+    // ring bookkeeping (all wave-uniform): slot to fill next, slot to read next, stream position of the next fill
+    int wslot = 0, rslot = 0;
+    const float* wnext = wsrc;
+    auto issue_step = [&]() {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+        for (int p = 0; p < KB; ++p) wn_dma16(wnext + p * 256, ring + wslot * STEP + p * 256, lane);
+        wnext += STEP;
+        wslot = wslot + 1 == WN_SLOTS ? 0 : wslot + 1;
+    };
+    const int total_steps = chunks * 8;
 #pragma unroll
-        for (int i = 0; i < 4 * KB; ++i) wb[q][i] = wr[(q * 4 * KB + i) * 64];
+    for (int q = 0; q < DIST; ++q) issue_step();      // total_steps >= 8 > DIST: never past the stream
     fetch(0);
-    commit(0);
+    commit(0);          // the compiler drains the VM counter for the fetched registers here: the first DIST steps have landed too
     __syncthreads();
     for (int chunk = 0; chunk < chunks; ++chunk) {
-        const float* wc = wr + (size_t)chunk * (8 * 4 * KB * 64);
         const float* pbuf = smem + (chunk & 1) * WN_BUF + lbase;
+        const bool last = chunk + 1 == chunks;
+        auto step = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            // [A] records of step s + DIST into the slot step s - 2 read; nothing is issued past the end of the stream
+            if (!last || s + DIST < 8) issue_step();
+            // [B] the next chunk's window: eight steps of cover until the commit below
+            if (s == 0 && !last) fetch(chunk + 1);
+            // [C] step s's records were issued DIST steps ago; behind them in the counter: the steps issued since (DIST of
+            // them, fewer at the end of the stream) and, for s <= DIST, this chunk's window fetch
+            if (!last) wn_wait_vm<DIST * KB + (s <= DIST ? WN_FETCH_OPS : 0)>();
+            else wn_wait_vm<(7 - s < DIST ? 7 - s : DIST) * KB>();
+            // [D] this lane's A operands of the step
+            const float* rs = ring + rslot * STEP + 4 * lane;
+            rslot = rslot + 1 == WN_SLOTS ? 0 : rslot + 1;
+            float wa[4 * KB];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            // step s + 3 (possibly in the next chunk, or the zero pad behind the last one) goes into the slot step s - 1 freed
-            asm volatile("" ::: "memory");      // keep the issue order of the loads: the vm counter retires them in order
+            for (int p = 0; p < KB; ++p) {
+                const w4f v4 = *reinterpret_cast<const w4f*>(rs + p * 256);
 #pragma unroll
-            for (int i = 0; i < 4 * KB; ++i) wb[(s + 3) & 3][i] = wc[((s + 3) * 4 * KB + i) * 64];
-            if (s == 3 && chunk + 1 < chunks) fetch(chunk + 1);      // needed four steps from now
-            asm volatile("" ::: "memory");
+                for (int j = 0; j < 4; ++j) wa[4 * p + j] = v4[j];
+            }
+            // [E] B operands: row w of B^T d B of the tile, from the raw window
             const float* pa = pbuf + (2 * s + hh) * WN_CH;
             const w2f a0 = *reinterpret_cast<const w2f*>(pa + ra * WN_PS), a1 = *reinterpret_cast<const w2f*>(pa + ra * WN_PS + 2);
             const w2f b0 = *reinterpret_cast<const w2f*>(pa + rb * WN_PS), b1 = *reinterpret_cast<const w2f*>(pa + rb * WN_PS + 2);
@@ -169,11 +252,19 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3(const float* __restrict__ re
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc[nu][kb] = WN_MFMA(wb[s & 3][nu * KB + kb], v[nu], acc[nu][kb]);
-        }
+                for (int kb = 0; kb < KB; ++kb) acc[nu][kb] = WN_MFMA(wa[nu * KB + kb], v[nu], acc[nu][kb]);
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
         // the other buffer was last read one chunk ago (every wave has passed the barrier behind it): fill it, then one barrier
         // both publishes it and retires this chunk's buffer
-        if (chunk + 1 < chunks) commit((chunk + 1) & 1);
+        if (!last) commit(chunk + 1);
         __syncthreads();
     }
     // ---- output transform Y = A^T M A: columns (nu) inside the wave, rows (w) across the waves through LDS (all KB at once)
@@ -220,13 +311,20 @@ template <int KB>
 static void wn_launch(const float* records, const float* x, WnTensor xi, int Hi, int Wi, int pad, float* y, WnTensor yo, int Ho, int Wo,
                       int n_img, int c_in, int c_out, int groups, hipStream_t st) {
     dim3 grid((unsigned)((Wo + 15) / 16), (unsigned)((Ho + 7) / 8), (unsigned)(n_img * groups));
-    hipLaunchKernelGGL((k_wino3x3<KB>), grid, dim3(256), 0, st, records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, c_in, c_out, groups);
+    constexpr size_t smem = sizeof(float) * (2 * WN_CC * 10 * WN_PS + 4 * WN_SLOTS * 4 * KB * 64);     // >= the KB * 8192 floats of the exchange
+    static_assert(smem >= sizeof(float) * KB * 8192, "the output exchange re-uses the staging memory");
+    static bool once = false;           // more than the default 64 KB of dynamic LDS needs the attribute once per kernel
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)k_wino3x3<KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        once = true;
+    }
+    hipLaunchKernelGGL((k_wino3x3<KB>), grid, dim3(256), smem, st, records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, c_in, c_out, groups);
 }
 
 extern "C" int nf_conv3x3_wino(const float* records, int k_per_group, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi,
                                int Wi, int pad, float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img,
                                int c_in, int c_out, int tile_blocks, nf_stream_t stream) {
-    NF_REQUIRE(n_img >= 1 && c_in >= 1 && c_out >= 1 && Hi >= 1 && Wi >= 1 && Ho >= 1 && Wo >= 1 && (k_per_group == 64 || k_per_group == 32),
+    NF_REQUIRE(n_img >= 1 && c_in >= 1 && c_out >= 1 && Hi >= 1 && Wi >= 2 && Ho >= 1 && Wo >= 1 && (k_per_group == 64 || k_per_group == 32),
                "nf_conv3x3_wino: bad arguments (k_per_group %d)", k_per_group);
     const int groups = (c_out + k_per_group - 1) / k_per_group;
     const WnTensor xi = {xs_n, xs_c, xs_h}, yo = {ys_n, ys_c, ys_h};

@@ -53,6 +53,25 @@ def test_fused_cnn_glue():
     pc.check_fused_cnn_glue('cuda')
 
 
+def test_winograd_full_size_layers_repeated():
+    """BASELINE-size layers, several launches each: the weight ring of csrc/nf_wino.hip is refilled by LDS-DMA behind the
+    reads, a hazard that only shows on grids of more than one round of workgroups and not on every launch."""
+    import torch
+    import torch.nn.functional as F
+    from nerfool_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    for (ci, co, H, W) in ((64, 64, 189, 252), (256, 128, 96, 126), (128, 64, 192, 252), (256, 256, 48, 63)):
+        wgt = (torch.randn(co, ci, 3, 3, generator=gen) * 0.05).cuda()
+        x = torch.randn(4, ci, H + 2, W + 2, generator=gen).cuda()
+        gy = torch.randn(4, co, H, W, generator=gen).cuda()
+        ref, gref = F.conv2d(x, wgt), F.conv_transpose2d(gy, wgt)
+        rf, rb = ops.wino_pack(wgt, False, 'cuda'), ops.wino_pack(wgt, True, 'cuda')
+        for _ in range(8):
+            got, ggot = ops.conv3x3_wino(rf, x, co, 0), ops.conv3x3_wino(rb, gy, ci, 2)
+            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (ci, co, H, W)
+            assert float((ggot - gref).abs().max()) <= 2e-5 * float(gref.abs().max()), (ci, co, H, W)
+
+
 def test_fused_resunet_matches_module_graph():
     pc.check_fused_resunet('cuda')
 

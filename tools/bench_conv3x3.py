@@ -1,12 +1,16 @@
 """3x3 stride-1 convolutions of the ResUNet at BASELINE config 2 sizes: MIOpen (aten.convolution / convolution_backward on the
-pre-padded activation) vs the Winograd matrix-core kernel (csrc/nf_wino.hip).  usage: python tools/bench_conv3x3.py [iters]"""
+pre-padded activation) vs the Winograd matrix-core kernel (csrc/nf_wino.hip).
+usage: python tools/bench_conv3x3.py [iters] [tuning build of the library, tools/build_variant.sh]"""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nerfool_amd import ops                                   # noqa: E402
+from nerfool_amd import _lib, ops                             # noqa: E402
+
+if len(sys.argv) > 2:
+    _lib.use_library_for_tests(sys.argv[2], emulated=False)
 
 aten = torch.ops.aten
 
