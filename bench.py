@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3      # MI355X fp32 MFMA / vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec peak
 ROOFLINE_KERNELS = ('nf_ibrnet_fwd', 'nf_ibrnet_bwd', 'nf_ibrnet_fwd_mfma', 'nf_ibrnet_bwd_mfma', 'nf_project_gather_fwd',
-                    'nf_project_gather_bwd', 'nf_gnt_fwd', 'nf_gnt_fwd_mfma', 'nf_gnt_bwd', 'nf_gnt_bwd_mfma', 'nf_pgd_adam_step')
+                    'nf_project_gather_bwd', 'nf_gnt_fwd', 'nf_gnt_fwd_mfma', 'nf_gnt_bwd', 'nf_gnt_bwd_mfma', 'nf_pgd_adam_step',
+                    'nf_conv3x3_wino')
 
 
 def ibrnet_flops(R, S, V):
@@ -240,6 +241,7 @@ def main():
     # ---- roofline of the dominant hand-written kernel of the timed region
     V, Sc, Sf, R = a.views, a.samples, a.samples + a.importance, a.n_rand
     table = {}
+    wino_direct, wino_bytes = [], []
     for name, k in kernels.items():
         per_launch = []
         for ms, meta in zip(k['ms'], k['meta']):
@@ -257,6 +259,14 @@ def main():
                 per_launch.append(('mfma', fl / (ms * 1e-3) / 1e12))
             elif name == 'nf_pgd_adam_step':
                 per_launch.append(('hbm', meta['n'] * 32 / (ms * 1e-3) / 1e9))
+            elif name == 'nf_conv3x3_wino':
+                # Winograd F(2x2,3x3): 16 multiply-adds per 2x2 output tile and (c_in, c_out) pair -- the products the kernel
+                # puts on the matrix cores (the direct form of the same convolution needs 36: extra.kernels reports that rate too)
+                tiles = meta['n_img'] * ((meta['Ho'] + 1) // 2) * ((meta['Wo'] + 1) // 2)
+                per_launch.append(('mfma', 2.0 * 16 * meta['c_in'] * meta['c_out'] * tiles / (ms * 1e-3) / 1e12))
+                wino_direct.append(2.0 * 9 * meta['c_in'] * meta['c_out'] * meta['n_img'] * meta['Ho'] * meta['Wo'] / (ms * 1e-3) / 1e12)
+                wino_bytes.append(4.0 * (meta['n_img'] * (meta['c_in'] * meta['Hi'] * meta['Wi'] + meta['c_out'] * meta['Ho'] * meta['Wo'])
+                                         + 16 * meta['c_in'] * meta['c_out']))
         if per_launch:
             bound = per_launch[0][0]
             ach = float(np.mean([x[1] for x in per_launch]))
@@ -264,12 +274,16 @@ def main():
             table[name] = {'bound': bound, 'achieved': round(ach, 4), 'peak': peak, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
                            'frac': round(ach / peak, 5), 'launches': k['launches'], 'mean_ms': round(k['mean_ms'], 4),
                            'total_ms': round(k['total_ms'], 3)}
+    if 'nf_conv3x3_wino' in table:
+        table['nf_conv3x3_wino']['direct_form_equivalent_tflops'] = round(float(np.mean(wino_direct)), 2)
     dominant = max(table, key=lambda n: table[n]['total_ms']) if table else None
     roofline = None
     if dominant:
         d = table[dominant]
         roofline = {'kernel': dominant, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'], 'unit': d['unit'],
                     'frac': d['frac'], 'traffic': pmc_traffic(dominant, a)}
+        if dominant == 'nf_conv3x3_wino' and roofline['traffic'] is not None and roofline['traffic'].get('algorithmic_bytes_per_launch') is None:
+            roofline['traffic']['algorithmic_bytes_per_launch'] = int(np.mean(wino_bytes))     # input + output + transformed weights
 
     rays_per_step = a.n_rand * world
     out = {

@@ -120,7 +120,7 @@ __device__ __forceinline__ void wn_wait_vm() {
 
 template <int KB>
 __global__ void __launch_bounds__(256, 2) k_wino3x3(const float* __restrict__ rec, const float* __restrict__ x, WnTensor xi, int Hi, int Wi,
-                                                    int pad, float* __restrict__ y, WnTensor yo, int Ho, int Wo, int C, int K, int groups) {
+                                                    int pad, float* __restrict__ y, WnTensor yo, int Ho, int Wo, int C, int K, int groups, int n_img) {
     // LDS: two buffers of the raw input window of a 16-channel chunk | one weight ring per wave; after the last chunk the same
     // memory carries the row half of the output transform from wave to wave
     constexpr int WN_PR = 10, WN_CH = WN_PR * WN_PS, WN_BUF = WN_CC * WN_CH;
@@ -130,8 +130,16 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3(const float* __restrict__ re
     float* ex = smem;
     const int lane = threadIdx.x & 63, w = wn_uniform(threadIdx.x >> 6);
     const int t = lane & 31, hh = lane >> 5, tr = t >> 3, tc = t & 7;
-    const int n = blockIdx.z / groups, grp = blockIdx.z - n * groups;
-    const int oy0 = blockIdx.y * 8, ox0 = blockIdx.x * 16;
+    // workgroup -> (tile, output-channel group).  The hardware deals consecutive workgroup ids round-robin over the 8 XCDs, each
+    // with its own L2: the ids that share an XCD (id % 8) walk a contiguous run of tiles in raster order, the `groups` channel
+    // groups of a tile back to back -- the groups re-read the same input window, neighbouring tiles share its halo.
+    const int tiles_x = (Wo + 15) >> 4, tiles_y = (Ho + 7) >> 3;
+    const int n_tiles = tiles_x * tiles_y * n_img, per_xcd = (n_tiles + 7) >> 3;
+    const int slot = blockIdx.x >> 3, tl = slot / groups, grp = slot - tl * groups;
+    const int tile = (blockIdx.x & 7) * per_xcd + tl;
+    if (tile >= n_tiles) return;                // whole workgroup, before any barrier
+    const int n = tile / (tiles_x * tiles_y), trem = tile - n * (tiles_x * tiles_y);
+    const int oy0 = (trem / tiles_x) * 8, ox0 = (trem % tiles_x) * 16;
     const int iy0 = oy0 - pad, ix0 = ox0 - pad;
     const int chunks = (C + WN_CC - 1) / WN_CC;
     const float* xn = x + n * xi.ns;
@@ -310,7 +318,8 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3(const float* __restrict__ re
 template <int KB>
 static void wn_launch(const float* records, const float* x, WnTensor xi, int Hi, int Wi, int pad, float* y, WnTensor yo, int Ho, int Wo,
                       int n_img, int c_in, int c_out, int groups, hipStream_t st) {
-    dim3 grid((unsigned)((Wo + 15) / 16), (unsigned)((Ho + 7) / 8), (unsigned)(n_img * groups));
+    const int n_tiles = ((Wo + 15) / 16) * ((Ho + 7) / 8) * n_img;
+    dim3 grid((unsigned)(8 * ((n_tiles + 7) / 8) * groups));
     constexpr size_t smem = sizeof(float) * (2 * WN_CC * 10 * WN_PS + 4 * WN_SLOTS * 4 * KB * 64);     // >= the KB * 8192 floats of the exchange
     static_assert(smem >= sizeof(float) * KB * 8192, "the output exchange re-uses the staging memory");
     static bool once = false;           // more than the default 64 KB of dynamic LDS needs the attribute once per kernel
@@ -318,7 +327,7 @@ static void wn_launch(const float* records, const float* x, WnTensor xi, int Hi,
         (void)hipFuncSetAttribute((const void*)k_wino3x3<KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         once = true;
     }
-    hipLaunchKernelGGL((k_wino3x3<KB>), grid, dim3(256), smem, st, records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, c_in, c_out, groups);
+    hipLaunchKernelGGL((k_wino3x3<KB>), grid, dim3(256), smem, st, records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, c_in, c_out, groups, n_img);
 }
 
 extern "C" int nf_conv3x3_wino(const float* records, int k_per_group, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi,

@@ -453,7 +453,7 @@ def conv3x3_wino(records, x, c_out, pad, tile_blocks=0):
     Ho, Wo = Hi - 2 + 2 * pad, Wi - 2 + 2 * pad
     y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
-    with prof.launch('nf_conv3x3_wino', x, n=y.numel()):
+    with prof.launch('nf_conv3x3_wino', x, n_img=N, c_in=c_in, c_out=c_out, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo):
         _lib.check(_lib.lib().nf_conv3x3_wino(_ptr(records), wino_group(c_out), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y),
                                               ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out, int(tile_blocks), _stream(x)),
                    'nf_conv3x3_wino')

@@ -10,7 +10,7 @@ import sys
 ABI = {'nf_ibrnet_fwd_mfma': ('k_ibr_rows_fwd', 'k_ibr_ray_fwd'),
        'nf_ibrnet_bwd_mfma': ('k_ibr_rows_bwd', 'k_ibr_ray_bwd'),
        'nf_project_gather_fwd': ('k_project_gather_fwd',), 'nf_project_gather_bwd': ('k_project_gather_bwd',),
-       'nf_pgd_adam_step': ('k_pgd_adam_step',)}
+       'nf_pgd_adam_step': ('k_pgd_adam_step',), 'nf_conv3x3_wino': ('k_wino3x3',)}
 
 
 def load(path, counter, steps):
@@ -49,6 +49,8 @@ def main():
             if name.startswith(prefixes):
                 tot += k['hbm_bytes_per_launch'] * k['launches_per_step']
         calls = 1 if entry == 'nf_pgd_adam_step' else 2          # coarse + fine level per step
+        if entry == 'nf_conv3x3_wino':                           # one kernel launch per call: every stride-1 3x3 layer, both directions
+            calls = sum(k['launches_per_step'] for name, k in kernels.items() if name.startswith(prefixes)) or 1
         abi[entry] = {'hbm_bytes_per_launch': int(tot / calls), 'calls_per_step': calls}
         if entry in alg[64]:
             abi[entry]['algorithmic_bytes_per_launch'] = int((alg[64][entry] + alg[128][entry]) / 2)
