@@ -173,13 +173,15 @@ int nf_upsample2x_pad_fwd(const float* x, int64_t planes, int64_t xs_plane, int6
  *   y[n, co, r, c] = bias[co] + sum_ci M[co][ci] x[n, ci, r, c] on an H x W pixel grid; x and y are addressed with element
  *   strides (image, channel, row, column): NCHW, NHWC and stride-2 subsampled views are the same call.  `records` =
  *   nf_conv1x1_pack(weight [c_out][c_in]) (HOST pointers); with transposed != 0 the records hold weight^T and the call
- *   nf_conv1x1(..., c_in := c_out, c_out := c_in) is the backward-data pass.
+ *   nf_conv1x1(..., c_in := c_out, c_out := c_in) is the backward-data pass.  x2 (nullable): input channels
+ *   c_split .. c_in - 1 come from x2[n, ci - c_split, r, c] (same strides as x; c_split a multiple of 32) -- out_conv's backward
+ *   reads the gradients of the coarse and the fine feature maps (feature_network.py:265-268) where autograd delivers them.
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t nf_conv1x1_pack_floats(int c_out, int c_in);
 int nf_conv1x1_pack(const float* weight_host, int c_out, int c_in, int transposed, float* records_host);
 int nf_conv1x1(const float* records, const float* bias, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w,
                float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, int n_img, int H, int W, int c_in, int c_out,
-               nf_stream_t stream);
+               const float* x2, int c_split, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a14  ResUNet 3x3 stride-1 convolutions as Winograd F(2x2, 3x3) on the fp32 matrix cores.

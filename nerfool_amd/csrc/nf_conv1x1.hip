@@ -39,7 +39,7 @@ struct C1Tensor { int64_t ns, cs, rs, ws; };      // element strides: image, cha
 template <int KT>
 __global__ void __launch_bounds__(256) k_conv1x1(const float* __restrict__ rec, const float* __restrict__ bias, const float* __restrict__ x,
                                                  C1Tensor xi, float* __restrict__ y, C1Tensor yo, int n_img, int H, int W, int c_in,
-                                                 int c_out) {
+                                                 int c_out, const float* __restrict__ x2, int c_split) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
     const int64_t HW = (int64_t)H * W, n_pix = (int64_t)n_img * HW;
@@ -55,7 +55,11 @@ __global__ void __launch_bounds__(256) k_conv1x1(const float* __restrict__ rec, 
         const int q = (int)(p - (int64_t)n * HW);
         const int row = q / W, col = q - row * W;
         // wave-uniform channel offsets + ONE per-lane offset (pixel position and the lane half's 4-channel shift)
-        const float* xl = x + n * xi.ns + row * xi.rs + col * xi.ws + 4 * h * xi.cs;
+        const int64_t xoff = n * xi.ns + row * xi.rs + col * xi.ws + 4 * h * xi.cs;
+        const float* xl = x + xoff;
+        // second source: channels c_split .. c_in - 1 live in x2 (same strides) -- the two feature-map gradients of out_conv's
+        // backward arrive as separate tensors; c_split is a multiple of 32, so a k-tile reads one source
+        const float* xl2 = x2 ? x2 + xoff - (int64_t)c_split * xi.cs : xl;
         float* yl = y + n * yo.ns + row * yo.rs + col * yo.ws + 4 * h * yo.cs;
         c16 xv[KT];
         if (xi.cs == 1 && (c_in & 7) == 0) {        // channels-last input: registers r..r+3 are 4 consecutive channels
@@ -64,7 +68,8 @@ __global__ void __launch_bounds__(256) k_conv1x1(const float* __restrict__ rec, 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = 32 * kt + 8 * g;
-                    c1_f4u v = (c + 4 * h < c_in) ? *reinterpret_cast<const c1_f4u*>(xl + c) : c1_f4u{0.f, 0.f, 0.f, 0.f};
+                    const float* xs = c >= c_split ? xl2 : xl;
+                    c1_f4u v = (c + 4 * h < c_in) ? *reinterpret_cast<const c1_f4u*>(xs + c) : c1_f4u{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) xv[kt][4 * g + j] = v[j];
                 }
@@ -74,7 +79,8 @@ __global__ void __launch_bounds__(256) k_conv1x1(const float* __restrict__ rec, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = 32 * kt + c1_nidx(r, 0);
-                    xv[kt][r] = (c + 4 * h < c_in) ? xl[c * xi.cs] : 0.f;
+                    const float* xs = c >= c_split ? xl2 : xl;
+                    xv[kt][r] = (c + 4 * h < c_in) ? xs[c * xi.cs] : 0.f;
                 }
         }
         for (int t = blockIdx.y; t < nt_out; t += gridDim.y) {
@@ -111,12 +117,16 @@ __global__ void __launch_bounds__(256) k_conv1x1(const float* __restrict__ rec, 
 
 /* y[n, co, row, col] = bias[co] + sum_ci M[co][ci] x[n, ci, row, col] over an H x W pixel grid; x and y are addressed with
  * element strides (image, channel, row, column), so a stride-2 subsampled view, NCHW and NHWC are the same call.
- * records: nf_conv1x1_pack of the weight (transposed for the backward-data pass, where c_in / c_out swap roles). */
+ * records: nf_conv1x1_pack of the weight (transposed for the backward-data pass, where c_in / c_out swap roles).
+ * x2 (nullable): input channels c_split .. c_in - 1 are read from x2[n, ci - c_split, row, col] (same strides as x). */
 extern "C" int nf_conv1x1(const float* records, const float* bias, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h,
                           int64_t xs_w, float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, int n_img, int H, int W,
-                          int c_in, int c_out, nf_stream_t stream) {
+                          int c_in, int c_out, const float* x2, int c_split, nf_stream_t stream) {
     NF_REQUIRE(n_img >= 1 && H >= 1 && W >= 1 && c_in >= 1 && c_in <= 256 && c_out >= 1 && c_out <= 1024,
                "nf_conv1x1: need 1 <= c_in <= 256, 1 <= c_out <= 1024 (got c_in %d c_out %d)", c_in, c_out);
+    NF_REQUIRE(!x2 || (c_split > 0 && c_split < c_in && c_split % 32 == 0),
+               "nf_conv1x1: a second source needs 0 < c_split < c_in, c_split a multiple of 32 (got %d of %d)", c_split, c_in);
+    if (!x2) c_split = c_in;
     const int64_t tiles = ((int64_t)n_img * H * W + 31) / 32;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > 4096) blocks = 4096;
@@ -128,7 +138,7 @@ extern "C" int nf_conv1x1(const float* records, const float* bias, const float* 
     hipStream_t st = (hipStream_t)stream;
     const int kt = (c_in + 31) / 32;
 #define C1_LAUNCH(KT) \
-    hipLaunchKernelGGL(k_conv1x1<KT>, dim3((unsigned)blocks, (unsigned)split), dim3(256), 0, st, records, bias, x, xi, y, yo, n_img, H, W, c_in, c_out)
+    hipLaunchKernelGGL(k_conv1x1<KT>, dim3((unsigned)blocks, (unsigned)split), dim3(256), 0, st, records, bias, x, xi, y, yo, n_img, H, W, c_in, c_out, x2, c_split)
     switch (kt) {
         case 1: C1_LAUNCH(1); break;
         case 2: C1_LAUNCH(2); break;

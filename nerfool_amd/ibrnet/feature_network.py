@@ -112,12 +112,10 @@ class ResUNet(nn.Module):
     def forward(self, x):
         frozen = not any(p.requires_grad for p in self.parameters())
         if CNN_PATH == 'fused' and frozen and (x.is_cuda or ops._lib.emulated()):
-            out = _FusedResUNet.apply(x, self)
-            if self.single_net:
-                return out, out
-            if self.coarse_only:
-                return out, None
-            return out[:, :self.coarse_out_ch], out[:, -self.fine_out_ch:]
+            if self.single_net or self.coarse_only:
+                out, = _FusedResUNet.apply(x, self, (self.coarse_out_ch,))
+                return (out, out) if self.single_net else (out, None)
+            return _FusedResUNet.apply(x, self, (self.coarse_out_ch, self.fine_out_ch))
         x = F.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
@@ -261,7 +259,11 @@ def _conv1x1(tape, inp, conv, sink, channels_last_out=False):
     out = _Slot(ops.conv1x1(cache[1], conv.bias, inp, c_out, channels_last_out))
 
     def bwd():
-        sink(ops.conv1x1(cache[2], None, out.g, c_in))
+        if isinstance(out.g, tuple):          # out_conv: one gradient per feature map, read where they lie
+            g0, g1 = out.g
+            sink(ops.conv1x1(cache[2], None, g0, c_in, x2=g1))
+        else:
+            sink(ops.conv1x1(cache[2], None, out.g, c_in))
         out.g = None
     tape.append(bwd)
     return out
@@ -373,17 +375,26 @@ def fused_forward(net, x):
 
 
 class _FusedResUNet(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, net):
-        out, tape, xin = fused_forward(net, x)
-        ctx.tape, ctx.out, ctx.xin = tape, out, xin
-        return out.v.contiguous(memory_format=torch.channels_last)
+    """outputs: the feature maps as channel slices of out_conv's ONE channels-last buffer, split INSIDE the function -- the
+    gradients then arrive one per map and out_conv's backward reads them in place (nf_conv1x1's second source) instead of
+    autograd assembling them with zero fills, two strided copies and an add (0.19 ms per step at BASELINE config 2)."""
 
     @staticmethod
-    def backward(ctx, d_out):
-        ctx.out.g = d_out                        # any layout: the 1x1 backward addresses it by strides
+    def forward(ctx, x, net, split):
+        out, tape, xin = fused_forward(net, x)
+        ctx.tape, ctx.out, ctx.xin = tape, out, xin
+        full = out.v.contiguous(memory_format=torch.channels_last)
+        if len(split) == 1:
+            return (full,)
+        return tuple(full.split(list(split), dim=1))
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        ref = next(g for g in d_outs if g is not None)
+        d_outs = [torch.zeros_like(ref) if g is None else g for g in d_outs]
+        ctx.out.g = d_outs[0] if len(d_outs) == 1 else tuple(d_outs)     # any layout: the 1x1 backward addresses it by strides
         for step in reversed(ctx.tape):
             step()
         g = ctx.xin.g
         ctx.tape = ctx.out = ctx.xin = None
-        return g, None
+        return g, None, None

@@ -410,11 +410,20 @@ def conv1x1_pack(weight, transposed, device):
     return out.to(device)
 
 
-def conv1x1(records, bias, x, c_out, channels_last_out=False):
+def conv1x1(records, bias, x, c_out, channels_last_out=False, x2=None):
     """1x1 convolution of x [N, c_in, H, W] (ANY strides: NCHW, channels-last, subsampled views) -> [N, c_out, H, W]
-    contiguous, or channels-last when channels_last_out."""
+    contiguous, or channels-last when channels_last_out.  x2: the input channels continue in a second tensor
+    (x = channels 0 .. c1 - 1 with c1 a multiple of 32, x2 the rest, same strides)."""
     _f32(x, 'x')
     N, c_in, H, W = x.shape
+    c_split = 0
+    if x2 is not None:
+        _f32(x2, 'x2')
+        if x2.stride() != x.stride() or c_in % 32 != 0:
+            x, x2 = torch.cat([x, x2], dim=1), None
+            c_in = x.shape[1]
+        else:
+            c_split, c_in = c_in, c_in + x2.shape[1]
     if channels_last_out:
         y = torch.empty(N, H, W, c_out, dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
     else:
@@ -422,7 +431,7 @@ def conv1x1(records, bias, x, c_out, channels_last_out=False):
     xs, ys = x.stride(), y.stride()
     with prof.launch('nf_conv1x1', x, n=y.numel()):
         _lib.check(_lib.lib().nf_conv1x1(_ptr(records), _ptr(bias), _ptr(x), xs[0], xs[1], xs[2], xs[3], _ptr(y), ys[0], ys[1], ys[2],
-                                         ys[3], N, H, W, c_in, c_out, _stream(x)), 'nf_conv1x1')
+                                         ys[3], N, H, W, c_in, c_out, _ptr(x2), c_split, _stream(x)), 'nf_conv1x1')
     return y
 
 

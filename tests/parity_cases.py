@@ -474,6 +474,11 @@ def check_fused_cnn_glue(dev):
         gyd = gy.to(dev).contiguous(memory_format=torch.channels_last) if cl else gy.to(dev)
         ggot = ops.conv1x1(ops.conv1x1_pack(wgt, True, dev), None, gyd, ci)
         assert_close(ggot, gref, 1e-5, 1e-5, '1x1 convolution backward-data')
+        if co % 64 == 0:        # the gradient delivered as two tensors (out_conv's backward: coarse | fine feature maps)
+            half = co // 2
+            g0, g1 = (t.contiguous(memory_format=torch.channels_last) for t in gy.to(dev).split([half, co - half], dim=1))
+            ggot2 = ops.conv1x1(ops.conv1x1_pack(wgt, True, dev), None, g0, ci, x2=g1)
+            assert_close(ggot2, gref, 1e-5, 1e-5, '1x1 convolution backward-data from two sources')
     # decoder: x2 bilinear upsampling (align_corners) fused with the reflect padding, from contiguous and strided sources
     for (N, C, h, w, pad, strided) in ((2, 3, 5, 7, 1, False), (1, 4, 6, 4, 1, True), (1, 2, 1, 3, 0, False)):
         store = torch.randn(N, C, h + 2, w + 2, generator=gen)
