@@ -13,7 +13,7 @@
 // 2.25x fewer multiplies than the direct form.
 // Data movement: the accumulators take 128 of a lane's registers, so nothing else may live in registers for long.
 //   * weights: every wave streams ITS records from L2 into a private LDS ring by LDS-DMA (global_load_lds_dwordx4: 1 KB per
-//     instruction, no register in between), WN_SLOTS - 2 = 4 steps ahead, and reads a step's A operands back with ds_read_b128;
+//     instruction, no register in between), slots - 2 = 4 steps ahead, and reads a step's A operands back with ds_read_b128;
 //   * input: the next chunk's raw window is fetched into 12 registers at the top of a chunk and committed to the second LDS
 //     buffer at its end (one barrier per chunk).
 //   Both streams share the wave's in-order VM counter.  The DMA is issued from inline asm and waited for with exact counted
@@ -80,12 +80,15 @@ extern "C" int nf_wino_pack(const float* weight, int c_out, int c_in, int backwa
 
 struct WnTensor { int64_t ns, cs, rs; };        // element strides: image, channel, row (unit column stride)
 
-// Ring slots per wave.  A step's records are issued WN_SLOTS - 2 steps before they are used, into the slot that was read TWO
+// Ring slots per wave.  A step's records are issued slots - 2 steps before they are used, into the slot that was read TWO
 // steps earlier: the wait of the step in between also retires the wave's LDS reads (lgkmcnt(0)), so a refill can never
-// overtake a read of the slot it overwrites.  (Refilling the slot read ONE step earlier -- a distance of WN_SLOTS - 1 --
+// overtake a read of the slot it overwrites.  (Refilling the slot read ONE step earlier -- a distance of slots - 1 --
 // corrupted a few outputs per launch on the large layers: an L2-hit DMA can land within ~250 cycles, before a read still
 // queued behind the neighbour workgroup's LDS traffic has executed.)
-#define WN_SLOTS 6
+// KB = 2 (64 output channels per workgroup): 6 slots, 78 KB of LDS, two workgroups per CU.  KB = 1 (32 channels: half the
+// multiplications per staged window, for grids that would otherwise run a nearly empty second round of workgroups): 5 slots,
+// 50 KB, three workgroups per CU.
+__host__ __device__ constexpr int wn_slots(int kb) { return kb == 1 ? 5 : 6; }
 #define WN_FETCH_OPS 6      // VM instructions one window fetch issues per wave (two segments x three 8-byte loads)
 
 // ---- the three device-only primitives of the weight ring (their host forms keep the file compilable in the host pass)
@@ -119,12 +122,13 @@ __device__ __forceinline__ void wn_wait_vm() {
 }
 
 template <int KB>
-__global__ void __launch_bounds__(256, 2) k_wino3x3(const float* __restrict__ rec, const float* __restrict__ x, WnTensor xi, int Hi, int Wi,
+__global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* __restrict__ rec, const float* __restrict__ x, WnTensor xi, int Hi, int Wi,
                                                     int pad, float* __restrict__ y, WnTensor yo, int Ho, int Wo, int C, int K, int groups, int n_img) {
     // LDS: two buffers of the raw input window of a 16-channel chunk | one weight ring per wave; after the last chunk the same
     // memory carries the row half of the output transform from wave to wave
     constexpr int WN_PR = 10, WN_CH = WN_PR * WN_PS, WN_BUF = WN_CC * WN_CH;
     constexpr int STEP = 4 * KB * 64;                 // floats of one step's records = KB pieces of 256
+    constexpr int WN_SLOTS = wn_slots(KB);
     constexpr int DIST = WN_SLOTS - 2;
     HIP_DYNAMIC_SHARED(float, smem)
     float* ex = smem;
@@ -320,7 +324,7 @@ static void wn_launch(const float* records, const float* x, WnTensor xi, int Hi,
                       int n_img, int c_in, int c_out, int groups, hipStream_t st) {
     const int n_tiles = ((Wo + 15) / 16) * ((Ho + 7) / 8) * n_img;
     dim3 grid((unsigned)(8 * ((n_tiles + 7) / 8) * groups));
-    constexpr size_t smem = sizeof(float) * (2 * WN_CC * 10 * WN_PS + 4 * WN_SLOTS * 4 * KB * 64);     // >= the KB * 8192 floats of the exchange
+    constexpr size_t smem = sizeof(float) * (2 * WN_CC * 10 * WN_PS + 4 * wn_slots(KB) * 4 * KB * 64);     // >= the KB * 8192 floats of the exchange
     static_assert(smem >= sizeof(float) * KB * 8192, "the output exchange re-uses the staging memory");
     static bool once = false;           // more than the default 64 KB of dynamic LDS needs the attribute once per kernel
     if (!once) {

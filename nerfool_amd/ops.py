@@ -440,21 +440,23 @@ def wino_group(c_out):
     return 32 if c_out <= 32 else 64
 
 
-def wino_pack(weight, backward, device):
-    """weight [c_out, c_in, 3, 3] -> Winograd-domain MFMA records (backward: the backward-data convolution)"""
+def wino_pack(weight, backward, device, k_per_group=None):
+    """weight [c_out, c_in, 3, 3] -> Winograd-domain MFMA records (backward: the backward-data convolution);
+    k_per_group: output channels per workgroup, 64 or 32 (default wino_group)"""
     L = _lib.lib()
     w = weight.detach().to('cpu', torch.float32).contiguous()
     c_out, c_in = w.shape[0], w.shape[1]
     n_out = c_in if backward else c_out
-    kg = wino_group(n_out)
+    kg = wino_group(n_out) if k_per_group is None else int(k_per_group)
     out = torch.empty(L.nf_wino_pack_floats(n_out, c_out if backward else c_in, kg), dtype=torch.float32)
     _lib.check(L.nf_wino_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), kg, out.data_ptr()), 'nf_wino_pack')
     return out.to(device)
 
 
-def conv3x3_wino(records, x, c_out, pad, tile_blocks=0):
+def conv3x3_wino(records, x, c_out, pad, tile_blocks=0, k_per_group=None):
     """3x3 stride-1 convolution of x [N, c_in, Hi, Wi] (unit column stride) with zero padding `pad` (0: the network's
-    forward on pre-padded activations, 2: its backward-data on the gradient) -> [N, c_out, Hi - 2 + 2 pad, Wi - 2 + 2 pad]."""
+    forward on pre-padded activations, 2: its backward-data on the gradient) -> [N, c_out, Hi - 2 + 2 pad, Wi - 2 + 2 pad].
+    k_per_group must be the value the records were packed with."""
     _f32(x, 'x')
     if x.stride(3) != 1:
         x = x.contiguous()
@@ -463,7 +465,7 @@ def conv3x3_wino(records, x, c_out, pad, tile_blocks=0):
     y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
     with prof.launch('nf_conv3x3_wino', x, n_img=N, c_in=c_in, c_out=c_out, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo):
-        _lib.check(_lib.lib().nf_conv3x3_wino(_ptr(records), wino_group(c_out), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y),
+        _lib.check(_lib.lib().nf_conv3x3_wino(_ptr(records), wino_group(c_out) if k_per_group is None else int(k_per_group), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y),
                                               ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out, int(tile_blocks), _stream(x)),
                    'nf_conv3x3_wino')
     return y

@@ -44,13 +44,16 @@ def main():
         t_mb, dx = timed(lambda: aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0], iters)
         t_wf, y2 = timed(lambda: ops.conv3x3_wino(rf, x, co, 0), iters)
         t_wb, dx2 = timed(lambda: ops.conv3x3_wino(rb, g, ci, 2), iters)
-        t1 = [timed(lambda: ops.conv3x3_wino(rf, x, co, 0, tb), iters)[0] for tb in (1, 2)] + [timed(lambda: ops.conv3x3_wino(rb, g, ci, 2, tb), iters)[0] for tb in (1, 2)]
+        rf32, rb32 = ops.wino_pack(w, False, dev, 32), ops.wino_pack(w, True, dev, 32)
+        t_f32, y3 = timed(lambda: ops.conv3x3_wino(rf32, x, co, 0, k_per_group=32), iters)
+        t_b32, dx3 = timed(lambda: ops.conv3x3_wino(rb32, g, ci, 2, k_per_group=32), iters)
+        t1 = (t_wf, t_f32, t_wb, t_b32, float((y - y3).abs().max() / y.abs().max()), float((dx - dx3).abs().max() / dx.abs().max()))
         fl = 2.0 * 4 * H * W * ci * co * 9
         err_f = float((y - y2).abs().max() / y.abs().max())
         err_b = float((dx - dx2).abs().max() / dx.abs().max())
         tot_m += count * (t_mf + t_mb)
         tot_w += count * (t_wf + t_wb)
-        print('      tile blocks 1 / 2: fwd %.1f / %.1f us, bwd %.1f / %.1f us' % tuple(t1))
+        print('      output channels per workgroup 64 / 32: fwd %.1f / %.1f us, bwd %.1f / %.1f us (rel err of the 32 form %.1e %.1e)' % t1)
         print('%3d->%3d %3dx%3d: MIOpen fwd %6.1f us (%5.1f TF) bwd %6.1f us | Winograd MFMA fwd %6.1f us (%5.1f TF) bwd %6.1f us | rel err %.1e %.1e  x%d'
               % (ci, co, H, W, t_mf, fl / t_mf / 1e6, t_mb, t_wf, fl / t_wf / 1e6, t_wb, err_f, err_b, count), flush=True)
     print('weighted per step: MIOpen %.2f ms, Winograd MFMA %.2f ms' % (tot_m / 1e3, tot_w / 1e3))
