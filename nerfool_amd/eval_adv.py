@@ -107,20 +107,28 @@ class _GatherViewFeatures(torch.autograd.Function):
     rank keeps the slice of its own views.  Runs on every rank in both directions, also on ranks that own no view."""
 
     @staticmethod
-    def forward(ctx, local, shard, lo, hi, n_views):
+    def forward(ctx, local, shard, lo, hi, n_views, split):
         full = torch.zeros((n_views,) + tuple(local.shape[1:]), dtype=local.dtype,
                            device=local.device).contiguous(memory_format=torch.channels_last)
         if hi > lo:
             full[lo:hi] = local
         shard.all_reduce_nhwc_(full)
         ctx.shard, ctx.lo, ctx.hi = shard, lo, hi
-        return full
+        # the per-map channel split happens HERE, so each map's gradient comes back as its own tensor (sliced outside,
+        # autograd would assemble them with zero fills, strided copies and an add over all V views)
+        return tuple(full.split(list(split), dim=1)) if len(split) > 1 else (full,)
 
     @staticmethod
-    def backward(ctx, g):
-        g = g.clone(memory_format=torch.channels_last)          # never reduce into autograd's own buffer
-        ctx.shard.all_reduce_nhwc_(g)
-        return g[ctx.lo:ctx.hi], None, None, None, None
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        mine = []
+        for g in gs:
+            g = torch.zeros_like(ref, memory_format=torch.channels_last) if g is None \
+                else g.clone(memory_format=torch.channels_last)          # never reduce into autograd's own buffer
+            ctx.shard.all_reduce_nhwc_(g)
+            mine.append(g[ctx.lo:ctx.hi])
+        local = mine[0] if len(mine) == 1 else torch.cat(mine, dim=1).contiguous(memory_format=torch.channels_last)
+        return local, None, None, None, None, None
 
 
 class RayShard:
@@ -162,24 +170,17 @@ class RayShard:
         """feature_net(src + delta) with the views split over the ranks -> the same tuple the network returns."""
         n_views, H, W = src_rgbs.shape[1], src_rgbs.shape[2], src_rgbs.shape[3]
         lo, hi = self.view_range(n_views)
+        channels, twice, second_none, Hf, Wf = feature_net.describe_output(H, W)
         if hi > lo:
-            outs = feature_net((src_rgbs[:, lo:hi] + delta[:, lo:hi]).squeeze(0).permute(0, 3, 1, 2))
-            twice = outs[1] is outs[0]
-            parts = [o for o in (outs[:1] if twice else outs) if o is not None]
-            channels = [int(o.shape[1]) for o in parts]
-            local = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
-            layout = (channels, twice, outs[1] is None)
+            local = feature_net.forward_full((src_rgbs[:, lo:hi] + delta[:, lo:hi]).squeeze(0).permute(0, 3, 1, 2))
         else:       # nothing to compute here, but this rank still takes part in both exchanges
-            channels, twice, second_none, Hf, Wf = feature_net.describe_output(H, W)
             local = delta.new_zeros((0, sum(channels), Hf, Wf)) + delta[:, 0:0].sum()
-            layout = (channels, twice, second_none)
-        full = _GatherViewFeatures.apply(local, self, lo, hi, n_views)
-        channels, twice, second_none = layout
+        maps = _GatherViewFeatures.apply(local, self, lo, hi, n_views, tuple(channels))
         if twice:
-            return full, full
+            return maps[0], maps[0]
         if second_none:
-            return full, None
-        return full[:, :channels[0]], full[:, channels[0]:]
+            return maps[0], None
+        return maps[0], maps[1]
 
     def global_mask_counts(self, ret):
         def count(o):       # masked MSE counts the valid rays, the unmasked one (GNT) every ray

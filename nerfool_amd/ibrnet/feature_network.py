@@ -109,20 +109,33 @@ class ResUNet(nn.Module):
             return [self.coarse_out_ch], False, True, size(H), size(W)
         return [self.coarse_out_ch, self.fine_out_ch], False, False, size(H), size(W)
 
-    def forward(self, x):
+    def _fused(self, x):
         frozen = not any(p.requires_grad for p in self.parameters())
-        if CNN_PATH == 'fused' and frozen and (x.is_cuda or ops._lib.emulated()):
-            if self.single_net or self.coarse_only:
-                out, = _FusedResUNet.apply(x, self, (self.coarse_out_ch,))
-                return (out, out) if self.single_net else (out, None)
-            return _FusedResUNet.apply(x, self, (self.coarse_out_ch, self.fine_out_ch))
+        return CNN_PATH == 'fused' and frozen and (x.is_cuda or ops._lib.emulated())
+
+    def _module_graph(self, x):
         x = F.relu(self.bn1(self.conv1(x)))
         x1 = self.layer1(x)
         x2 = self.layer2(x1)
         x3 = self.layer3(x2)
         y = self.iconv3(_join(x2, self.upconv3(x3)))
         y = self.iconv2(_join(x1, self.upconv2(y)))
-        out = self.out_conv(y).contiguous(memory_format=torch.channels_last)
+        return self.out_conv(y).contiguous(memory_format=torch.channels_last)
+
+    def forward_full(self, x):
+        """out_conv's whole output [N, coarse + fine channels, Hf, Wf] (channels-last), i.e. forward() before the channel
+        split -- what the view-sharded attack step exchanges between the ranks (eval_adv.RayShard)."""
+        if self._fused(x):
+            return _FusedResUNet.apply(x, self, (self.coarse_out_ch + self.fine_out_ch,))[0]
+        return self._module_graph(x)
+
+    def forward(self, x):
+        if self._fused(x):
+            if self.single_net or self.coarse_only:
+                out, = _FusedResUNet.apply(x, self, (self.coarse_out_ch,))
+                return (out, out) if self.single_net else (out, None)
+            return _FusedResUNet.apply(x, self, (self.coarse_out_ch, self.fine_out_ch))
+        out = self._module_graph(x)
         if self.single_net:
             return out, out
         if self.coarse_only:
