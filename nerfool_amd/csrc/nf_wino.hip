@@ -22,7 +22,9 @@
 //   dropping the fetch).  Two workgroups per CU (78 KB of LDS each).
 // Measured and dropped (tools/bench_conv3x3.py, 64 -> 64 at 189 x 252): two tile blocks per wave at one workgroup per CU
 // (+30 %), B operands loaded straight from global memory without LDS (+50 %), weights through a four-deep register ring (the
-// previous form of this kernel).
+// previous form of this kernel), the window by LDS-DMA as well (15 single-float pieces per wave and chunk with per-lane
+// addresses, nothing left for the compiler to drain: +3-6 % -- more address arithmetic and thinner memory requests than the six
+// 8-byte loads), 32 output channels per workgroup at three workgroups per CU (+-2 %).
 #include "nf_common.h"
 
 #include <type_traits>
