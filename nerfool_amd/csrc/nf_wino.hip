@@ -13,7 +13,9 @@
 // 2.25x fewer multiplies than the direct form.
 // Data movement: the accumulators take 128 of a lane's registers, so nothing else may live in registers for long.
 //   * weights: every wave streams ITS records from L2 into a private LDS ring by LDS-DMA (global_load_lds_dwordx4: 1 KB per
-//     instruction, no register in between), slots - 2 = 4 steps ahead, and reads a step's A operands back with ds_read_b128;
+//     instruction, no register in between), five steps ahead, and reads a step's A operands back with ds_read_b128 -- one step
+//     before the multiplications that use them (two register sets), like the B operands, so the LDS latency hides behind the
+//     previous step's eight MFMAs;
 //   * input: the next chunk's raw window is fetched into 12 registers at the top of a chunk and committed to the second LDS
 //     buffer at its end (one barrier per chunk).
 //   Both streams share the wave's in-order VM counter.  The DMA is issued from inline asm and waited for with exact counted
@@ -82,11 +84,11 @@ extern "C" int nf_wino_pack(const float* weight, int c_out, int c_in, int backwa
 
 struct WnTensor { int64_t ns, cs, rs; };        // element strides: image, channel, row (unit column stride)
 
-// Ring slots per wave.  A step's records are issued slots - 2 steps before they are used, into the slot that was read TWO
-// steps earlier: the wait of the step in between also retires the wave's LDS reads (lgkmcnt(0)), so a refill can never
-// overtake a read of the slot it overwrites.  (Refilling the slot read ONE step earlier -- a distance of slots - 1 --
-// corrupted a few outputs per launch on the large layers: an L2-hit DMA can land within ~250 cycles, before a read still
-// queued behind the neighbour workgroup's LDS traffic has executed.)
+// Ring slots per wave.  A step's records are issued slots - 1 steps before they are used, into the slot whose operands were
+// read (one step ahead of their use) two steps earlier: the wait of the step in between also retires the wave's LDS reads
+// (lgkmcnt(0)), so a refill can never overtake a read of the slot it overwrites.  (Refilling a slot right behind the step that
+// read it corrupted a few outputs per launch on the large layers: an L2-hit DMA can land within ~250 cycles, before a read
+// still queued behind the neighbour workgroup's LDS traffic has executed.)
 // KB = 2 (64 output channels per workgroup): 6 slots, 78 KB of LDS, two workgroups per CU.  KB = 1 (32 channels: half the
 // multiplications per staged window, for grids that would otherwise run a nearly empty second round of workgroups): 5 slots,
 // 50 KB, three workgroups per CU.
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
     constexpr int WN_PR = 10, WN_CH = WN_PR * WN_PS, WN_BUF = WN_CC * WN_CH;
     constexpr int STEP = 4 * KB * 64;                 // floats of one step's records = KB pieces of 256
     constexpr int WN_SLOTS = wn_slots(KB);
-    constexpr int DIST = WN_SLOTS - 2;
+    constexpr int DIST = WN_SLOTS - 1;
     HIP_DYNAMIC_SHARED(float, smem)
     float* ex = smem;
     const int lane = threadIdx.x & 63, w = wn_uniform(threadIdx.x >> 6);
@@ -228,45 +230,62 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
         wnext += STEP;
         wslot = wslot + 1 == WN_SLOTS ? 0 : wslot + 1;
     };
-    const int total_steps = chunks * 8;
+    // operands of a step, read from LDS ONE STEP AHEAD of the multiplications that use them (two register sets, parity of the
+    // step): the LDS latency then hides behind the previous step's eight MFMAs instead of idling the matrix pipe
+    float opa[2][4 * KB];
+    w2f opb[2][4];
+    auto read_ops = [&](float (&wa)[4 * KB], w2f (&pb)[4], const float* win, int s1) {
+        const float* rs = ring + rslot * STEP + 4 * lane;
+        rslot = rslot + 1 == WN_SLOTS ? 0 : rslot + 1;
 #pragma unroll
-    for (int q = 0; q < DIST; ++q) issue_step();      // total_steps >= 8 > DIST: never past the stream
+        for (int p = 0; p < KB; ++p) {
+            const w4f v4 = *reinterpret_cast<const w4f*>(rs + p * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wa[4 * p + j] = v4[j];
+        }
+        const float* pa = win + (2 * s1 + hh) * WN_CH;          // row w of B^T d B of the tile comes from two window rows
+        pb[0] = *reinterpret_cast<const w2f*>(pa + ra * WN_PS), pb[1] = *reinterpret_cast<const w2f*>(pa + ra * WN_PS + 2);
+        pb[2] = *reinterpret_cast<const w2f*>(pa + rb * WN_PS), pb[3] = *reinterpret_cast<const w2f*>(pa + rb * WN_PS + 2);
+    };
+#pragma unroll
+    for (int q = 0; q < DIST; ++q) issue_step();      // 8 steps at least in the stream, DIST < 8: never past its end
     fetch(0);
     commit(0);          // the compiler drains the VM counter for the fetched registers here: the first DIST steps have landed too
     __syncthreads();
+    read_ops(opa[0], opb[0], smem + lbase, 0);
     for (int chunk = 0; chunk < chunks; ++chunk) {
         const float* pbuf = smem + (chunk & 1) * WN_BUF + lbase;
+        const float* pnext = smem + ((chunk + 1) & 1) * WN_BUF + lbase;
         const bool last = chunk + 1 == chunks;
         auto step = [&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            // [A] records of step s + DIST into the slot step s - 2 read; nothing is issued past the end of the stream
-            if (!last || s + DIST < 8) issue_step();
-            // [B] the next chunk's window: eight steps of cover until the commit below
-            if (s == 0 && !last) fetch(chunk + 1);
-            // [C] step s's records were issued DIST steps ago; behind them in the counter: the steps issued since (DIST of
-            // them, fewer at the end of the stream) and, for s <= DIST, this chunk's window fetch
-            if (!last) wn_wait_vm<DIST * KB + (s <= DIST ? WN_FETCH_OPS : 0)>();
-            else wn_wait_vm<(7 - s < DIST ? 7 - s : DIST) * KB>();
-            // [D] this lane's A operands of the step
-            const float* rs = ring + rslot * STEP + 4 * lane;
-            rslot = rslot + 1 == WN_SLOTS ? 0 : rslot + 1;
-            float wa[4 * KB];
-#pragma unroll
-            for (int p = 0; p < KB; ++p) {
-                const w4f v4 = *reinterpret_cast<const w4f*>(rs + p * 256);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wa[4 * p + j] = v4[j];
+            // the chunk hand-over sits in front of step 7: the next window (fetched at step 0) goes to the other buffer -- last read
+            // one chunk ago, every wave has passed the barrier behind that -- and one barrier both publishes it and retires this
+            // chunk's buffer, whose last operands (step 7's) were read during step 6
+            if (s == 7 && !last) {
+                commit(chunk + 1);
+                __syncthreads();
             }
-            // [E] B operands: row w of B^T d B of the tile, from the raw window
-            const float* pa = pbuf + (2 * s + hh) * WN_CH;
-            const w2f a0 = *reinterpret_cast<const w2f*>(pa + ra * WN_PS), a1 = *reinterpret_cast<const w2f*>(pa + ra * WN_PS + 2);
-            const w2f b0 = *reinterpret_cast<const w2f*>(pa + rb * WN_PS), b1 = *reinterpret_cast<const w2f*>(pa + rb * WN_PS + 2);
+            // [A] records of step s + DIST into the slot whose operands were read two steps ago; never past the end of the stream
+            if (!last || s + DIST < 8) issue_step();
+            // [B] the next chunk's window: seven steps of cover until the commit
+            if (s == 0 && !last) fetch(chunk + 1);
+            if (!last || s < 7) {
+                // [C] the records of step s + 1 were issued DIST - 1 steps ago; behind them in the counter: the steps issued since
+                // (fewer at the end of the stream) and, for s < DIST, this chunk's window fetch
+                if (!last) wn_wait_vm<(DIST - 1) * KB + (s < DIST ? WN_FETCH_OPS : 0)>();
+                else wn_wait_vm<(6 - s < DIST - 1 ? 6 - s : DIST - 1) * KB>();
+                // [D] next step's operands
+                read_ops(opa[(s + 1) & 1], opb[(s + 1) & 1], s == 7 ? pnext : pbuf, (s + 1) & 7);
+            }
+            // [E] this step's multiplications
+            const w2f a0 = opb[s & 1][0], a1 = opb[s & 1][1], b0 = opb[s & 1][2], b1 = opb[s & 1][3];
             const float e0 = a0[0] + sb * b0[0], e1 = a0[1] + sb * b0[1], e2 = a1[0] + sb * b1[0], e3 = a1[1] + sb * b1[1];
             const float v[4] = {e0 - e2, e1 + e2, e2 - e1, e1 - e3};
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) acc[nu][kb] = WN_MFMA(wa[nu * KB + kb], v[nu], acc[nu][kb]);
+                for (int kb = 0; kb < KB; ++kb) acc[nu][kb] = WN_MFMA(opa[s & 1][nu * KB + kb], v[nu], acc[nu][kb]);
         };
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
@@ -276,11 +295,8 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
         step(std::integral_constant<int, 5>{});
         step(std::integral_constant<int, 6>{});
         step(std::integral_constant<int, 7>{});
-        // the other buffer was last read one chunk ago (every wave has passed the barrier behind it): fill it, then one barrier
-        // both publishes it and retires this chunk's buffer
-        if (!last) commit(chunk + 1);
-        __syncthreads();
     }
+    __syncthreads();      // every wave is done with the windows and its ring: the same memory now carries the output transform
     // ---- output transform Y = A^T M A: columns (nu) inside the wave, rows (w) across the waves through LDS (all KB at once)
     const int kbase = grp * (32 * KB);
     float* yn = y + n * yo.ns;
