@@ -34,6 +34,7 @@
 typedef float w16 __attribute__((ext_vector_type(16)));
 typedef float w2f __attribute__((ext_vector_type(2), aligned(4)));
 typedef float w4f __attribute__((ext_vector_type(4)));
+typedef float w2a __attribute__((ext_vector_type(2)));        // 8-byte aligned: LDS accesses (ds_read_b64 / ds_write_b64)
 #define WN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 __host__ __device__ constexpr int wn_nidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
             const bool ok0 = row_ok && a >= 0 && a < Wi, ok1 = row_ok && a + 1 >= 0 && a + 1 < Wi;
             const float v0 = ok0 ? (same ? raw[2 * q] : raw[2 * q + 1]) : 0.f;
             const float v1 = ok1 ? (same ? raw[2 * q + 1] : raw[2 * q]) : 0.f;
-            *reinterpret_cast<w2f*>(dst + 2 * q) = w2f{v0, v1};
+            *reinterpret_cast<w2a*>(dst + 2 * q) = w2a{v0, v1};
         }
     };
     auto fetch = [&](int chunk) {
@@ -233,8 +234,8 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
     // operands of a step, read from LDS ONE STEP AHEAD of the multiplications that use them (two register sets, parity of the
     // step): the LDS latency then hides behind the previous step's eight MFMAs instead of idling the matrix pipe
     float opa[2][4 * KB];
-    w2f opb[2][4];
-    auto read_ops = [&](float (&wa)[4 * KB], w2f (&pb)[4], const float* win, int s1) {
+    w2a opb[2][4];
+    auto read_ops = [&](float (&wa)[4 * KB], w2a (&pb)[4], const float* win, int s1) {
         const float* rs = ring + rslot * STEP + 4 * lane;
         rslot = rslot + 1 == WN_SLOTS ? 0 : rslot + 1;
 #pragma unroll
@@ -244,8 +245,10 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
             for (int j = 0; j < 4; ++j) wa[4 * p + j] = v4[j];
         }
         const float* pa = win + (2 * s1 + hh) * WN_CH;          // row w of B^T d B of the tile comes from two window rows
-        pb[0] = *reinterpret_cast<const w2f*>(pa + ra * WN_PS), pb[1] = *reinterpret_cast<const w2f*>(pa + ra * WN_PS + 2);
-        pb[2] = *reinterpret_cast<const w2f*>(pa + rb * WN_PS), pb[3] = *reinterpret_cast<const w2f*>(pa + rb * WN_PS + 2);
+        // every offset here is even: 8-byte LDS reads (the 4-byte-aligned type made them ds_read2_b32 pairs, whose two halves of a
+        // wave collide on the banks -- a third of the LDS cycles -- and whose 8-bit offsets cost an address add each)
+        pb[0] = *reinterpret_cast<const w2a*>(pa + ra * WN_PS), pb[1] = *reinterpret_cast<const w2a*>(pa + ra * WN_PS + 2);
+        pb[2] = *reinterpret_cast<const w2a*>(pa + rb * WN_PS), pb[3] = *reinterpret_cast<const w2a*>(pa + rb * WN_PS + 2);
     };
 #pragma unroll
     for (int q = 0; q < DIST; ++q) issue_step();      // 8 steps at least in the stream, DIST < 8: never past its end
@@ -279,8 +282,9 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
                 read_ops(opa[(s + 1) & 1], opb[(s + 1) & 1], s == 7 ? pnext : pbuf, (s + 1) & 7);
             }
             // [E] this step's multiplications
-            const w2f a0 = opb[s & 1][0], a1 = opb[s & 1][1], b0 = opb[s & 1][2], b1 = opb[s & 1][3];
-            const float e0 = a0[0] + sb * b0[0], e1 = a0[1] + sb * b0[1], e2 = a1[0] + sb * b1[0], e3 = a1[1] + sb * b1[1];
+            const w2a a0 = opb[s & 1][0], a1 = opb[s & 1][1], b0 = opb[s & 1][2], b1 = opb[s & 1][3];
+            // sb = +-1: the fused form is exact, i.e. the same value as a multiply and an add, in one instruction
+            const float e0 = fmaf(sb, b0[0], a0[0]), e1 = fmaf(sb, b0[1], a0[1]), e2 = fmaf(sb, b1[0], a1[0]), e3 = fmaf(sb, b1[1], a1[1]);
             const float v[4] = {e0 - e2, e1 + e2, e2 - e1, e1 - e3};
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu)
