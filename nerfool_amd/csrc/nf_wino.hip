@@ -13,7 +13,7 @@
 // 2.25x fewer multiplies than the direct form.
 // Data movement: the accumulators take 128 of a lane's registers, so nothing else may live in registers for long.
 //   * weights: every wave streams ITS records from L2 into a private LDS ring by LDS-DMA (global_load_lds_dwordx4: 1 KB per
-//     instruction, no register in between), five steps ahead, and reads a step's A operands back with ds_read_b128 -- one step
+//     instruction, no register in between), three steps ahead, and reads a step's A operands back with ds_read_b128 -- one step
 //     before the multiplications that use them (two register sets), like the B operands, so the LDS latency hides behind the
 //     previous step's eight MFMAs;
 //   * input: the next chunk's raw window is fetched into 12 registers at the top of a chunk and committed to the second LDS
@@ -90,10 +90,14 @@ struct WnTensor { int64_t ns, cs, rs; };        // element strides: image, chann
 // (lgkmcnt(0)), so a refill can never overtake a read of the slot it overwrites.  (Refilling a slot right behind the step that
 // read it corrupted a few outputs per launch on the large layers: an L2-hit DMA can land within ~250 cycles, before a read
 // still queued behind the neighbour workgroup's LDS traffic has executed.)
-// KB = 2 (64 output channels per workgroup): 6 slots, 78 KB of LDS, two workgroups per CU.  KB = 1 (32 channels: half the
-// multiplications per staged window, for grids that would otherwise run a nearly empty second round of workgroups): 5 slots,
-// 50 KB, three workgroups per CU.
-__host__ __device__ constexpr int wn_slots(int kb) { return kb == 1 ? 5 : 6; }
+// KB = 2 (64 output channels per workgroup): 4 slots -- the slot of a step is then a compile-time constant (4 divides the 8 steps
+// of a chunk): no slot bookkeeping, immediate LDS offsets; 6 slots with run-time indices measured 2 % slower -- 62 KB of staging,
+// 64 KB with the output exchange, two workgroups per CU.  KB = 1 (32 channels: half the multiplications per staged window):
+// 5 slots, 50 KB, three workgroups per CU.
+#ifndef WN_SLOTS2
+#define WN_SLOTS2 4
+#endif
+__host__ __device__ constexpr int wn_slots(int kb) { return kb == 1 ? 5 : WN_SLOTS2; }
 #define WN_FETCH_OPS 6      // VM instructions one window fetch issues per wave (two segments x three 8-byte loads)
 
 // ---- the three device-only primitives of the weight ring (their host forms keep the file compilable in the host pass)
@@ -116,6 +120,25 @@ __device__ __forceinline__ void wn_dma16(const float* gsrc, float* dst, int lane
                  : "memory");
 #else
     for (int j = 0; j < 4; ++j) dst[4 * lane + j] = gsrc[4 * lane + j];
+#endif
+}
+// the same for the PIECES (1 or 2) consecutive 1 KB pieces of a step under one M0 set-up: the instruction offset of the second
+// piece advances the global and the LDS address alike
+template <int PIECES>
+__device__ __forceinline__ void wn_dma16xn(const float* gsrc, float* dst, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned keep;
+    const unsigned lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)dst;
+    if (PIECES == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                     "global_load_lds_dwordx4 %1, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane * 16), "s"(lds), "s"(gsrc)
+                     : "memory");
+    else
+        wn_dma16(gsrc, dst, lane);
+#else
+    for (int j = 0; j < 4 * PIECES; ++j) dst[(j >> 2) * 256 + 4 * lane + (j & 3)] = gsrc[(j >> 2) * 256 + 4 * lane + (j & 3)];
 #endif
 }
 // wait until at most N of this wave's VM operations are outstanding (they retire in issue order) and all its LDS reads returned
@@ -225,19 +248,21 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
     // ring bookkeeping (all wave-uniform): slot to fill next, slot to read next, stream position of the next fill
     int wslot = 0, rslot = 0;
     const float* wnext = wsrc;
-    auto issue_step = [&]() {
-#pragma unroll
-        for (int p = 0; p < KB; ++p) wn_dma16(wnext + p * 256, ring + wslot * STEP + p * 256, lane);
+    // when the slot count divides the 8 steps of a chunk, a step's slot is a compile-time constant (`fixed`)
+    constexpr bool WN_FIXED = 8 % WN_SLOTS == 0;
+    auto issue_step = [&](int fixed) {
+        const int slot = WN_FIXED ? fixed % WN_SLOTS : wslot;
+        wn_dma16xn<KB>(wnext, ring + slot * STEP, lane);
         wnext += STEP;
-        wslot = wslot + 1 == WN_SLOTS ? 0 : wslot + 1;
+        if (!WN_FIXED) wslot = wslot + 1 == WN_SLOTS ? 0 : wslot + 1;
     };
     // operands of a step, read from LDS ONE STEP AHEAD of the multiplications that use them (two register sets, parity of the
     // step): the LDS latency then hides behind the previous step's eight MFMAs instead of idling the matrix pipe
     float opa[2][4 * KB];
     w2a opb[2][4];
     auto read_ops = [&](float (&wa)[4 * KB], w2a (&pb)[4], const float* win, int s1) {
-        const float* rs = ring + rslot * STEP + 4 * lane;
-        rslot = rslot + 1 == WN_SLOTS ? 0 : rslot + 1;
+        const float* rs = ring + (WN_FIXED ? s1 % WN_SLOTS : rslot) * STEP + 4 * lane;
+        if (!WN_FIXED) rslot = rslot + 1 == WN_SLOTS ? 0 : rslot + 1;
 #pragma unroll
         for (int p = 0; p < KB; ++p) {
             const w4f v4 = *reinterpret_cast<const w4f*>(rs + p * 256);
@@ -251,15 +276,16 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
         pb[2] = *reinterpret_cast<const w2a*>(pa + rb * WN_PS), pb[3] = *reinterpret_cast<const w2a*>(pa + rb * WN_PS + 2);
     };
 #pragma unroll
-    for (int q = 0; q < DIST; ++q) issue_step();      // 8 steps at least in the stream, DIST < 8: never past its end
+    for (int q = 0; q < DIST; ++q) issue_step(q);     // 8 steps at least in the stream, DIST < 8: never past its end
     fetch(0);
     commit(0);          // the compiler drains the VM counter for the fetched registers here: the first DIST steps have landed too
     __syncthreads();
     read_ops(opa[0], opb[0], smem + lbase, 0);
-    for (int chunk = 0; chunk < chunks; ++chunk) {
+    // one chunk = eight steps; `last` (the final chunk: nothing to fetch, the stream ends) is a compile-time flag of the body
+    auto run_chunk = [&](auto last_c, int chunk) {
+        constexpr bool last = decltype(last_c)::value;
         const float* pbuf = smem + (chunk & 1) * WN_BUF + lbase;
         const float* pnext = smem + ((chunk + 1) & 1) * WN_BUF + lbase;
-        const bool last = chunk + 1 == chunks;
         auto step = [&](auto sc) {
             constexpr int s = decltype(sc)::value;
             // the chunk hand-over sits in front of step 7: the next window (fetched at step 0) goes to the other buffer -- last read
@@ -270,7 +296,7 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
                 __syncthreads();
             }
             // [A] records of step s + DIST into the slot whose operands were read two steps ago; never past the end of the stream
-            if (!last || s + DIST < 8) issue_step();
+            if (!last || s + DIST < 8) issue_step(s + DIST);
             // [B] the next chunk's window: seven steps of cover until the commit
             if (s == 0 && !last) fetch(chunk + 1);
             if (!last || s < 7) {
@@ -299,7 +325,9 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
         step(std::integral_constant<int, 5>{});
         step(std::integral_constant<int, 6>{});
         step(std::integral_constant<int, 7>{});
-    }
+    };
+    for (int chunk = 0; chunk + 1 < chunks; ++chunk) run_chunk(std::false_type{}, chunk);
+    run_chunk(std::true_type{}, chunks - 1);
     __syncthreads();      // every wave is done with the windows and its ring: the same memory now carries the output transform
     // ---- output transform Y = A^T M A: columns (nu) inside the wave, rows (w) across the waves through LDS (all KB at once)
     const int kbase = grp * (32 * KB);
@@ -346,8 +374,9 @@ static void wn_launch(const float* records, const float* x, WnTensor xi, int Hi,
                       int n_img, int c_in, int c_out, int groups, hipStream_t st) {
     const int n_tiles = ((Wo + 15) / 16) * ((Ho + 7) / 8) * n_img;
     dim3 grid((unsigned)(8 * ((n_tiles + 7) / 8) * groups));
-    constexpr size_t smem = sizeof(float) * (2 * WN_CC * 10 * WN_PS + 4 * wn_slots(KB) * 4 * KB * 64);     // >= the KB * 8192 floats of the exchange
-    static_assert(smem >= sizeof(float) * KB * 8192, "the output exchange re-uses the staging memory");
+    // two windows + four rings; the output exchange (KB * 8192 floats) re-uses the same memory
+    constexpr size_t staging = sizeof(float) * (2 * WN_CC * 10 * WN_PS + 4 * wn_slots(KB) * 4 * KB * 64);
+    constexpr size_t smem = staging > sizeof(float) * KB * 8192 ? staging : sizeof(float) * KB * 8192;
     static bool once = false;           // more than the default 64 KB of dynamic LDS needs the attribute once per kernel
     if (!once) {
         (void)hipFuncSetAttribute((const void*)k_wino3x3<KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
