@@ -21,7 +21,7 @@
 //   Both streams share the wave's in-order VM counter.  The DMA is issued from inline asm and waited for with exact counted
 //   s_waitcnt vmcnt(N) (the window fetch is a FIXED six loads per wave, see fetch_seg), so a weight wait never has to sit out the
 //   HBM latency of the window fetch issued behind it -- with the earlier register ring that coupling cost 12-23 % (measured by
-//   dropping the fetch).  Two workgroups per CU (78 KB of LDS each).
+//   dropping the fetch).  Two workgroups per CU (64 KB of LDS each).
 // Measured and dropped (tools/bench_conv3x3.py, 64 -> 64 at 189 x 252): two tile blocks per wave at one workgroup per CU
 // (+30 %), B operands loaded straight from global memory without LDS (+50 %), weights through a four-deep register ring (the
 // previous form of this kernel), the window by LDS-DMA as well (15 single-float pieces per wave and chunk with per-lane
@@ -332,37 +332,51 @@ __global__ void __launch_bounds__(256, KB == 1 ? 3 : 2) k_wino3x3(const float* _
     // ---- output transform Y = A^T M A: columns (nu) inside the wave, rows (w) across the waves through LDS (all KB at once)
     const int kbase = grp * (32 * KB);
     float* yn = y + n * yo.ns;
+    // exchange image: [kb][writer wave m][output column j][r / 4][lane][r % 4] -- a lane's four consecutive accumulator registers
+    // travel as one 16-byte LDS access in both directions (48 LDS instructions per wave instead of 192 four-byte ones)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a0 = acc[0][kb][r], a1 = acc[1][kb][r], a2 = acc[2][kb][r], a3 = acc[3][kb][r];
-            ex[kb * 8192 + ((w * 2 + 0) * 16 + r) * 64 + lane] = a0 + a1 + a2;
-            ex[kb * 8192 + ((w * 2 + 1) * 16 + r) * 64 + lane] = a1 - a2 - a3;
+        for (int r4 = 0; r4 < 4; ++r4) {
+            w4f c0, c1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * r4 + i;
+                const float a0 = acc[0][kb][r], a1 = acc[1][kb][r], a2 = acc[2][kb][r], a3 = acc[3][kb][r];
+                c0[i] = a0 + a1 + a2;
+                c1[i] = a1 - a2 - a3;
+            }
+            float* e = ex + kb * 8192 + w * 2048 + r4 * 256 + 4 * lane;
+            *reinterpret_cast<w4f*>(e) = c0;
+            *reinterpret_cast<w4f*>(e + 1024) = c1;
         }
     __syncthreads();
     {
         const int oy = w & 1, rsel = 8 * (w >> 1);
         const int row = oy0 + 2 * tr + oy, col = ox0 + 2 * tc;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KB; ++kb) {
+            float o[2][8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const float* e = ex + kb * 8192 + j * 1024 + ((rsel >> 2) + hf) * 256 + 4 * lane;
+                    const w4f m0 = *reinterpret_cast<const w4f*>(e), m1 = *reinterpret_cast<const w4f*>(e + 2048);
+                    const w4f m2 = *reinterpret_cast<const w4f*>(e + 4096), m3 = *reinterpret_cast<const w4f*>(e + 6144);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[j][4 * hf + i] = oy == 0 ? m0[i] + m1[i] + m2[i] : m1[i] - m2[i] - m3[i];
+                }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int r = rsel + q;
-                float o[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float* e = ex + kb * 8192 + (j * 16 + r) * 64 + lane;
-                    const float m0 = e[0 * 2048], m1 = e[1 * 2048], m2 = e[2 * 2048], m3 = e[3 * 2048];
-                    o[j] = oy == 0 ? m0 + m1 + m2 : m1 - m2 - m3;
-                }
-                const int k = kbase + 32 * kb + wn_nidx(r, hh);
+                const int k = kbase + 32 * kb + wn_nidx(rsel + q, hh);
                 if (k < K && row < Ho) {
                     float* yp = yn + k * yo.cs + row * yo.rs + col;
-                    if (col + 1 < Wo) *reinterpret_cast<w2f*>(yp) = w2f{o[0], o[1]};
-                    else if (col < Wo) yp[0] = o[0];
+                    if (col + 1 < Wo) *reinterpret_cast<w2f*>(yp) = w2f{o[0][q], o[1][q]};
+                    else if (col < Wo) yp[0] = o[0][q];
                 }
             }
+        }
     }
 }
 
