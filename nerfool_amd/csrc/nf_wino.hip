@@ -93,11 +93,11 @@ struct WnTensor { int64_t ns, cs, rs; };        // element strides: image, chann
 // KB = 2 (64 output channels per workgroup): 4 slots -- the slot of a step is then a compile-time constant (4 divides the 8 steps
 // of a chunk): no slot bookkeeping, immediate LDS offsets; 6 slots with run-time indices measured 2 % slower -- 62 KB of staging,
 // 64 KB with the output exchange, two workgroups per CU.  KB = 1 (32 channels: half the multiplications per staged window):
-// 5 slots, 50 KB, three workgroups per CU.
+// 4 slots, 46 KB, three workgroups per CU.
 #ifndef WN_SLOTS2
 #define WN_SLOTS2 4
 #endif
-__host__ __device__ constexpr int wn_slots(int kb) { return kb == 1 ? 5 : WN_SLOTS2; }
+__host__ __device__ constexpr int wn_slots(int kb) { return kb == 1 ? 4 : WN_SLOTS2; }
 #define WN_FETCH_OPS 6      // VM instructions one window fetch issues per wave (two segments x three 8-byte loads)
 
 // ---- the three device-only primitives of the weight ring (their host forms keep the file compilable in the host pass)

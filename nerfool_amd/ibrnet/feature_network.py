@@ -185,8 +185,9 @@ class _Act:
         self.gs = g if self.gs is None else self.gs + g
 
 
-# 3x3 stride-1 convolutions: 'auto' times MIOpen against the Winograd matrix-core kernel (csrc/nf_wino.hip) once per
-# (shape, direction) on first use and keeps the faster one; 'wino' / 'miopen' force a side (NERFOOL_CONV3X3)
+# 3x3 stride-1 convolutions: 'auto' times MIOpen against the Winograd matrix-core kernel (csrc/nf_wino.hip) with 64 and with 32
+# output channels per workgroup, once per (shape, direction) on first use, and keeps the fastest; 'wino' / 'wino32' / 'miopen'
+# force a side (NERFOOL_CONV3X3)
 CONV3X3 = os.environ.get('NERFOOL_CONV3X3', 'auto')
 _CONV_CHOICE = {}
 
@@ -202,22 +203,26 @@ def _time_us(fn, iters=3):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-def _pick(key, miopen_fn, wino_fn):
-    """which implementation runs this convolution: decided once per key"""
-    if CONV3X3 in ('wino', 'miopen'):
+def _pick(key, candidates, timed):
+    """which implementation runs this convolution (candidates: name -> thunk): decided once per key"""
+    if CONV3X3 in candidates:
         return CONV3X3
+    if not timed:                       # CPU stand-in build: no timing, the default Winograd form
+        return 'wino'
     if key not in _CONV_CHOICE:
-        _CONV_CHOICE[key] = 'wino' if _time_us(wino_fn) < _time_us(miopen_fn) else 'miopen'
+        _CONV_CHOICE[key] = min(candidates, key=lambda name: _time_us(candidates[name]))
     return _CONV_CHOICE[key]
 
 
-def _wino_records(conv_w):
+def _wino_records(conv_w, k_per_group):
+    """(forward records, backward-data records) of a weight for one workgroup width; packed on first use"""
     key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
-    cache = _WINO_CACHE.get(id(conv_w))
+    slot = (id(conv_w), k_per_group)
+    cache = _WINO_CACHE.get(slot)
     if cache is None or cache[0] != key:
-        cache = (key, ops.wino_pack(conv_w, False, conv_w.device), ops.wino_pack(conv_w, True, conv_w.device))
-        _WINO_CACHE[id(conv_w)] = cache
-    return cache
+        cache = (key, ops.wino_pack(conv_w, False, conv_w.device, k_per_group), ops.wino_pack(conv_w, True, conv_w.device, k_per_group))
+        _WINO_CACHE[slot] = cache
+    return cache[1], cache[2]
 
 
 _WINO_CACHE = {}
@@ -226,20 +231,21 @@ _WINO_CACHE = {}
 def _conv3x3(tape, inp, w, sink):
     """3x3 stride-1 convolution on a pre-padded activation (padding 0) and its backward-data pass"""
     c_out, c_in = w.shape[0], w.shape[1]
-    use_gpu_timing = inp.is_cuda
-    rec = _wino_records(w)
-    mio_f = lambda: _aten.convolution(inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
-    win_f = lambda: ops.conv3x3_wino(rec[1], inp, c_out, 0)
-    how_f = _pick(('f', c_in, c_out) + tuple(inp.shape), mio_f, win_f) if use_gpu_timing else ('wino' if CONV3X3 != 'miopen' else 'miopen')
-    out = _Slot(win_f() if how_f == 'wino' else mio_f())
+    timed = inp.is_cuda
+    fwd = {'miopen': lambda: _aten.convolution(inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1),
+           'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out))[0], inp, c_out, 0, k_per_group=ops.wino_group(c_out))}
+    if c_out > 64:                      # narrower workgroups only matter when they add workgroups to a thin grid
+        fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[0], inp, c_out, 0, k_per_group=32)
+    out = _Slot(fwd[_pick(('f', c_in, c_out) + tuple(inp.shape), fwd, timed)]())
 
     def bwd():
         g_out = out.g
-        mio_b = lambda: _aten.convolution_backward(g_out, inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                   [True, False, False])[0]
-        win_b = lambda: ops.conv3x3_wino(rec[2], g_out, c_in, 2)
-        how_b = _pick(('b', c_in, c_out) + tuple(inp.shape), mio_b, win_b) if use_gpu_timing else ('wino' if CONV3X3 != 'miopen' else 'miopen')
-        sink(win_b() if how_b == 'wino' else mio_b())
+        cand = {'miopen': lambda: _aten.convolution_backward(g_out, inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                             [True, False, False])[0],
+                'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_in))[1], g_out, c_in, 2, k_per_group=ops.wino_group(c_in))}
+        if c_in > 64:
+            cand['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[1], g_out, c_in, 2, k_per_group=32)
+        sink(cand[_pick(('b', c_in, c_out) + tuple(inp.shape), cand, timed)]())
         out.g = None
     tape.append(bwd)
     return out

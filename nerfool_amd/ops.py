@@ -436,7 +436,7 @@ def conv1x1(records, bias, x, c_out, channels_last_out=False, x2=None):
 
 
 def wino_group(c_out):
-    """output channels per workgroup of the Winograd convolution: 64 keeps >= 2 workgroups per CU on the small layers"""
+    """default output channels per workgroup of the Winograd convolution"""
     return 32 if c_out <= 32 else 64
 
 
