@@ -192,15 +192,19 @@ CONV3X3 = os.environ.get('NERFOOL_CONV3X3', 'auto')
 _CONV_CHOICE = {}
 
 
-def _time_us(fn, iters=3):
+def _time_us(fn, iters=3, batches=2):
+    """best mean over `batches` batches of `iters` calls after one warm-up call (first use happens on a cold device)"""
     fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    best = float('inf')
+    for _ in range(batches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters * 1e3)
+    return best
 
 
 def _pick(key, candidates, timed):
