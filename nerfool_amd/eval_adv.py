@@ -108,11 +108,11 @@ class _GatherViewFeatures(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, local, shard, lo, hi, n_views, split):
-        full = torch.zeros((n_views,) + tuple(local.shape[1:]), dtype=local.dtype,
+        full = torch.empty((n_views,) + tuple(local.shape[1:]), dtype=local.dtype,
                            device=local.device).contiguous(memory_format=torch.channels_last)
         if hi > lo:
             full[lo:hi] = local
-        shard.all_reduce_nhwc_(full)
+        shard.broadcast_views_nhwc_(full)
         ctx.shard, ctx.lo, ctx.hi = shard, lo, hi
         # the per-map channel split happens HERE, so each map's gradient comes back as its own tensor (sliced outside,
         # autograd would assemble them with zero fills, strided copies and an add over all V views)
@@ -125,7 +125,7 @@ class _GatherViewFeatures(torch.autograd.Function):
         for g in gs:
             g = torch.zeros_like(ref, memory_format=torch.channels_last) if g is None \
                 else g.clone(memory_format=torch.channels_last)          # never reduce into autograd's own buffer
-            ctx.shard.all_reduce_nhwc_(g)
+            ctx.shard.reduce_views_nhwc_(g)
             mine.append(g[ctx.lo:ctx.hi])
         local = mine[0] if len(mine) == 1 else torch.cat(mine, dim=1).contiguous(memory_format=torch.channels_last)
         return local, None, None, None, None, None
@@ -141,9 +141,11 @@ class RayShard:
 
     source views (shard_views=True, SURVEY 8e "shard the CNN by view"): the V source images are independent samples of
     the feature CNN (InstanceNorm is per sample, feature_network.py:137,180), so rank r runs the CNN forward/backward only
-    for its contiguous block of views; the feature maps are exchanged with one all-reduce of disjointly filled buffers
-    forward and one all-reduce (sum) of d featmaps backward.  d(delta) of a rank is then non-zero only on its own views
-    and the all-reduce above assembles the full gradient."""
+    for its contiguous block of views.  Exchanges are per view, to / from the rank that owns it, so that only the bytes that
+    are needed travel (half of what all-reducing zero-filled buffers moves) and ragged or empty blocks need no special case:
+    forward a broadcast of each view's feature maps from its owner, backward a reduce (sum) of each view's d featmaps to
+    its owner; d(delta) of a rank is non-zero only on its own views, so the full gradient is assembled by a broadcast of
+    each view's slice from its owner instead of the all-reduce."""
 
     def __init__(self, group=None, shard_views=True):
         import torch.distributed as dist
@@ -160,10 +162,35 @@ class RayShard:
         lo = self.rank * base + min(self.rank, extra)
         return lo, lo + base + (1 if self.rank < extra else 0)
 
-    def all_reduce_nhwc_(self, t):
+    def owner(self, v, n_views):
+        """group rank that owns source view v (inverse of view_range)"""
+        base, extra = divmod(n_views, self.world)
+        cut = extra * (base + 1)
+        return v // (base + 1) if v < cut else extra + (v - cut) // base
+
+    def _global(self, r):
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
+    def _per_view(self, t, op):
+        """one collective per view on its contiguous block of t (views on the leading axis), enqueued back to back in view order
+        on every rank, waited for together"""
+        n_views = t.shape[0]
+        work = [op(t[v], self._global(self.owner(v, n_views))) for v in range(n_views)]
+        for w in work:
+            w.wait()
+
+    def broadcast_views_nhwc_(self, t):
+        """t [V,C,H,W] channels-last, view v valid on owner(v): afterwards every rank holds every view"""
         flat = t.permute(0, 2, 3, 1)            # channels-last storage seen as a plain contiguous [V,H,W,C] tensor
         assert flat.is_contiguous()
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._per_view(flat, lambda x, r: self.dist.broadcast(x, src=r, group=self.group, async_op=True))
+        return t
+
+    def reduce_views_nhwc_(self, t):
+        """t [V,C,H,W] channels-last: afterwards view v on owner(v) holds the sum over the ranks (elsewhere: unspecified)"""
+        flat = t.permute(0, 2, 3, 1)
+        assert flat.is_contiguous()
+        self._per_view(flat, lambda x, r: self.dist.reduce(x, dst=r, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
         return t
 
     def view_sharded_featmaps(self, feature_net, src_rgbs, delta):
@@ -194,7 +221,12 @@ class RayShard:
         return counts
 
     def all_reduce_grad(self, grad):
-        self.dist.all_reduce(grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        """the full d(delta) [1,V,H,W,3] on every rank.  Views sharded: a rank's gradient is non-zero only on its own views,
+        so the sum over the ranks IS each view's slice from its owner -- V broadcasts, half the bytes of an all-reduce."""
+        if self.shard_views and self.world > 1 and grad.dim() == 5 and grad.is_contiguous():
+            self._per_view(grad[0], lambda x, r: self.dist.broadcast(x, src=r, group=self.group, async_op=True))
+        else:
+            self.dist.all_reduce(grad, op=self.dist.ReduceOp.SUM, group=self.group)
         return grad
 
 
