@@ -280,10 +280,14 @@ def main():
     roofline = None
     if dominant:
         d = table[dominant]
+        t = pmc_traffic(dominant, a)
+        if t is not None and t.get('algorithmic_bytes_per_launch') is None and dominant == 'nf_conv3x3_wino':
+            t['algorithmic_bytes_per_launch'] = int(np.mean(wino_bytes))     # input + output + transformed weights
+        # traffic: HBM bytes per launch of the dominant kernel from the committed PMC passes (null when they do not cover this workload)
         roofline = {'kernel': dominant, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'], 'unit': d['unit'],
-                    'frac': d['frac'], 'traffic': pmc_traffic(dominant, a)}
-        if dominant == 'nf_conv3x3_wino' and roofline['traffic'] is not None and roofline['traffic'].get('algorithmic_bytes_per_launch') is None:
-            roofline['traffic']['algorithmic_bytes_per_launch'] = int(np.mean(wino_bytes))     # input + output + transformed weights
+                    'frac': d['frac'], 'traffic': None if t is None else t['hbm_bytes_per_launch'], 'traffic_unit': 'B/launch',
+                    'traffic_algorithmic': None if t is None else t.get('algorithmic_bytes_per_launch'),
+                    'traffic_source': None if t is None else t['source']}
 
     rays_per_step = a.n_rand * world
     out = {

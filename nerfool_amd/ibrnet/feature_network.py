@@ -110,8 +110,13 @@ class ResUNet(nn.Module):
         return [self.coarse_out_ch, self.fine_out_ch], False, False, size(H), size(W)
 
     def _fused(self, x):
-        frozen = not any(p.requires_grad for p in self.parameters())
-        return CNN_PATH == 'fused' and frozen and (x.is_cuda or ops._lib.emulated())
+        # the fused executor computes no weight gradients: frozen parameters only.  Walking all ~140 parameters on every
+        # call costs 70 us of host time; the first convolution's flag is the sentinel for "somebody changed requires_grad"
+        sentinel = self.conv1.weight.requires_grad
+        if getattr(self, '_frozen_seen', None) != sentinel:
+            self._frozen_seen = sentinel
+            self._frozen = not any(p.requires_grad for p in self.parameters())
+        return CNN_PATH == 'fused' and self._frozen and (x.is_cuda or ops._lib.emulated())
 
     def _module_graph(self, x):
         x = F.relu(self.bn1(self.conv1(x)))

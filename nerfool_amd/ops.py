@@ -6,8 +6,14 @@ from . import _lib
 from . import prof
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(t):
+    """hipStream_t of torch's current stream on t's device (the raw-handle query: a step makes ~250 launches)"""
     if t.is_cuda:
+        if _raw_stream is not None:
+            return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
         return torch.cuda.current_stream(t.device).cuda_stream
     return 0
 

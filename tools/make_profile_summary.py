@@ -25,7 +25,7 @@ def main():
     steady = open(os.path.join(P, 'r01_steady_state_kernels.txt')).read().rstrip()
     long_run = load('r01_bench_1000iters_ibrnet.json')
     r, c = b['roofline'], b['cpu_baseline']
-    tr = r.get('traffic') or {}
+    tr = {'hbm_bytes_per_launch': r.get('traffic') or 0, 'algorithmic_bytes_per_launch': r.get('traffic_algorithmic')}
     md = []
     md.append('# Round 1 profiles (MI355X, gfx950) -- final state of the round\n')
     md.append('Commands (all through `tools/profile_round.sh` on one box; `cd /tmp; export TMPDIR=/tmp` first):\n')
