@@ -11,6 +11,7 @@ Host-side component.  Differences from the reference, none observabl
     (nf_legacy_choice, csrc/nf_pixel_draw.hip) on a copy of the generator state, and adopted -- state included -- only if
     that next call asks for the same draw and nobody touched `rng` in between: the stream any caller observes is unchanged."""
 import ctypes
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -22,7 +23,7 @@ rng = np.random.RandomState(234)
 
 _pool = None
 _ahead = None            # (pop, size, generator object, its state when the job was queued, future)
-_scratch = {}            # helper-thread scratch per population size
+_scratch = threading.local()          # per-thread shuffle buffer (the helper thread and direct callers never share one)
 
 
 def legacy_choice(state, pop, size):
@@ -31,10 +32,9 @@ def legacy_choice(state, pop, size):
     key = np.array(state[1], dtype=np.uint32)
     pos = ctypes.c_int32(int(state[2]))
     out = np.empty((size,), dtype=np.int64)
-    scratch = _scratch.get(pop)
-    if scratch is None:
-        _scratch.clear()
-        scratch = _scratch[pop] = np.empty((pop,), dtype=np.int64)
+    scratch = getattr(_scratch, 'buf', None)
+    if scratch is None or scratch.shape[0] != pop:
+        scratch = _scratch.buf = np.empty((pop,), dtype=np.int64)
     _lib.check(_lib.lib().nf_legacy_choice(key.ctypes.data, ctypes.byref(pos), pop, size, out.ctypes.data, scratch.ctypes.data),
                'nf_legacy_choice')
     return out, (state[0], key, pos.value) + tuple(state[3:])
