@@ -447,7 +447,8 @@ def check_fused_cnn_glue(dev):
                                    d_extra_sub=dsub.to(dev))
         assert_close(dx, gx, 1e-3, 1e-4 * float(gx.abs().max()), 'gradient of a stride-2 consumer')
     # 3x3 stride-1 convolutions as Winograd F(2x2,3x3) on the matrix cores: forward (padding 0) and backward-data, ragged sizes
-    for (N, ci, co, H, W) in ((1, 16, 32, 9, 18), (2, 32, 64, 7, 21), (1, 48, 96, 16, 16), (1, 112, 32, 5, 4)):
+    for (N, ci, co, H, W) in ((1, 16, 32, 9, 18), (2, 32, 64, 7, 21), (1, 48, 96, 16, 16), (1, 112, 32, 5, 4), (1, 40, 40, 3, 2),
+                             (3, 24, 72, 2, 33)):      # also channel counts that are no multiple of the 16-channel chunk / 32-channel tile
         wgt = torch.randn(co, ci, 3, 3, generator=gen) * 0.2
         xin = torch.randn(N, ci, H + 2, W + 2, generator=gen)
         ref = F.conv2d(xin, wgt)

@@ -65,11 +65,13 @@ def test_winograd_full_size_layers_repeated():
         x = torch.randn(4, ci, H + 2, W + 2, generator=gen).cuda()
         gy = torch.randn(4, co, H, W, generator=gen).cuda()
         ref, gref = F.conv2d(x, wgt), F.conv_transpose2d(gy, wgt)
-        rf, rb = ops.wino_pack(wgt, False, 'cuda'), ops.wino_pack(wgt, True, 'cuda')
-        for _ in range(8):
-            got, ggot = ops.conv3x3_wino(rf, x, co, 0), ops.conv3x3_wino(rb, gy, ci, 2)
-            assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (ci, co, H, W)
-            assert float((ggot - gref).abs().max()) <= 2e-5 * float(gref.abs().max()), (ci, co, H, W)
+        for kg in (64, 32):              # both workgroup widths the per-layer timing chooses from
+            rf, rb = ops.wino_pack(wgt, False, 'cuda', kg), ops.wino_pack(wgt, True, 'cuda', kg)
+            for _ in range(6):
+                got = ops.conv3x3_wino(rf, x, co, 0, k_per_group=kg)
+                ggot = ops.conv3x3_wino(rb, gy, ci, 2, k_per_group=kg)
+                assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (ci, co, H, W, kg)
+                assert float((ggot - gref).abs().max()) <= 2e-5 * float(gref.abs().max()), (ci, co, H, W, kg)
 
 
 def test_fused_resunet_matches_module_graph():
