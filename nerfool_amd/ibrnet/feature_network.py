@@ -116,7 +116,14 @@ class ResUNet(nn.Module):
         if getattr(self, '_frozen_seen', None) != sentinel:
             self._frozen_seen = sentinel
             self._frozen = not any(p.requires_grad for p in self.parameters())
-        return CNN_PATH == 'fused' and self._frozen and (x.is_cuda or ops._lib.emulated())
+        if CNN_PATH != 'fused':
+            return False                # NERFOOL_CNN=torch: the plain nn.Module graph, an explicit choice (tests compare against it)
+        if not (x.is_cuda or ops._lib.emulated()):
+            raise RuntimeError('ResUNet: input on %s -- the feature CNN runs on the GPU only (no CPU fallback)' % x.device)
+        if not self._frozen:
+            raise NotImplementedError('ResUNet: the fused executor differentiates w.r.t. its input only; freeze the weights '
+                                      '(requires_grad_(False), as IBRNetModel does) or set NERFOOL_CNN=torch')
+        return True
 
     def _module_graph(self, x):
         x = F.relu(self.bn1(self.conv1(x)))

@@ -121,3 +121,18 @@ def test_pixel_lookahead_keeps_the_stream(built_library):
     assert np.array_equal(sample_ray._choice(7000, 32, False), plain.choice(7000, size=(32,), replace=False))
     assert sample_ray._ahead is None
     assert np.array_equal(sample_ray.rng.get_state()[1], plain.get_state()[1])
+
+
+def test_feature_cnn_has_no_cpu_fallback():
+    """A CPU tensor (outside the CPU stand-in build the parity tests bind explicitly) or trainable weights raise instead of
+    silently running the nn.Module graph."""
+    import torch
+    from nerfool_amd import _lib
+    from nerfool_amd.ibrnet import feature_network as fn
+    if _lib.emulated() or fn.CNN_PATH != 'fused':
+        pytest.skip('stand-in build bound / torch graph selected in this process')
+    net = fn.ResUNet(coarse_out_ch=32, fine_out_ch=32)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net(torch.zeros(1, 3, 32, 32))
