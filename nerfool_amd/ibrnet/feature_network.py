@@ -110,12 +110,9 @@ class ResUNet(nn.Module):
         return [self.coarse_out_ch, self.fine_out_ch], False, False, size(H), size(W)
 
     def _fused(self, x):
-        # the fused executor computes no weight gradients: frozen parameters only.  Walking all ~140 parameters on every
-        # call costs 70 us of host time; the first convolution's flag is the sentinel for "somebody changed requires_grad"
-        sentinel = self.conv1.weight.requires_grad
-        if getattr(self, '_frozen_seen', None) != sentinel:
-            self._frozen_seen = sentinel
-            self._frozen = not any(p.requires_grad for p in self.parameters())
+        # the fused executor computes no weight gradients: frozen parameters only (checked on every call: ~70 us of host time
+        # next to a multi-millisecond network, and a partly unfrozen network must not pass silently)
+        self._frozen = not any(p.requires_grad for p in self.parameters())
         if CNN_PATH != 'fused':
             return False                # NERFOOL_CNN=torch: the plain nn.Module graph, an explicit choice (tests compare against it)
         if not (x.is_cuda or ops._lib.emulated()):
@@ -231,17 +228,18 @@ def _pick(key, candidates, timed):
 
 
 def _wino_records(conv_w, k_per_group):
-    """(forward records, backward-data records) of a weight for one workgroup width; packed on first use"""
+    """(forward records, backward-data records) of a weight for one workgroup width; packed on first use.  The records hang
+    on the weight tensor itself (like conv._nf_records of the 1x1 convolutions), so they die with it and can never be taken
+    for another weight's; they are re-packed when the weight's storage, version or device changed."""
     key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
-    slot = (id(conv_w), k_per_group)
-    cache = _WINO_CACHE.get(slot)
+    store = getattr(conv_w, '_nf_wino', None)
+    if store is None:
+        store = conv_w._nf_wino = {}
+    cache = store.get(k_per_group)
     if cache is None or cache[0] != key:
         cache = (key, ops.wino_pack(conv_w, False, conv_w.device, k_per_group), ops.wino_pack(conv_w, True, conv_w.device, k_per_group))
-        _WINO_CACHE[slot] = cache
+        store[k_per_group] = cache
     return cache[1], cache[2]
-
-
-_WINO_CACHE = {}
 
 
 def _conv3x3(tape, inp, w, sink):
@@ -304,11 +302,19 @@ def _conv1x1(tape, inp, conv, sink, channels_last_out=False):
     return out
 
 
+# Checker hook (tests only): a list here collects the interior of every ReLU output in network order, from which a test
+# reads the activation pattern this evaluation used (the backward takes ReLU' from the same stored output / the same
+# arithmetic).  The ReLU is the network's one discontinuity: see oracle/feature_net_ref.ReluTrace.
+TRACE_RELU = None
+
+
 def _fuse(tape, xs, norm, res, act, pad):
     gamma, beta = (norm.weight, norm.bias) if norm is not None else (None, None)
     yp, mean, rstd = ops.in_act_pad_fwd(xs.v, gamma, beta, None if res is None else res.interior(), act, pad,
                                         eps=norm.eps if norm is not None else 0.0)
     a = _Act(yp, pad)
+    if TRACE_RELU is not None and act == ops.ACT_RELU:
+        TRACE_RELU.append(a.interior())
 
     def bwd():
         dx, d_res = ops.in_act_pad_bwd(a.gp, a.gi, yp, xs.v if norm is not None else None, gamma, mean, rstd, act, pad,
@@ -381,9 +387,17 @@ def _join_pad(tape, enc, dec, pad):
     return out
 
 
-def fused_forward(net, x):
+class _NoTape:
+    """tape of an evaluation nobody will differentiate (torch.no_grad(), or an input without requires_grad): the backward
+    closures are dropped as they are made, so no activation outlives its consumer (full-image evaluation)"""
+
+    def append(self, step):
+        pass
+
+
+def fused_forward(net, x, need_grad=True):
     """x [V,3,H,W] -> (out [V,64,Hf,Wf] NCHW, tape, input slot)."""
-    tape = []
+    tape = [] if need_grad else _NoTape()
     xin = _Slot(x.contiguous())
     a = _fuse(tape, xin, None, None, ops.ACT_NONE, 3)
     t = _conv(tape, a.yp, net.conv1.weight, 2, a.add_p)
@@ -416,7 +430,7 @@ class _FusedResUNet(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, net, split):
-        out, tape, xin = fused_forward(net, x)
+        out, tape, xin = fused_forward(net, x, need_grad=ctx.needs_input_grad[0])
         ctx.tape, ctx.out, ctx.xin = tape, out, xin
         full = out.v.contiguous(memory_format=torch.channels_last)
         if len(split) == 1:
@@ -425,6 +439,9 @@ class _FusedResUNet(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *d_outs):
+        if ctx.tape is None:
+            raise RuntimeError('ResUNet (fused executor): the backward tape is consumed by the first backward pass and its '
+                               'activations are released; call the network again instead of backward(retain_graph=True) twice')
         ref = next(g for g in d_outs if g is not None)
         d_outs = [torch.zeros_like(ref) if g is None else g for g in d_outs]
         ctx.out.g = d_outs[0] if len(d_outs) == 1 else tuple(d_outs)     # any layout: the 1x1 backward addresses it by strides

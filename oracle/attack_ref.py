@@ -26,10 +26,11 @@ def init_adv_perturb(src_rgbs, epsilon, upper_limit=1.0, lower_limit=0.0, genera
     return delta.requires_grad_(True)
 
 
-def attack_loss(delta, cnn_state, params_coarse, params_fine, src_ray_batch, train_ray_batch, cfg):
-    """ref: eval/ibrnet/eval_adv.py:292-310 -- features from PERTURBED images, colours from CLEAN images."""
+def attack_loss(delta, cnn_state, params_coarse, params_fine, src_ray_batch, train_ray_batch, cfg, cnn_trace=None):
+    """ref: eval/ibrnet/eval_adv.py:292-310 -- features from PERTURBED images, colours from CLEAN images.
+    cnn_trace: optional feature_net_ref.ReluTrace (evaluate the CNN on a given ReLU activation pattern / record its own)."""
     imgs = (src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2)
-    featmaps = fnet.resunet_forward(cnn_state, imgs)
+    featmaps = fnet.resunet_forward(cnn_state, imgs, trace=cnn_trace)
     ret = ib.render_rays(train_ray_batch, params_coarse, params_fine, featmaps, cfg['N_samples'],
                          inv_uniform=cfg['inv_uniform'], N_importance=cfg['N_importance'], det=True,
                          white_bkgd=cfg.get('white_bkgd', False), src_ray_batch=src_ray_batch,
@@ -106,3 +107,44 @@ def pick_pixels(rng, n_pixels, n_rand):
 def new_pixel_rng():
     """ref: ibrnet/sample_ray.py:20."""
     return np.random.RandomState(234)
+
+
+def float64_gradient(delta, cnn_state, params_coarse, params_fine, data, picks, cfg, relu_masks=None):
+    """Ground truth for gradient-parity checks: d loss / d delta of attack_loss evaluated in float64 from the fp32 inputs
+    (`data` = loader-style batch dict of the target view, `picks` = flat pixel indices of the drawn rays; the rays are the
+    fp32 rays of ibrnet_ref.rays_single_image, an input of the step like the images).  Pinned against the reference's own
+    float64 evaluation by tests/test_oracle_golden.py (tests/golden/attack_grad64.npz).
+    relu_masks: evaluate the CNN on this ReLU activation pattern (feature_net_ref.ReluTrace) instead of its own.
+    -> (loss float, grad float64 tensor, ReluTrace with the float64 ReLU arguments)"""
+    f64 = lambda t: t.detach().cpu().double() if torch.is_tensor(t) and t.is_floating_point() else t
+    cam = data['camera'].detach().cpu().float()
+    H, W = int(cam[0, 0]), int(cam[0, 1])
+    ro, rd = ib.rays_single_image(H, W, cam[:, 2:18].reshape(-1, 4, 4), cam[:, 18:34].reshape(-1, 4, 4))
+    idx = torch.as_tensor(np.asarray(picks, dtype=np.int64))
+    src = {'src_rgbs': f64(data['src_rgbs']), 'src_cameras': f64(data['src_cameras'])}
+    batch = {'ray_o': f64(ro[idx]), 'ray_d': f64(rd[idx]), 'rgb': f64(data['rgb'].detach().cpu().reshape(-1, 3)[idx]),
+             'camera': f64(cam), 'depth_range': f64(data['depth_range']), 'src_rgbs': src['src_rgbs'],
+             'src_cameras': src['src_cameras']}
+    trace = fnet.ReluTrace(relu_masks)
+    d = f64(delta).clone().requires_grad_(True)
+    loss, _ = attack_loss(d, {k: f64(v) for k, v in cnn_state.items()}, {k: f64(v) for k, v in params_coarse.items()},
+                          {k: f64(v) for k, v in params_fine.items()}, src, batch, cfg, cnn_trace=trace)
+    grad, = torch.autograd.grad(loss, d)
+    return float(loss.detach()), grad, trace
+
+
+def relu_pattern_flips(trace64, masks):
+    """Units whose ReLU decision in `masks` differs from the float64 evaluation recorded in `trace64`:
+    -> (number of flipped units, number of units, largest |argument| of a flipped unit relative to its plane's rms).
+    A flip is legitimate rounding behaviour only where the float64 argument is within fp32 noise of zero."""
+    n_flip, n_all, worst = 0, 0, 0.0
+    for pre, m in zip(trace64.pre, masks):
+        m = m.to(pre.device)
+        diff = (pre > 0) != m
+        n_all += pre.numel()
+        k = int(diff.sum())
+        if k:
+            rms = pre.pow(2).mean(dim=(2, 3), keepdim=True).sqrt().expand_as(pre)
+            worst = max(worst, float((pre.abs() / rms)[diff].max()))
+            n_flip += k
+    return n_flip, n_all, worst

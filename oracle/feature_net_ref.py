@@ -26,13 +26,36 @@ def _inorm(sd, name, x):
     return F.instance_norm(x, weight=sd[name + '.weight'], bias=sd[name + '.bias'], eps=1e-5)
 
 
-def _basic_block(sd, prefix, x, stride):
+class ReluTrace:
+    """Checker hook for the ONE discontinuous operation of the network.  A ReLU whose argument is within rounding noise of
+    zero can land on either side in two correct fp32 evaluations, and one flipped unit of an N-element activation changes the
+    gradient by ~1/sqrt(N) of its norm.  With `masks` (bool tensors in call order: stem, then per block the inner and the
+    outer ReLU) every ReLU becomes `x * mask`, i.e. the network is evaluated on the activation pattern of another evaluation;
+    `pre` collects the arguments so that a test can list the flipped units and how close to zero they were."""
+
+    def __init__(self, masks=None):
+        self.masks = None if masks is None else list(masks)
+        self.pre = []
+
+    def relu(self, x):
+        i = len(self.pre)
+        self.pre.append(x.detach())
+        if self.masks is None:
+            return F.relu(x)
+        return x * self.masks[i].to(device=x.device, dtype=x.dtype)
+
+
+def _relu(x, trace):
+    return F.relu(x) if trace is None else trace.relu(x)
+
+
+def _basic_block(sd, prefix, x, stride, trace=None):
     """ref: ibrnet/feature_network.py:38-78."""
-    y = F.relu(_inorm(sd, prefix + '.bn1', _conv(sd, prefix + '.conv1', x, stride)))
+    y = _relu(_inorm(sd, prefix + '.bn1', _conv(sd, prefix + '.conv1', x, stride)), trace)
     y = _inorm(sd, prefix + '.bn2', _conv(sd, prefix + '.conv2', y))
     if (prefix + '.downsample.0.weight') in sd:
         x = _inorm(sd, prefix + '.downsample.1', _conv(sd, prefix + '.downsample.0', x, stride))
-    return F.relu(y + x)
+    return _relu(y + x, trace)
 
 
 def _conv_in_elu(sd, prefix, x):
@@ -54,13 +77,14 @@ def _skip(small, big):
     return torch.cat([big, small], dim=1)
 
 
-def resunet_forward(sd, x, coarse_out_ch=32, fine_out_ch=32):
-    """x [V,3,H,W] -> (coarse [V,32,Hf,Wf], fine [V,32,Hf,Wf]).  ref: ibrnet/feature_network.py:245-268."""
-    x = F.relu(_inorm(sd, 'bn1', _conv(sd, 'conv1', x, stride=2)))
+def resunet_forward(sd, x, coarse_out_ch=32, fine_out_ch=32, trace=None):
+    """x [V,3,H,W] -> (coarse [V,32,Hf,Wf], fine [V,32,Hf,Wf]).  ref: ibrnet/feature_network.py:245-268.
+    trace: optional ReluTrace (checker hook, see there)."""
+    x = _relu(_inorm(sd, 'bn1', _conv(sd, 'conv1', x, stride=2)), trace)
     feats = []
     for name, n_blocks, _ in _STAGES:
         for b in range(n_blocks):
-            x = _basic_block(sd, '%s.%d' % (name, b), x, stride=2 if b == 0 else 1)
+            x = _basic_block(sd, '%s.%d' % (name, b), x, stride=2 if b == 0 else 1, trace=trace)
         feats.append(x)
     x1, x2, x3 = feats
     y = _conv_in_elu(sd, 'iconv3', _skip(x2, _up(sd, 'upconv3', x3)))

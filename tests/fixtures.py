@@ -54,3 +54,25 @@ def assert_close(a, b, rtol=1e-4, atol=1e-5, name='', frac_ok=0.0):
         i = np.unravel_index(np.argmax(np.abs(a - b) - rtol * np.abs(b)), a.shape) if a.ndim else ()
         raise AssertionError('%s: %d/%d elements off (max abs err %.3e at %s: %r vs %r)'
                              % (name, bad.sum(), bad.size, np.abs(a - b).max(), i, a[i], b[i]))
+
+
+# the medium case of tests/golden/attack_grad64.npz: every input is regenerated from seeds (only picks + outputs are stored)
+GRAD64_MEDIUM = dict(H=96, W=128, V=4, R=256, S=64, N_imp=64, seed=6)
+
+
+def grad64_medium_inputs(c=GRAD64_MEDIUM):
+    """(data, ResUNet state, coarse params, fine params, delta0, pixel picks) of the medium float64 gradient case; the same
+    calls are made by tests/golden/make_golden_grad64.py in front of the reference."""
+    from nerfool_amd.synthetic import make_scene
+    from oracle.feature_net_ref import random_resunet_state
+    from oracle.ibrnet_ref import random_ibrnet_params
+    data = make_scene(c['H'], c['W'], c['V'], seed=c['seed'], tilt=0.3)
+    cnn_sd = random_resunet_state(c['seed'] + 100)
+    pc = random_ibrnet_params(c['S'], seed=30 + c['seed'])
+    pf = random_ibrnet_params(c['S'] + c['N_imp'], seed=40 + c['seed'])
+    gen = torch.Generator().manual_seed(c['seed'] + 5)
+    eps = 8 / 255.
+    delta0 = torch.zeros_like(data['src_rgbs']).uniform_(-eps, eps, generator=gen)
+    delta0 = torch.max(torch.min(delta0, 1 - data['src_rgbs']), 0 - data['src_rgbs'])
+    picks = np.random.RandomState(234).choice(c['H'] * c['W'], size=(c['R'],), replace=False)
+    return data, cnn_sd, pc, pf, delta0, picks

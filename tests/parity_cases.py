@@ -153,11 +153,28 @@ def check_render_rays(case, dev):
             assert_close(ret[level][k], g.np('%s/%s' % (level, k)), 2e-3, 5e-4, '%s %s' % (level, k), frac_ok=2e-3)
     assert_close(loss, g.np('loss'), 1e-3, 1e-6, 'loss')
     grads = torch.autograd.grad(loss, [fm_c, fm_f] if cfg['N_importance'] else [fm_c])
-    gc = g.np('grad/featmap_coarse')
-    assert_close(grads[0], gc, 5e-3, 2e-3 * float(np.abs(gc).max()), 'd loss / d featmap_coarse', frac_ok=1e-3)
+    # d loss / d feature maps against the float64 oracle on the same fp32 inputs (the oracle's render path in float64 is
+    # pinned to the reference's float64 run through attack_grad64.npz's dfm64 in tests/test_oracle_golden.py): norm-wise
+    # <= 1e-3 (north_star), element-wise 1e-3 of the largest entry with 0.1 % outliers for the discrete events of the render
+    # path (re-sampling bin flips at cdf ties, render_ray.py:62-64, move a few samples' taps to neighbouring pixels)
+    d64 = lambda t: t.detach().cpu().double()
+    rb64 = {k: d64(v) for k, v in rb.items()}
+    f64c, f64f = d64(fm_c).requires_grad_(True), d64(fm_f).requires_grad_(True)
+    pc64 = {k: d64(v) for k, v in g.params('coarse').items()}
+    pf64 = {k: d64(v) for k, v in g.params('fine').items()} if cfg['N_importance'] else None
+    ret64 = ib.render_rays(rb64, pc64, pf64, (f64c, f64f), cfg['S'], inv_uniform=cfg['inv_uniform'], N_importance=cfg['N_importance'],
+                           det=True, white_bkgd=cfg['white_bkgd'], anti_alias_pooling=cfg['anti_alias_pooling'])
+    loss64 = ib.criterion(ret64['outputs_coarse'], rb64)
     if cfg['N_importance']:
-        gf = g.np('grad/featmap_fine')
-        assert_close(grads[1], gf, 5e-3, 5e-3 * float(np.abs(gf).max()), 'd loss / d featmap_fine', frac_ok=2e-3)
+        loss64 = loss64 + ib.criterion(ret64['outputs_fine'], rb64)
+    g64 = torch.autograd.grad(loss64, [f64c, f64f] if cfg['N_importance'] else [f64c])
+    for name, mine, want, ref32 in zip(('coarse', 'fine'), grads, g64, ('grad/featmap_coarse', 'grad/featmap_fine')):
+        err = float((d64(mine) - want).norm() / want.norm())
+        floor = float(np.linalg.norm(g.np(ref32) - want.numpy()) / want.norm())
+        print('[grad parity] %s d loss / d featmap_%s: rel-L2 vs float64 %.3e (reference fp32: %.3e)' % (case, name, err, floor))
+        assert err <= 1e-3, 'd loss / d featmap_%s: rel-L2 %.3e vs float64' % (name, err)
+        assert_close(mine, want, 0, 1e-3 * float(want.abs().max()), 'd loss / d featmap_' + name, frac_ok=1e-3)
+    assert abs(float(loss) - float(loss64)) <= 1e-4 * float(loss64), 'loss vs float64'
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -178,6 +195,83 @@ def _attack_setup(dev):
                            lr_step_size=4, lr_gamma=0.5, adv_iters=n_adam, chunk_size=1000)
     sampler = RaySamplerSingleImage(data, dev)
     return g, args, model, data, sampler, (H, W, V, R, S, N_imp, n_adam, n_sign)
+
+
+def grad64_setup(case, dev):
+    """(Golden('attack_grad64'), args, model, data, sampler, delta0, picks) of one float64-gradient case: 'tiny' = the
+    inputs of attack_tiny.npz at iteration 0, 'medium' = 96x128 / 256 rays / 64+64 samples regenerated from seeds."""
+    from fixtures import GRAD64_MEDIUM, grad64_medium_inputs
+    g64 = Golden('attack_grad64')
+    if case == 'tiny':
+        g, args, model, data, sampler, dims = _attack_setup(dev)
+        return g64, args, model, data, sampler, g.t('in/delta0', dev), g.np('adam/selected_inds')[0]
+    c = GRAD64_MEDIUM
+    data, cnn_sd, p_coarse, p_fine, delta0, picks = grad64_medium_inputs()
+    assert np.array_equal(picks, g64.np('medium/picks'))
+    assert abs(float(delta0.double().sum()) - float(g64.np('medium/delta0_checksum'))) < 1e-9, 'seeded inputs changed'
+    feature_net = ResUNet(coarse_out_ch=32, fine_out_ch=32)
+    feature_net.load_state_dict(cnn_sd, strict=True)
+    for p in feature_net.parameters():
+        p.requires_grad_(False)
+    model = SimpleNamespace(net_coarse=make_net(p_coarse, c['S'], True, dev), net_fine=make_net(p_fine, c['S'] + c['N_imp'], True, dev),
+                            feature_net=feature_net.to(dev).eval())
+    args = SimpleNamespace(N_rand=c['R'], sample_mode='uniform', center_ratio=0.8, N_samples=c['S'], N_importance=c['N_imp'],
+                           inv_uniform=True, det=True, white_bkgd=False, epsilon=8, adv_lr=2, use_adam=True, adam_lr=1e-3,
+                           lr_step_size=100, lr_gamma=1.0, adv_iters=1, chunk_size=4096)
+    sampler = RaySamplerSingleImage(data, dev)
+    return g64, args, model, data, sampler, delta0.to(dev), picks
+
+
+def delta_gradient_float64_check(model, data, delta, picks, cfg, run_gradient, tag, floor=None, ref64=None):
+    """d loss / d delta of the HIP path against the float64 oracle (oracle/attack_ref.float64_gradient, pinned to the
+    reference's own float64 evaluation by tests/test_oracle_golden.py).
+
+    The feature CNN has exactly one discontinuous operation, the ReLU: a unit whose argument is within fp32 rounding of
+    zero may land on either side in two correct fp32 evaluations, and ONE flipped unit of an N-element activation moves the
+    gradient by ~1/sqrt(N) of its norm (measured on the MI355X, tools/diag_cnn_layers.py: 8e-3 on the 48x64 case, 5e-3 on
+    the 96x128 one -- the reference's own fp32-vs-float64 distance of 4.6e-3 on the latter is such a flip too).  So the
+    bound is stated on the activation pattern the HIP evaluation actually used: the float64 oracle is evaluated on that
+    pattern (every other operation in float64), the relative L2 distance must be <= 1e-3 (north_star; measured 1e-4 or
+    better), and every unit whose decision differs from the float64 evaluation must have a float64 argument below 1e-4 of
+    its plane's rms, i.e. inside rounding noise.  With no flipped unit the bound against the committed reference-float64
+    gradient is 3x the reference's own fp32 floor."""
+    from nerfool_amd.ibrnet import feature_network
+    feature_network.TRACE_RELU = trace = []
+    try:
+        grad = run_gradient()
+    finally:
+        feature_network.TRACE_RELU = None
+    assert len(trace) == 27, 'one feature-network evaluation expected (27 ReLU layers), got %d' % len(trace)
+    masks = [(t > 0).cpu() for t in trace]
+    cnn = model.feature_net.state_dict()
+    pc_, pf_ = model.net_coarse.state_dict(), model.net_fine.state_dict()
+    _, g_nat, tr_nat = atk.float64_gradient(delta, cnn, pc_, pf_, data, picks, cfg)
+    n_flip, n_units, worst = atk.relu_pattern_flips(tr_nat, masks)
+    g_pat = g_nat if n_flip == 0 else atk.float64_gradient(delta, cnn, pc_, pf_, data, picks, cfg, relu_masks=masks)[1]
+    rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())
+    err_pat, err_nat = rel(grad, g_pat), rel(grad, g_nat)
+    print('[grad parity] %s: rel-L2 vs float64 on the same ReLU pattern %.3e | vs plain float64 %.3e | flipped ReLU units %d of %d '
+          '(largest |argument| / plane rms %.1e)%s' % (tag, err_pat, err_nat, n_flip, n_units, worst,
+                                                       '' if floor is None else ' | reference fp32 floor %.2e' % floor))
+    if ref64 is not None:
+        assert rel(g_nat, torch.as_tensor(ref64).double()) < 1e-6, 'oracle float64 departs from the committed reference float64 gradient'
+    assert err_pat <= 1e-3, '%s: d loss / d delta rel-L2 error %.3e vs the float64 oracle on the same ReLU pattern' % (tag, err_pat)
+    assert worst <= 1e-4 and n_flip <= 2 + 1e-5 * n_units, '%s: %d ReLU decisions differ, argument up to %.2e of the plane rms' % (tag, n_flip, worst)
+    if n_flip == 0 and floor is not None:
+        assert err_nat <= 3 * floor, '%s: %.3e vs 3 x reference fp32 floor %.3e' % (tag, err_nat, floor)
+    return err_pat, err_nat, n_flip
+
+
+def check_delta_gradient_vs_float64(case, dev):
+    """tests/golden/attack_grad64.npz cases: whole PGD-step gradient vs the float64 ground truth."""
+    g64, args, model, data, sampler, delta0, picks = grad64_setup(case, dev)
+    src = sampler.get_all()
+    attack = EA.PGDAttack(args, model, Projector(dev), src, delta=delta0.clone().requires_grad_(True))
+    cfg = dict(N_samples=args.N_samples, N_importance=args.N_importance, inv_uniform=True, white_bkgd=False)
+    delta_gradient_float64_check(model, data, delta0, picks, cfg, lambda: attack.gradient(data, select_inds=picks, lookahead=False),
+                                 case, floor=float(g64.np(case + '/floor/grad')), ref64=g64.np(case + '/grad64'))
+    loss64 = float(g64.np(case + '/loss64'))
+    assert abs(float(attack.last_loss) - loss64) <= 1e-4 * loss64, 'loss %.8f vs float64 %.8f' % (float(attack.last_loss), loss64)
 
 
 def check_ray_sampler(dev):
@@ -215,14 +309,20 @@ def check_attack_steps(dev, free_steps=None):
         grad = atk_state.gradient(data, select_inds=picks[t])
         ref_grad = g.np('adam/grad_iter%d' % t)
         assert_close(atk_state.last_loss, g.np('adam/losses')[t], 1e-3, 1e-6, 'attack loss, iter %d' % t)
-        # The gradient passes backward through the 20-layer InstanceNorm ResUNet, which is ill-conditioned in fp32: the
-        # same module evaluated in fp32 on the CPU already differs from its float64 evaluation by ~2e-3 (rel. L2,
-        # tools/diag_cnn.py), MIOpen by 2-3e-3.  Hence a norm-wise bound against the reference's fp32 gradient, plus a
-        # loose element-wise one.
-        gerr = float(np.linalg.norm(grad.cpu().numpy() - ref_grad) / np.linalg.norm(ref_grad))
-        assert gerr < 2e-2, 'd loss / d delta, iter %d: relative L2 error %.3e' % (t, gerr)
-        assert_close(grad, ref_grad, 5e-2, 1e-2 * float(np.abs(ref_grad).max()), 'd loss / d delta, iter %d' % t,
-                     frac_ok=2e-2)
+        # gradient: float64 oracle on the ReLU activation pattern of this evaluation, <= 1e-3 (see delta_gradient_float64_check);
+        # against the reference's fp32 capture the distance is then bounded by both sides' distances to float64
+        if torch.device(dev).type == 'cuda':
+            cfg64 = dict(N_samples=args.N_samples, N_importance=args.N_importance, inv_uniform=True, white_bkgd=False)
+            holder = {}
+
+            def run(t=t):
+                holder['g'] = atk_state.gradient(data, select_inds=picks[t])
+                return holder['g']
+            delta_gradient_float64_check(model, data, deltas[t], picks[t], cfg64, run, 'attack_tiny iter %d' % t)
+        else:       # CPU stand-in: nn.Module CNN (no ReLU trace); norm-wise bound against the reference's fp32 gradient
+            gerr = float(np.linalg.norm(grad.cpu().numpy() - ref_grad) / np.linalg.norm(ref_grad))
+            print('[grad parity] attack_tiny iter %d (CPU stand-in): rel-L2 vs reference fp32 %.3e' % (t, gerr))
+            assert gerr < 2e-3, 'd loss / d delta, iter %d: relative L2 error %.3e' % (t, gerr)
         atk_state.apply(g.t('adam/grad_iter%d' % t, dev))                 # the reference's gradient
         assert_close(atk_state.delta.data, deltas[t + 1], 0, 2e-7, 'delta after fused Adam step %d' % (t + 1))
     m_ref, v_ref = g.np('adam/exp_avg_3'), g.np('adam/exp_avg_sq_3')

@@ -86,6 +86,11 @@ def test_attack_steps():
     pc.check_attack_steps('cuda')
 
 
+@pytest.mark.parametrize('case', ['tiny', 'medium'])
+def test_delta_gradient_vs_float64(case):
+    pc.check_delta_gradient_vs_float64(case, 'cuda')
+
+
 def test_hybrid_and_sample_pdf():
     pc.check_hybrid_and_sample_pdf('cuda')
 

@@ -218,3 +218,47 @@ def test_sample_pdf_matches_reference():
     for n in (17, 64):
         got = ib.sample_pdf(h.t('pdf/bins'), h.t('pdf/weights'), n, det=True)
         assert_close(got, h.np('pdf/samples_%d' % n), 1e-5, 1e-5, 'sample_pdf %d' % n)
+
+
+@pytest.mark.parametrize('case', ['tiny', 'medium'])
+def test_oracle_float64_gradient_matches_reference_float64(case):
+    """attack_grad64.npz holds the reference's d loss / d delta evaluated in float64 (make_golden_grad64.py).  The oracle
+    evaluated in float64 must reproduce it to float32-storage accuracy, and the oracle in fp32 must sit at the reference's
+    own fp32 noise floor -- this pins the ground truth the GPU gradient-parity bound is stated against."""
+    from fixtures import GRAD64_MEDIUM, grad64_medium_inputs
+    g64 = Golden('attack_grad64')
+    if case == 'tiny':
+        g = Golden('attack_tiny')
+        H, W, V, R, S, N_imp, cnn_seed = [int(x) for x in g.np('cfg')[:7]]
+        data = {k: g.t('in/' + k) for k in ('rgb', 'camera', 'src_rgbs', 'src_cameras', 'depth_range')}
+        cnn, pc_, pf_ = fnet.random_resunet_state(cnn_seed), g.params('coarse'), g.params('fine')
+        delta0, picks = g.t('in/delta0'), g.np('adam/selected_inds')[0]
+    else:
+        c = GRAD64_MEDIUM
+        H, W, S, N_imp = c['H'], c['W'], c['S'], c['N_imp']
+        data, cnn, pc_, pf_, delta0, picks = grad64_medium_inputs()
+    cam = data['camera']
+    ro, rd = ib.rays_single_image(H, W, cam[:, 2:18].reshape(-1, 4, 4), cam[:, 18:34].reshape(-1, 4, 4))
+    idx = torch.from_numpy(np.asarray(picks, dtype=np.int64))
+    cfg = dict(N_samples=S, N_importance=N_imp, inv_uniform=True, white_bkgd=False)
+
+    def run(dtype):
+        c_ = lambda t: t.to(dtype) if torch.is_tensor(t) and t.is_floating_point() else t
+        batch = {'ray_o': c_(ro[idx]), 'ray_d': c_(rd[idx]), 'rgb': c_(data['rgb'].reshape(-1, 3)[idx]), 'camera': c_(cam),
+                 'depth_range': c_(data['depth_range']), 'src_rgbs': c_(data['src_rgbs']), 'src_cameras': c_(data['src_cameras'])}
+        src = {'src_rgbs': c_(data['src_rgbs']), 'src_cameras': c_(data['src_cameras'])}
+        d = c_(delta0).clone().requires_grad_(True)
+        loss, _ = atk.attack_loss(d, {k: c_(v) for k, v in cnn.items()}, {k: c_(v) for k, v in pc_.items()},
+                                  {k: c_(v) for k, v in pf_.items()}, src, batch, cfg)
+        grad, = torch.autograd.grad(loss, d)
+        return float(loss.detach()), grad.double().numpy()
+
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    ref64 = g64.np(case + '/grad64').astype(np.float64)
+    loss64, grad64 = run(torch.float64)
+    assert abs(loss64 - float(g64.np(case + '/loss64'))) < 1e-9
+    assert rel(grad64, ref64) < 2e-7, 'oracle float64 vs reference float64: %.3e' % rel(grad64, ref64)
+    floor = float(g64.np(case + '/floor/grad'))
+    assert abs(rel(g64.np(case + '/grad32').astype(np.float64), ref64) - floor) < 1e-6
+    loss32, grad32 = run(torch.float32)
+    assert rel(grad32, ref64) < 3 * floor, 'oracle fp32 %.3e vs floor %.3e' % (rel(grad32, ref64), floor)
