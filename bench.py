@@ -3,16 +3,20 @@
 
 One "step" = one PGD iteration of the view-specific IBRNet attack on a synthetic LLFF-'fern'-shaped scene
 (756x1008 sources and target, 4 source views, 64 coarse + 64 importance samples, N_rand rays, Adam-ascent lr 1e-3,
-eps 8/255): ray picking, ResUNet on the perturbed sources (MIOpen), coarse+fine render, masked MSE, backward to delta,
-fused Adam/eps-ball/[0,1] update.  `value` = rays rendered-and-differentiated per second over all ranks.
+eps 8/255): ray picking, ResUNet on the perturbed sources, coarse+fine render, masked MSE, backward to delta, fused
+Adam/eps-ball/[0,1] update.  `value` = rays rendered-and-differentiated per second over all ranks.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Multi-GPU (weak scaling): every rank differentiates its own N_rand rays of the step's global batch, the CNN is
-replicated, two collectives per step (2-float mask counts, then one RCCL all-reduce of d(delta)).
-Prints ONE JSON line on rank 0.
+Multi-GPU: rays are sharded over the ranks (nerfool_amd.eval_adv.RayShard).  `--scaling weak` (default): every rank
+differentiates its own N_rand rays (global batch N_rand * N); `--scaling strong`: the N_rand rays of the single-GPU step are
+split over the ranks.  `--cnn-shard view` (default): the feature CNN is sharded by source view, 4 collectives per step
+(16-byte counts/loss all-reduce, all-gather of the feature maps, reduce-scatter of their gradients, all-gather of d delta);
+`--cnn-shard replicated`: the north-star form, 2 collectives per step (16-byte all-reduce + ONE RCCL all-reduce of d delta).
+Whatever the headline flags, an N > 1 run also times the other scaling mode and the replicated form and reports them under
+`extra.multi_gpu`.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3      # MI355X fp32 MFMA / vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec peak
+PMC_PROFILE = 'profiles/r02_pmc_traffic.json'
 ROOFLINE_KERNELS = ('nf_ibrnet_fwd', 'nf_ibrnet_bwd', 'nf_ibrnet_fwd_mfma', 'nf_ibrnet_bwd_mfma', 'nf_project_gather_fwd',
                     'nf_project_gather_bwd', 'nf_gnt_fwd', 'nf_gnt_fwd_mfma', 'nf_gnt_bwd', 'nf_gnt_bwd_mfma', 'nf_pgd_adam_step',
                     'nf_conv3x3_wino')
@@ -39,23 +44,32 @@ def ibrnet_flops(R, S, V):
     return 2.0 * R * S * (V * 13256 + 6480 + 32 * S)
 
 
+def resunet_flops(H, W):
+    """Algorithmic forward FLOPs of the ResUNet per image (SURVEY section 6: FlopCounterMode at the two benchmark sizes;
+    other sizes scaled by area)."""
+    known = {(756, 1008): 121.9e9, (800, 800): 101.3e9, (512, 512): 41.5e9}
+    return known.get((H, W), 121.9e9 * H * W / (756.0 * 1008.0))
+
+
 def pmc_traffic(kernel, a):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     in their own runs of this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the
     profile does not cover this workload: counters cannot be read from inside the benchmark process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(path) as f:
-            prof = json.load(f)
-    except (OSError, ValueError):
-        return None
-    w = prof.get('workload', {})
-    if (w.get('model'), w.get('n_rand'), w.get('height'), w.get('width'), w.get('views')) != (a.model, a.n_rand, a.height, a.width, a.views):
-        return None
-    entry = prof.get('abi_kernels', {}).get(kernel)
-    return None if entry is None else {'hbm_bytes_per_launch': entry['hbm_bytes_per_launch'], 'unit': 'B',
-                                       'algorithmic_bytes_per_launch': entry.get('algorithmic_bytes_per_launch'),
-                                       'source': 'profiles/r01_pmc_traffic.json'}
+    for rel in (PMC_PROFILE, 'profiles/r01_pmc_traffic.json'):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                prof = json.load(f)
+        except (OSError, ValueError):
+            continue
+        w = prof.get('workload', {})
+        if (w.get('model'), w.get('n_rand'), w.get('height'), w.get('width'), w.get('views')) != (a.model, a.n_rand, a.height, a.width, a.views):
+            continue
+        entry = prof.get('abi_kernels', {}).get(kernel)
+        if entry is None:
+            continue
+        return {'hbm_bytes_per_launch': entry['hbm_bytes_per_launch'], 'unit': 'B',
+                'algorithmic_bytes_per_launch': entry.get('algorithmic_bytes_per_launch'), 'source': rel}
+    return None
 
 
 def parse():
@@ -63,7 +77,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--n-rand', type=int, default=512, help='rays per rank per PGD step (reference default N_rand)')
+    ap.add_argument('--n-rand', type=int, default=512, help='rays per PGD step: per rank (weak scaling) or in total (strong)')
     ap.add_argument('--height', type=int, default=756)
     ap.add_argument('--width', type=int, default=1008)
     ap.add_argument('--views', type=int, default=4)
@@ -74,30 +88,41 @@ def parse():
                     help="'gnt' = BASELINE config 4 (GNT depth 8, 800x800, 10 views, 64 samples) -- not the headline line")
     ap.add_argument('--depth', type=int, default=8, help='GNT trans_depth')
     ap.add_argument('--cnn-shard', choices=('view', 'replicated'), default='view',
-                    help='N > 1: feature CNN sharded by source view (exchange of feature maps) or replicated on every rank')
-    ap.add_argument('--cpu-iters', type=int, default=2, help='timed CPU-oracle PGD iterations for cpu_baseline (0 = skip)')
+                    help='N > 1: feature CNN sharded by source view (exchange of feature maps) or replicated on every rank '
+                         '(north-star form: one all-reduce of d delta)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='N > 1: --n-rand rays per rank (weak) or split over the ranks (strong)')
+    ap.add_argument('--cpu-iters', type=int, default=10, help='timed CPU-oracle PGD iterations for cpu_baseline after 2 warm-ups (0 = skip)')
+    ap.add_argument('--extras', type=int, default=1, help='0 = only the headline timed region (profiling runs)')
     return ap.parse_args()
 
 
-def build_problem(a, dev):
+def make_args(a, n_rand):
+    args = SimpleNamespace(anti_alias_pooling=1, N_samples=a.samples, N_importance=a.importance, N_rand=n_rand,
+                           inv_uniform=True, det=True, white_bkgd=False, epsilon=8, adv_lr=2, use_adam=True, adam_lr=1e-3,
+                           lr_step_size=100, lr_gamma=1.0, adv_iters=1000, local_rank=0, coarse_only=False, ckpt_path=None,
+                           sample_mode='uniform', center_ratio=0.8, chunk_size=4096)
+    if a.model == 'gnt':
+        args.netwidth, args.trans_depth, args.single_net, args.ret_alpha = 64, a.depth, True, False
+        args.N_importance = 0
+    return args
+
+
+def build_problem(a, dev, height=None, width=None):
     from nerfool_amd import eval_adv as EA
     from nerfool_amd.ibrnet.model import IBRNetModel
     from nerfool_amd.ibrnet.projection import Projector
     from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
     from nerfool_amd.synthetic import make_scene
-    args = SimpleNamespace(anti_alias_pooling=1, N_samples=a.samples, N_importance=a.importance, N_rand=a.n_rand,
-                           inv_uniform=True, det=True, white_bkgd=False, epsilon=8, adv_lr=2, use_adam=True, adam_lr=1e-3,
-                           lr_step_size=100, lr_gamma=1.0, adv_iters=1000, local_rank=0, coarse_only=False, ckpt_path=None,
-                           sample_mode='uniform', center_ratio=0.8, chunk_size=4096)
+    H, W = height or a.height, width or a.width
+    args = make_args(a, a.n_rand)
     torch.manual_seed(0)
     if a.model == 'gnt':
         from nerfool_amd.gnt.model import GNTModel
-        args.netwidth, args.trans_depth, args.single_net, args.ret_alpha = 64, a.depth, True, False
-        args.N_importance = 0
-        data = make_scene(a.height, a.width, a.views, seed=0, blender=True)
+        data = make_scene(H, W, a.views, seed=0, blender=True)
         model = GNTModel(args, device=dev)
     else:
-        data = make_scene(a.height, a.width, a.views, seed=0)
+        data = make_scene(H, W, a.views, seed=0)
         model = IBRNetModel(args, device=dev)
         with torch.no_grad():
             for net in (model.net_coarse, model.net_fine):
@@ -108,15 +133,43 @@ def build_problem(a, dev):
     return args, data, model, sampler, src_ray_batch, Projector(dev), EA
 
 
+def host_cpu():
+    """(physical cores, model string) of the host from /proc/cpuinfo"""
+    cores, model = set(), None
+    try:
+        phys = core = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                k, _, v = line.partition(':')
+                k, v = k.strip(), v.strip()
+                if k == 'model name' and model is None:
+                    model = v
+                elif k == 'physical id':
+                    phys = v
+                elif k == 'core id':
+                    core = v
+                elif not k and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    return n, model or 'unknown'
+
+
 def cpu_baseline(a, args, data, model):
-    """The oracle port (PyTorch-CPU restatement of the reference, oracle/) on the host cores, same workload, bounded:
-    1 untimed + `cpu_iters` timed PGD iterations."""
+    """The oracle port (PyTorch-CPU restatement of the reference, oracle/) on the host's physical cores, same workload,
+    bounded: 2 untimed + `cpu_iters` timed PGD iterations, and 3 timed 4096-ray render chunks after 1 warm-up."""
     from oracle import attack_ref as atk
-    threads = torch.get_num_threads()
+    from oracle import feature_net_ref as fnet
+    from oracle import ibrnet_ref as ib
+    cores, cpu_model = host_cpu()
+    torch.set_num_threads(cores)
     cnn = {k: v.detach().cpu() for k, v in model.feature_net.state_dict().items()}
     pc = {k: v.detach().cpu() for k, v in model.net_coarse.state_dict().items()}
     pf = {k: v.detach().cpu() for k, v in model.net_fine.state_dict().items()}
-    from oracle import ibrnet_ref as ib
     cam = data['camera']
     ro, rd = ib.rays_single_image(a.height, a.width, cam[:, 2:18].reshape(-1, 4, 4), cam[:, 18:34].reshape(-1, 4, 4))
     gt = data['rgb'].reshape(-1, 3)
@@ -130,13 +183,101 @@ def cpu_baseline(a, args, data, model):
                 'src_rgbs': src['src_rgbs'], 'src_cameras': src['src_cameras']}
 
     delta0 = atk.init_adv_perturb(data['src_rgbs'], 8 / 255., generator=torch.Generator().manual_seed(0)).detach()
-    delta, _, _, _ = atk.pgd_attack(delta0, cnn, pc, pf, src, batch, cfg, 1, adam_lr=1e-3, lr_gamma=1.0)
+    delta, _, _, _ = atk.pgd_attack(delta0, cnn, pc, pf, src, batch, cfg, 2, adam_lr=1e-3, lr_gamma=1.0)
     t0 = time.time()
     atk.pgd_attack(delta, cnn, pc, pf, src, batch, cfg, a.cpu_iters, adam_lr=1e-3, lr_gamma=1.0)
     dt = (time.time() - t0) / a.cpu_iters
-    return {'value': a.n_rand / dt, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d timed PGD iterations (after 1 warm-up) of the same workload, oracle/ (PyTorch-CPU restatement of the '
-                      'reference), %.2f s/iter => %.0f s per 1000 iters' % (a.cpu_iters, dt, dt * 1000)}
+    # render leg: feature maps once, then 4096-ray chunks, forward only
+    with torch.no_grad():
+        fm = fnet.resunet_forward(cnn, (data['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
+
+        def chunk(i):
+            sl = slice(i * 4096, (i + 1) * 4096)
+            return {'ray_o': ro[sl], 'ray_d': rd[sl], 'rgb': gt[sl], 'camera': cam, 'depth_range': data['depth_range'],
+                    'src_rgbs': src['src_rgbs'], 'src_cameras': src['src_cameras']}
+        ib.render_rays(chunk(0), pc, pf, fm, a.samples, inv_uniform=True, N_importance=a.importance, det=True)
+        r0 = time.time()
+        for i in range(3):
+            ib.render_rays(chunk(i + 1), pc, pf, fm, a.samples, inv_uniform=True, N_importance=a.importance, det=True)
+        rdt = (time.time() - r0) / 3
+    return {'value': a.n_rand / dt, 'unit': 'rays/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model,
+            'torch_threads': torch.get_num_threads(),
+            'sample': '%d timed PGD iterations (after 2 warm-ups) of the same workload, oracle/ (PyTorch-CPU restatement of the '
+                      'reference), %.2f s/iter => %.0f s per 1000 iters; render leg: 3 timed 4096-ray chunks after 1 warm-up'
+                      % (a.cpu_iters, dt, dt * 1000),
+            'attack_s_per_iter': dt, 'render_rays_per_s': 4096 / rdt}
+
+
+def time_steps(attack, data, steps, warmup, barrier, timer_ctx=None):
+    """`warmup` untimed + exactly `steps` timed PGD steps between barrier + synchronize brackets -> seconds (this rank)"""
+    for _ in range(warmup):
+        attack.step(data)
+    barrier()
+    t0 = time.perf_counter()
+    if timer_ctx is not None:
+        with timer_ctx:
+            for _ in range(steps):
+                attack.step(data)
+    else:
+        for _ in range(steps):
+            attack.step(data)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def render_leg(model, projector, sampler, src_ray_batch, featmaps, n_chunks, samples, importance, gnt, prof):
+    """forward-only throughput on 4096-ray chunks with resident feature maps: 1 warm-up chunk + n_chunks timed"""
+    if gnt:
+        from nerfool_amd.gnt.render_ray import render_rays as gnt_render_rays
+
+        def render_rays(rb, model, featmaps, projector, n_samples, **kw):
+            kw.pop('N_importance', None)
+            return gnt_render_rays(rb, model, featmaps, projector, n_samples, N_importance=0, **kw)
+    else:
+        from nerfool_amd.ibrnet.render_ray import render_rays
+    rays = sampler.get_all()
+    chunk = lambda i: {k: (v[i * 4096:(i + 1) * 4096] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in rays.items()}
+    with torch.no_grad():
+        render_rays(chunk(0), model, featmaps, projector, samples, inv_uniform=True, N_importance=importance, det=True,
+                    src_ray_batch=src_ray_batch)
+        torch.cuda.synchronize()
+        rtimer = prof.KernelTimer()
+        r0 = time.perf_counter()
+        with prof.timing(rtimer):
+            for i in range(n_chunks):
+                render_rays(chunk(i + 1), model, featmaps, projector, samples, inv_uniform=True, N_importance=importance,
+                            det=True, src_ray_batch=src_ray_batch)
+        torch.cuda.synchronize()
+        rdt = time.perf_counter() - r0
+    return {'rays_per_s': n_chunks * 4096 / rdt, 'chunks': n_chunks, 'chunk_rays': 4096, 'samples': '%d+%d' % (samples, importance),
+            'kernels_ms': {k: round(v['mean_ms'], 4) for k, v in rtimer.summary().items()}}
+
+
+def exchange_microbench(shard, V, C, Hf, Wf, H, W, dev, view_sharded, reps=10):
+    """the collectives of one step in isolation, on buffers of the step's sizes -> ms per step spent in them"""
+    fm = torch.zeros(V, Hf, Wf, C, device=dev).permute(0, 3, 1, 2)        # channels-last [V,C,Hf,Wf]
+    grad = torch.zeros(1, V, H, W, 3, device=dev)
+    small = torch.zeros(4, device=dev)
+    lo, hi = shard.view_range(V)
+
+    def once():
+        shard.dist.all_reduce(small, group=shard.group)
+        if view_sharded:
+            full = shard.gather_views_nhwc(fm[lo:hi].contiguous(memory_format=torch.channels_last), lo, hi, V)
+            shard.scatter_views_nhwc(full, lo, hi)
+        shard.all_reduce_grad(grad)
+    saved = (shard.collectives, shard.bytes, shard.shard_views)
+    shard.shard_views = view_sharded
+    once()
+    torch.cuda.synchronize()
+    shard.dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    shard.collectives, shard.bytes, shard.shard_views = saved
+    return 1e3 * dt
 
 
 def main():
@@ -149,89 +290,143 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == a.gpus, '--gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N > 1)' % (a.gpus, world)
-    import __graft_entry__ as entry
-    if not os.path.exists(entry.LIB):
-        entry.build()
     # one rank per GPU; the modulo only matters for the 1-GPU debugging set-up below (several ranks on one device)
     local_dev = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
-    shard = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # 'nccl' is RCCL.  NERFOOL_DIST_BACKEND=gloo lets two ranks share ONE GPU to exercise the sharded path on a
+        # 'nccl' is RCCL.  NERFOOL_DIST_BACKEND=gloo lets several ranks share ONE GPU to exercise the sharded path on a
         # single-GPU box (RCCL refuses duplicate devices); it is a functional check, never a measurement.
         backend = os.environ.get('NERFOOL_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    args, data, model, sampler, src_ray_batch, projector, EA = build_problem(a, dev)
+    # the library is built by ONE rank (a no-op when it is fresh, as on the GPU box where the built .so travels in the tree)
+    import __graft_entry__ as entry
+    if rank == 0 and not os.path.exists(entry.LIB):
+        entry.build()
     if world > 1:
-        shard = EA.RayShard(shard_views=a.cnn_shard == 'view')
+        torch.distributed.barrier()
+    args, data, model, sampler, src_ray_batch, projector, EA = build_problem(a, dev)
     from nerfool_amd import prof
-    attack = EA.PGDAttack(args, model, projector, src_ray_batch, shard=shard)
+    from nerfool_amd.ibrnet import feature_network
+
+    def make_attack(cnn_shard, scaling, n_rand=None):
+        """a fresh PGDAttack (own delta / moments) in the given multi-GPU form; n_rand as on the command line: rays per rank
+        (weak) or per step in total (strong)"""
+        shard = None
+        if world > 1:
+            shard = EA.RayShard(shard_views=cnn_shard == 'view', split_n_rand=scaling == 'strong')
+        return EA.PGDAttack(make_args(a, a.n_rand if n_rand is None else n_rand), model, projector, src_ray_batch, shard=shard)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        attack.step(data)
-    barrier()
+    def max_over_ranks(seconds):
+        if world > 1:
+            t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t)
+        return seconds
+
+    attack = make_attack(a.cnn_shard, a.scaling)
     # HIP events only around the kernels the roofline table prices (~10 of the ~250 launches of a step): bracketing every
     # launch costs ~1.5 ms of host time per step, which is visible now that the step is close to launch-bound
     timer = prof.KernelTimer(only=ROOFLINE_KERNELS)
-    t0 = time.perf_counter()
-    with prof.timing(timer):
-        for _ in range(a.steps):
-            attack.step(data)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed = max_over_ranks(time_steps(attack, data, a.steps, a.warmup, barrier, prof.timing(timer)))
     kernels = timer.summary()
     final_loss = float(attack.last_loss)
-    # every hand-written launch, timed over two extra steps OUTSIDE the timed region (extra.hand_written_kernel_ms_per_step)
-    all_timer = prof.KernelTimer()
-    with prof.timing(all_timer):
-        for _ in range(2):
-            attack.step(data)
-    hand_written_ms = sum(k['total_ms'] for k in all_timer.summary().values()) / 2
-    barrier()
+    rays_per_step = a.n_rand * (world if a.scaling == 'weak' else 1)
+    collectives_per_step = payload_per_step = None
+    if attack.shard is not None:
+        collectives_per_step = attack.shard.collectives / float(a.steps + a.warmup)
+        payload_per_step = attack.shard.bytes / float(a.steps + a.warmup)
 
-    # ---- render-throughput leg (forward only, feature maps resident), outside the timed region of the headline value
+    hand_written_ms = None
+    multi = None
+    if a.extras:
+        # every hand-written launch, timed over two extra steps OUTSIDE the timed region (extra.hand_written_kernel_ms_per_step)
+        all_timer = prof.KernelTimer()
+        with prof.timing(all_timer):
+            for _ in range(2):
+                attack.step(data)
+        hand_written_ms = sum(k['total_ms'] for k in all_timer.summary().values()) / 2
+        barrier()
+    if a.extras and world > 1:
+        # ---- the other multi-GPU forms, so that ONE driver run per N yields weak and strong scaling of both CNN placements
+        Hf, Wf = model.feature_net.describe_output(a.height, a.width)[3:5]
+        C = sum(model.feature_net.describe_output(a.height, a.width)[0])
+        multi = {'headline': {'cnn_shard': a.cnn_shard, 'scaling': a.scaling}, 'forms': {}}
+        for cnn_shard, scaling in (('view', 'weak'), ('view', 'strong'), ('replicated', 'weak'), ('replicated', 'strong')):
+            if (cnn_shard, scaling) == (a.cnn_shard, a.scaling):
+                ms, rays = 1e3 * elapsed / a.steps, rays_per_step
+                coll, payload = collectives_per_step, payload_per_step
+            else:
+                other = make_attack(cnn_shard, scaling)
+                n = max(5, a.steps // 2)
+                ms = 1e3 * max_over_ranks(time_steps(other, data, n, 2, barrier)) / n
+                rays = a.n_rand * (world if scaling == 'weak' else 1)
+                coll, payload = other.shard.collectives / float(n + 2), other.shard.bytes / float(n + 2)
+                del other
+            multi['forms']['%s/%s' % (cnn_shard, scaling)] = {
+                'ms_per_step': round(ms, 4), 'rays_per_step_all_ranks': rays, 'rays_per_s': rays / (ms * 1e-3),
+                'collectives_per_step': coll, 'collective_payload_bytes_per_step': payload}
+        for cnn_shard in ('view', 'replicated'):
+            multi['exchange_ms_per_step_isolated_' + cnn_shard] = round(max_over_ranks(
+                exchange_microbench(attack.shard, a.views, C, Hf, Wf, a.height, a.width, dev, cnn_shard == 'view') * 1e-3) * 1e3, 4)
+
+    # ---- single-GPU legs outside the timed region of the headline value
     render = None
-    if a.render_chunks > 0 and rank == 0:
-        if a.model == 'gnt':
-            from nerfool_amd.gnt.render_ray import render_rays as gnt_render_rays
-
-            def render_rays(rb, model, featmaps, projector, n_samples, **kw):
-                kw.pop('N_importance', None)
-                return gnt_render_rays(rb, model, featmaps, projector, n_samples, N_importance=0, **kw)
-        else:
-            from nerfool_amd.ibrnet.render_ray import render_rays
+    extra_legs = {}
+    featmaps = None
+    if a.extras and rank == 0 and (a.render_chunks > 0 or world == 1):
         with torch.no_grad():
             featmaps = model.feature_net((src_ray_batch['src_rgbs'] + attack.delta).squeeze(0).permute(0, 3, 1, 2))
-            rays = sampler.get_all()
-            chunk = lambda i: {k: (v[i * 4096:(i + 1) * 4096] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in rays.items()}
-            render_rays(chunk(0), model, featmaps, projector, a.samples, inv_uniform=True, N_importance=a.importance, det=True,
-                        src_ray_batch=src_ray_batch)
+    if a.extras and rank == 0 and a.render_chunks > 0:
+        render = render_leg(model, projector, sampler, src_ray_batch, featmaps, a.render_chunks, a.samples, a.importance,
+                            a.model == 'gnt', prof)
+    if a.extras and world == 1 and a.model == 'ibrnet':
+        # N_rand = 4096 attack step (SURVEY 8d asks for 512 and 4096)
+        big = make_attack(a.cnn_shard, a.scaling, n_rand=4096)
+        n = max(5, a.steps // 2)
+        ms = 1e3 * time_steps(big, data, n, 2, barrier) / n
+        extra_legs['attack_n_rand_4096'] = {'ms_per_step': round(ms, 4), 'rays_per_s': 4096 / (ms * 1e-3)}
+        del big
+        # the whole 756x1008 image through render_single_image: 187 chunks of 4096 rays, outputs moved to the host (D2H) and
+        # reshaped as the reference does (render_image.py:52-102)
+        from nerfool_amd.ibrnet.render_image import render_single_image
+        rays = sampler.get_all()
+        t_img = []
+        for _ in range(2):
             torch.cuda.synchronize()
-            rtimer = prof.KernelTimer()
-            r0 = time.perf_counter()
-            with prof.timing(rtimer):
-                for i in range(a.render_chunks):
-                    render_rays(chunk(i + 1), model, featmaps, projector, a.samples, inv_uniform=True,
-                                N_importance=a.importance, det=True, src_ray_batch=src_ray_batch)
+            t0 = time.perf_counter()
+            ret = render_single_image(ray_sampler=sampler, ray_batch=rays, model=model, projector=projector, chunk_size=4096,
+                                      N_samples=a.samples, inv_uniform=True, N_importance=a.importance, det=True, white_bkgd=False,
+                                      featmaps=featmaps, src_ray_batch=src_ray_batch)
             torch.cuda.synchronize()
-            rdt = time.perf_counter() - r0
-        render = {'rays_per_s': a.render_chunks * 4096 / rdt, 'chunks': a.render_chunks, 'chunk_rays': 4096,
-                  'kernels_ms': {k: round(v['mean_ms'], 4) for k, v in rtimer.summary().items()}}
+            t_img.append(time.perf_counter() - t0)
+        n_rays = a.height * a.width
+        extra_legs['render_single_image'] = {'image': '%dx%d' % (a.height, a.width), 'chunks': -(-n_rays // 4096), 'samples': '%d+%d' % (a.samples, a.importance),
+                                             'seconds': round(min(t_img), 4), 'rays_per_s': n_rays / min(t_img), 'includes': 'chunk loop, D2H of all six output fields per level, reshape',
+                                             'rgb_shape': list(ret['outputs_fine']['rgb'].shape)}
+        del ret
+        # north-star render case: 800x800 scene, 64 samples per ray -- coarse only and 64+64
+        a8 = argparse.Namespace(**vars(a))
+        a8.height, a8.width = 800, 800
+        args8, data8, model8, sampler8, src8, projector8, _ = build_problem(a8, dev)
+        with torch.no_grad():
+            fm8 = model8.feature_net(src8['src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
+        for imp, tag in ((0, 'render_800x800_64'), (64, 'render_800x800_64+64')):
+            r = render_leg(model8, projector8, sampler8, src8, fm8, 8, 64, imp, False, prof)
+            fl = ibrnet_flops(1, 64, a.views) + (ibrnet_flops(1, 64 + imp, a.views) if imp else 0)
+            r['mfma_frac_of_peak'] = round(r['rays_per_s'] * fl / 1e12 / PEAK_F32_TFLOPS, 4)
+            extra_legs[tag] = r
+        del model8, fm8, sampler8, src8, data8
 
     if rank != 0:
         if world > 1:
@@ -239,7 +434,7 @@ def main():
         return
 
     # ---- roofline of the dominant hand-written kernel of the timed region
-    V, Sc, Sf, R = a.views, a.samples, a.samples + a.importance, a.n_rand
+    V, Sc, R = a.views, a.samples, a.n_rand
     table = {}
     wino_direct, wino_bytes = [], []
     for name, k in kernels.items():
@@ -260,13 +455,15 @@ def main():
             elif name == 'nf_pgd_adam_step':
                 per_launch.append(('hbm', meta['n'] * 32 / (ms * 1e-3) / 1e9))
             elif name == 'nf_conv3x3_wino':
-                # Winograd F(2x2,3x3): 16 multiply-adds per 2x2 output tile and (c_in, c_out) pair -- the products the kernel
-                # puts on the matrix cores (the direct form of the same convolution needs 36: extra.kernels reports that rate too)
-                tiles = meta['n_img'] * ((meta['Ho'] + 1) // 2) * ((meta['Wo'] + 1) // 2)
-                per_launch.append(('mfma', 2.0 * 16 * meta['c_in'] * meta['c_out'] * tiles / (ms * 1e-3) / 1e12))
+                # Winograd: multiply-adds per output tile and (c_in, c_out) pair that the kernel puts on the matrix cores
+                # (F(2x2,3x3): 16 per 2x2 tile; F(4x4,3x3): 36 per 4x4 tile) -- the direct form of the same convolution needs
+                # 9 per output: extra.kernels reports that rate too
+                m = meta.get('m', 2)
+                tiles = meta['n_img'] * ((meta['Ho'] + m - 1) // m) * ((meta['Wo'] + m - 1) // m)
+                per_launch.append(('mfma', 2.0 * (m + 2) ** 2 * meta['c_in'] * meta['c_out'] * tiles / (ms * 1e-3) / 1e12))
                 wino_direct.append(2.0 * 9 * meta['c_in'] * meta['c_out'] * meta['n_img'] * meta['Ho'] * meta['Wo'] / (ms * 1e-3) / 1e12)
                 wino_bytes.append(4.0 * (meta['n_img'] * (meta['c_in'] * meta['Hi'] * meta['Wi'] + meta['c_out'] * meta['Ho'] * meta['Wo'])
-                                         + 16 * meta['c_in'] * meta['c_out']))
+                                         + (m + 2) ** 2 * meta['c_in'] * meta['c_out']))
         if per_launch:
             bound = per_launch[0][0]
             ach = float(np.mean([x[1] for x in per_launch]))
@@ -288,29 +485,45 @@ def main():
                     'frac': d['frac'], 'traffic': None if t is None else t['hbm_bytes_per_launch'], 'traffic_unit': 'B/launch',
                     'traffic_algorithmic': None if t is None else t.get('algorithmic_bytes_per_launch'),
                     'traffic_source': None if t is None else t['source']}
+    # whole step against the fp32 matrix peak: algorithmic FLOPs of the step (CNN forward + backward-data on the views this rank
+    # computes, render forward + input-gradient backward on its rays) / step time
+    ms_step = 1e3 * elapsed / a.steps
+    whole = None
+    if a.model == 'ibrnet':
+        views_here = V if (world == 1 or a.cnn_shard == 'replicated') else -(-V // world)
+        rays_here = rays_per_step / world
+        fl = 2.0 * views_here * resunet_flops(a.height, a.width) + rays_here * 2.0 * (
+            ibrnet_flops(1, Sc, V) + (ibrnet_flops(1, Sc + a.importance, V) if a.importance else 0))
+        whole = {'algorithmic_tflop_per_step_per_gpu': round(fl / 1e12, 4), 'achieved_tflops': round(fl / (ms_step * 1e-3) / 1e12, 3),
+                 'frac_of_fp32_mfma_peak': round(fl / (ms_step * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4),
+                 'note': 'direct-form FLOPs; the Winograd convolutions execute fewer multiplications than that'}
 
-    rays_per_step = a.n_rand * world
+    par = 'single GPU' if world == 1 else ('ray-sharded dp%d, %s scaling, feature CNN %s' % (
+        world, a.scaling, 'sharded by source view' if a.cnn_shard == 'view' else 'replicated (one all-reduce of d delta)'))
     out = {
         'metric': 'rays/s through the %s PGD attack step (render fwd+bwd + CNN fwd+bwd + delta update), %d src views'
                   % ('IBRNet' if a.model == 'ibrnet' else 'GNT', a.views),
         'value': rays_per_step * a.steps / elapsed,
         'unit': 'rays/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-        'ms_per_step': 1e3 * elapsed / a.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'ms_per_step': ms_step,
+        'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': ('BASELINE config 2: IBRNet view-specific attack, LLFF-fern-shaped synthetic scene %dx%d, %d source '
-                                'views, %d+%d samples/ray, N_rand=%d rays per rank per step, Adam lr 1e-3, eps 8/255'
-                                % (a.height, a.width, V, Sc, a.importance, a.n_rand)) if a.model == 'ibrnet' else
-                               ('BASELINE config 4: GNT depth %d view-specific attack, synthetic scene %dx%d, %d source views, %d '
-                                'samples/ray, N_rand=%d rays per rank per step' % (a.depth, a.height, a.width, V, Sc, a.n_rand)),
-                   'rays_per_step_all_ranks': rays_per_step, 'parallelism': 'ray-sharded dp%d%s' % (world, ', feature CNN sharded by source view' if world > 1 and a.cnn_shard == 'view' else '')},
+                                'views, %d+%d samples/ray, N_rand=%d rays per %s per step, Adam lr 1e-3, eps 8/255'
+                                % (a.height, a.width, V, Sc, a.importance, a.n_rand, 'rank' if a.scaling == 'weak' else 'step (all ranks)'))
+                   if a.model == 'ibrnet' else
+                   ('BASELINE config 4: GNT depth %d view-specific attack, synthetic scene %dx%d, %d source views, %d '
+                    'samples/ray, N_rand=%d rays per rank per step' % (a.depth, a.height, a.width, V, Sc, a.n_rand)),
+                   'rays_per_step_all_ranks': rays_per_step, 'parallelism': par,
+                   'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step},
         'roofline': roofline,
         'cpu_baseline': None,
-        'extra': {'attack_s_per_1000_iters': 1e3 * elapsed / a.steps, 'final_loss': final_loss, 'kernels': table,
-                  'hand_written_kernel_ms_per_step': round(hand_written_ms, 4),
-                  'render': render},
+        'extra': {'attack_s_per_1000_iters': ms_step, 'final_loss': final_loss, 'kernels': table, 'whole_step': whole,
+                  'hand_written_kernel_ms_per_step': None if hand_written_ms is None else round(hand_written_ms, 4),
+                  'conv3x3_choice': {'%s %s' % (k[0], 'x'.join(map(str, k[1:]))): v for k, v in feature_network._CONV_CHOICE.items()},
+                  'render': render, 'multi_gpu': multi, **extra_legs},
     }
-    if world == 1 and a.cpu_iters > 0:
+    if world == 1 and a.cpu_iters > 0 and a.extras:
         out['cpu_baseline'] = cpu_baseline(a, args, data, model)
     print(json.dumps(out))
     if world > 1:

@@ -29,6 +29,15 @@ void nf_set_error(const char* fmt, ...);
         }                                                                  \
     } while (0)
 
+// Per-device "already configured" flags (hipFuncSetAttribute is a per-device setting: a process that touches a second GPU
+// must opt in to the large dynamic LDS there too).  The host layer makes the tensor's device current before every launch.
+#define NF_MAX_DEVICES 16
+static inline int nf_current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= NF_MAX_DEVICES) d = 0;
+    return d;
+}
+
 static inline unsigned nf_blocks(int64_t work, int per_block) { return (unsigned)((work + per_block - 1) / per_block); }
 
 // wave64 butterflies (all 64 lanes must call)

@@ -1101,7 +1101,8 @@ static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray
                      const float* ray_d, int64_t n_rays, int V, int depth, int save, float* rgb, float* alpha, float* workspace,
                      hipStream_t st) {
     constexpr int S = 32 * NW;
-    static bool configured = false;
+    static bool configured_on[NF_MAX_DEVICES] = {};
+    bool& configured = configured_on[nf_current_device()];
     const size_t smem = GmLds<NW>::FLOATS * sizeof(float);
     if (!configured && smem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
@@ -1143,7 +1144,8 @@ extern "C" int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, co
 template <int NW>
 static int gm_launch_bwd(const float* mblob, const float* mask, const float* d_rgb, int64_t n_rays, int V, int depth,
                          float* d_rgb_feat, float* workspace, hipStream_t st) {
-    static bool configured = false;
+    static bool configured_on[NF_MAX_DEVICES] = {};
+    bool& configured = configured_on[nf_current_device()];
     const size_t smem = GmBwdLds<NW>::FLOATS * sizeof(float);
     if (!configured && smem > 64 * 1024) {
         if (hipFuncSetAttribute((const void*)k_gnt_bwd_mfma<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {

@@ -1509,7 +1509,8 @@ extern "C" int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, con
 template <int V>
 static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
                            const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, hipStream_t st) {
-    static bool configured = false;      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
+    static bool configured_on[NF_MAX_DEVICES] = {};      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel and device
+    bool& configured = configured_on[nf_current_device()];
     const size_t smem = NF_ROWS_BLOB_FLOATS * sizeof(float);
     if (!configured) {
         if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
@@ -1544,7 +1545,8 @@ extern "C" int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, con
         int64_t iters = (n_rays + rpi - 1) / rpi;
         unsigned blocks = (unsigned)(iters < 256 ? iters : 256);
         size_t smem_ray = (size_t)(RY_FLOATS + 4 * 32 * RAY_BWD_LDS_PER_SAMPLE) * sizeof(float);
-        static bool configured[3] = {false, false, false};
+        static bool configured_on[NF_MAX_DEVICES][3] = {};
+        bool* configured = configured_on[nf_current_device()];
         const void* fn = wpr == 1 ? (const void*)k_ibr_ray_bwd_mfma<1> : (wpr == 2 ? (const void*)k_ibr_ray_bwd_mfma<2>
                                                                                    : (const void*)k_ibr_ray_bwd_mfma<4>);
         int slot = wpr == 1 ? 0 : (wpr == 2 ? 1 : 2);

@@ -391,7 +391,8 @@ static void wn_launch(const float* records, const float* x, WnTensor xi, int Hi,
     // two windows + four rings; the output exchange (KB * 8192 floats) re-uses the same memory
     constexpr size_t staging = sizeof(float) * (2 * WN_CC * 10 * WN_PS + 4 * wn_slots(KB) * 4 * KB * 64);
     constexpr size_t smem = staging > sizeof(float) * KB * 8192 ? staging : sizeof(float) * KB * 8192;
-    static bool once = false;           // more than the default 64 KB of dynamic LDS needs the attribute once per kernel
+    static bool once_on[NF_MAX_DEVICES] = {};   // more than the default 64 KB of dynamic LDS needs the attribute once per kernel and device
+    bool& once = once_on[nf_current_device()];
     if (!once) {
         (void)hipFuncSetAttribute((const void*)k_wino3x3<KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         once = true;

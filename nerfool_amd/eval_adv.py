@@ -1,10 +1,11 @@
 """Attack half of the reference's eval/ibrnet/eval_adv.py with the same call surface -- `clamp`, `init_adv_perturb`,
 `optimize_adv_perturb` (rgb-loss path) -- plus `PGDAttack`, the view-specific / universal loop of eval_adv.py:609-740,
 762-843 with the Adam-ascent / sign-PGD update and both projections fused into one HIP kernel, and an optional
-ray-sharded multi-GPU mode (one RCCL all-reduce of d(delta) per step).
+ray-sharded multi-GPU mode (`RayShard`: one RCCL all-reduce of d(delta) per step, or the feature CNN sharded by source
+view with one collective per exchange).
 
-Everything outside the rgb-loss attack (pseudo ground truth, depth / density / camera losses, PCGrad, camera
-perturbation, purification) is out of scope and raises NotImplementedError when requested."""
+Everything outside the rgb-loss attack (depth / density / camera losses, PCGrad, camera perturbation, purification) is
+out of scope and raises NotImplementedError when requested."""
 import torch
 
 from . import ops
@@ -63,7 +64,7 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
     device = delta.device
     sampler = RaySamplerSingleImage.cached(data, device)
     if select_inds is None:
-        n_draw = args.N_rand * (shard.world if shard is not None else 1)
+        n_draw = args.N_rand if shard is None else shard.pixels_to_draw(args.N_rand)
         select_inds = sampler.sample_random_pixel(n_draw, getattr(args, 'sample_mode', 'uniform'),
                                                   getattr(args, 'center_ratio', 0.8), lookahead=lookahead)
         if shard is not None:
@@ -87,33 +88,34 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
         ret = render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
                           N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
                           det=getattr(args, 'det', True), white_bkgd=args.white_bkgd, args=args, src_ray_batch=src_ray_batch)
-    counts = None
+    counts, global_loss = None, None
     if shard is not None:
-        counts = shard.global_mask_counts(ret)
+        counts, global_loss = shard.global_counts_and_loss(ret, train_ray_batch)
     loss_rgb, _ = crit(ret['outputs_coarse'], train_ray_batch, None, None if counts is None else counts[0:1])
     if ret['outputs_fine'] is not None:
         fine_loss, _ = crit(ret['outputs_fine'], train_ray_batch, None, None if counts is None else counts[1:2])
         loss_rgb = loss_rgb + fine_loss
-    total_loss = {'rgb': loss_rgb}
+    # sharded: `loss` is this rank's partial sum over the global denominators (what backward() needs: the partial losses
+    # add up to the global loss); the all-reduced value is reported next to it
+    total_loss = {'rgb': loss_rgb if global_loss is None else global_loss}
     loss = loss_rgb
     if return_loss:
         return loss, total_loss
-    return torch.autograd.grad(loss, delta)[0].detach()
+    grad = torch.autograd.grad(loss, delta)[0].detach()
+    return grad if shard is None else shard.all_reduce_grad(grad)
 
 
 class _GatherViewFeatures(torch.autograd.Function):
-    """forward: each rank contributes the feature maps of the source views it owns and every rank receives all V of them
-    (sum of disjointly filled buffers); backward: d featmaps summed over the ranks (each rank rendered other rays), every
-    rank keeps the slice of its own views.  Runs on every rank in both directions, also on ranks that own no view."""
+    """forward: each rank contributes out_conv's output for the source views it owns and every rank receives all V of them
+    (ONE collective: all-gather, or an all-reduce of disjointly filled buffers when the views do not divide evenly);
+    backward: d featmaps summed over the ranks (each rank rendered other rays), every rank keeps the slice of its own views
+    (ONE collective: reduce-scatter / all-reduce).  Runs on every rank in both directions, also on ranks that own no view."""
 
     @staticmethod
     def forward(ctx, local, shard, lo, hi, n_views, split):
-        full = torch.empty((n_views,) + tuple(local.shape[1:]), dtype=local.dtype,
-                           device=local.device).contiguous(memory_format=torch.channels_last)
-        if hi > lo:
-            full[lo:hi] = local
-        shard.broadcast_views_nhwc_(full)
-        ctx.shard, ctx.lo, ctx.hi = shard, lo, hi
+        full = shard.gather_views_nhwc(local, lo, hi, n_views)
+        ctx.shard, ctx.lo, ctx.hi, ctx.n_views = shard, lo, hi, n_views
+        ctx.set_materialize_grads(False)
         # the per-map channel split happens HERE, so each map's gradient comes back as its own tensor (sliced outside,
         # autograd would assemble them with zero fills, strided copies and an add over all V views)
         return tuple(full.split(list(split), dim=1)) if len(split) > 1 else (full,)
@@ -121,39 +123,50 @@ class _GatherViewFeatures(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         ref = next(g for g in gs if g is not None)
-        mine = []
-        for g in gs:
-            g = torch.zeros_like(ref, memory_format=torch.channels_last) if g is None \
-                else g.clone(memory_format=torch.channels_last)          # never reduce into autograd's own buffer
-            ctx.shard.reduce_views_nhwc_(g)
-            mine.append(g[ctx.lo:ctx.hi])
-        local = mine[0] if len(mine) == 1 else torch.cat(mine, dim=1).contiguous(memory_format=torch.channels_last)
-        return local, None, None, None, None, None
+        gs = [torch.zeros_like(ref, memory_format=torch.channels_last) if g is None else g for g in gs]
+        # one buffer for all maps (a fresh tensor: never reduce into autograd's own buffers), one collective
+        g = gs[0].clone(memory_format=torch.channels_last) if len(gs) == 1 else \
+            torch.cat(gs, dim=1).contiguous(memory_format=torch.channels_last)
+        return ctx.shard.scatter_views_nhwc(g, ctx.lo, ctx.hi), None, None, None, None, None
 
 
 class RayShard:
     """Data-parallel sharding of one PGD step over the ranks of a torch.distributed group (backend 'nccl' = RCCL over
     xGMI on the GPU box, 'gloo' in the CPU tests).
 
-    rays: every rank renders its slice of the step's rays.  Collectives: a 2-float all-reduce of the mask counts (they
-    set the loss denominators, utils.py:58) and ONE all-reduce of d(delta) (valid because the CNN backward is linear in the
-    upstream gradient).  Every rank then applies the identical deterministic update, so delta stays replicated.
+    rays: every rank renders its slice of the step's rays.  With `split_n_rand=False` (weak scaling) `args.N_rand` is the
+    PER-RANK ray count: the step draws N_rand * world pixels from the RandomState(234) stream and the batch semantics become
+    N_rand * world rays per step.  With `split_n_rand=True` (strong scaling) `args.N_rand` is the GLOBAL batch: the step
+    draws exactly the pixels the single-GPU / reference run draws, so the trajectory equals the single-GPU one up to
+    summation order.
 
-    source views (shard_views=True, SURVEY 8e "shard the CNN by view"): the V source images are independent samples of
-    the feature CNN (InstanceNorm is per sample, feature_network.py:137,180), so rank r runs the CNN forward/backward only
-    for its contiguous block of views.  Exchanges are per view, to / from the rank that owns it, so that only the bytes that
-    are needed travel (half of what all-reducing zero-filled buffers moves) and ragged or empty blocks need no special case:
-    forward a broadcast of each view's feature maps from its owner, backward a reduce (sum) of each view's d featmaps to
-    its owner; d(delta) of a rank is non-zero only on its own views, so the full gradient is assembled by a broadcast of
-    each view's slice from its owner instead of the all-reduce."""
+    shard_views=False -- the north-star form: the feature CNN is replicated; collectives per step = ONE 16-byte all-reduce
+    (mask counts = loss denominators, utils.py:58, and loss numerators for the reported loss) + ONE all-reduce of d(delta)
+    (valid because the CNN backward is linear in the upstream gradient).
 
-    def __init__(self, group=None, shard_views=True):
+    shard_views=True (SURVEY 8e "shard the CNN by view") -- the V source images are independent samples of the feature CNN
+    (InstanceNorm is per sample, feature_network.py:137,180), so rank r runs the CNN forward/backward only for its
+    contiguous block of views: 4 collectives per step -- the 16-byte one, an all-gather of the feature maps, a
+    reduce-scatter of their gradients, an all-gather of the per-view slices of d(delta) (a rank's d(delta) is non-zero only
+    on its own views).  When the views do not divide evenly over the ranks (world does not divide V, or world > V: the ranks
+    beyond V own no view and only render) each of the three is an all-reduce of disjointly filled / full buffers instead --
+    still one collective per exchange, twice the bytes.
+
+    Every rank then applies the identical deterministic update, so delta stays replicated without a broadcast."""
+
+    def __init__(self, group=None, shard_views=True, split_n_rand=False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.shard_views = bool(shard_views)
+        self.split_n_rand = bool(split_n_rand)
+        self.collectives = 0            # issued so far (bench.py reports collectives per step)
+        self.bytes = 0                  # payload bytes of those collectives (size of the reduced / gathered buffer)
+
+    def pixels_to_draw(self, n_rand):
+        return n_rand if self.split_n_rand else n_rand * self.world
 
     def view_range(self, n_views):
         """contiguous block of source views owned by this rank (ragged when world does not divide V; empty for the
@@ -162,36 +175,42 @@ class RayShard:
         lo = self.rank * base + min(self.rank, extra)
         return lo, lo + base + (1 if self.rank < extra else 0)
 
-    def owner(self, v, n_views):
-        """group rank that owns source view v (inverse of view_range)"""
-        base, extra = divmod(n_views, self.world)
-        cut = extra * (base + 1)
-        return v // (base + 1) if v < cut else extra + (v - cut) // base
+    def even(self, n_views):
+        return n_views % self.world == 0
 
-    def _global(self, r):
-        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+    def _count(self, t):
+        self.collectives += 1
+        self.bytes += t.numel() * t.element_size()
 
-    def _per_view(self, t, op):
-        """one collective per view on its contiguous block of t (views on the leading axis), enqueued back to back in view order
-        on every rank, waited for together"""
-        n_views = t.shape[0]
-        work = [op(t[v], self._global(self.owner(v, n_views))) for v in range(n_views)]
-        for w in work:
-            w.wait()
-
-    def broadcast_views_nhwc_(self, t):
-        """t [V,C,H,W] channels-last, view v valid on owner(v): afterwards every rank holds every view"""
-        flat = t.permute(0, 2, 3, 1)            # channels-last storage seen as a plain contiguous [V,H,W,C] tensor
+    def gather_views_nhwc(self, local, lo, hi, n_views):
+        """local [hi-lo, C, H, W] channels-last (the views this rank owns) -> [V, C, H, W] channels-last on every rank"""
+        full = torch.empty((n_views,) + tuple(local.shape[1:]), dtype=local.dtype,
+                           device=local.device).contiguous(memory_format=torch.channels_last)
+        flat = full.permute(0, 2, 3, 1)            # channels-last storage seen as a plain contiguous [V,H,W,C] tensor
         assert flat.is_contiguous()
-        self._per_view(flat, lambda x, r: self.dist.broadcast(x, src=r, group=self.group, async_op=True))
-        return t
+        if self.even(n_views):
+            mine = local.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+            self.dist.all_gather_into_tensor(flat, mine, group=self.group)
+        else:
+            flat.zero_()
+            if hi > lo:
+                full[lo:hi] = local
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._count(flat)
+        return full
 
-    def reduce_views_nhwc_(self, t):
-        """t [V,C,H,W] channels-last: afterwards view v on owner(v) holds the sum over the ranks (elsewhere: unspecified)"""
-        flat = t.permute(0, 2, 3, 1)
+    def scatter_views_nhwc(self, g, lo, hi):
+        """g [V, C, H, W] channels-last, this rank's contribution (consumed) -> sum over the ranks of the own views
+        [hi-lo, C, H, W] channels-last"""
+        flat = g.permute(0, 2, 3, 1)
         assert flat.is_contiguous()
-        self._per_view(flat, lambda x, r: self.dist.reduce(x, dst=r, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
-        return t
+        self._count(flat)
+        if self.even(g.shape[0]):
+            out = torch.empty((hi - lo,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
+            self.dist.reduce_scatter_tensor(out.permute(0, 2, 3, 1), flat, op=self.dist.ReduceOp.SUM, group=self.group)
+            return out
+        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        return g[lo:hi]
 
     def view_sharded_featmaps(self, feature_net, src_rgbs, delta):
         """feature_net(src + delta) with the views split over the ranks -> the same tuple the network returns."""
@@ -209,24 +228,36 @@ class RayShard:
             return maps[0], None
         return maps[0], maps[1]
 
-    def global_mask_counts(self, ret):
-        def count(o):       # masked MSE counts the valid rays, the unmasked one (GNT) every ray
+    def global_counts_and_loss(self, ret, train_ray_batch):
+        """ONE small all-reduce per step: [valid rays coarse, valid rays fine, sum of masked squared errors coarse, fine]
+        -> (counts [2] = the loss denominators every rank divides by, the GLOBAL loss value for reporting)"""
+        def stats(o):       # masked MSE counts the valid rays, the unmasked one (GNT) every ray
+            err = (o['rgb'].detach() - train_ray_batch['rgb']) ** 2
             if 'mask' in o and o['mask'] is not None:
-                return o['mask'].sum(dtype=torch.float32).reshape(1)
-            return torch.full((1,), float(o['rgb'].shape[0]), dtype=torch.float32, device=o['rgb'].device)
-        c = count(ret['outputs_coarse'])
-        f = count(ret['outputs_fine']) if ret['outputs_fine'] is not None else c
-        counts = torch.cat([c, f])
-        self.dist.all_reduce(counts, op=self.dist.ReduceOp.SUM, group=self.group)
-        return counts
+                m = o['mask'].to(torch.float32)
+                return m.sum().reshape(1), (err * m[:, None]).sum().reshape(1)
+            return torch.full((1,), float(o['rgb'].shape[0]), dtype=torch.float32, device=err.device), err.sum().reshape(1)
+        c, nc = stats(ret['outputs_coarse'])
+        f, nf = stats(ret['outputs_fine']) if ret['outputs_fine'] is not None else (c, torch.zeros_like(nc))
+        buf = torch.cat([c, f, nc, nf])
+        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._count(buf)
+        loss = buf[2] / (buf[0] * 3 + 1e-6)
+        if ret['outputs_fine'] is not None:
+            loss = loss + buf[3] / (buf[1] * 3 + 1e-6)
+        return buf[:2], loss
 
     def all_reduce_grad(self, grad):
         """the full d(delta) [1,V,H,W,3] on every rank.  Views sharded: a rank's gradient is non-zero only on its own views,
-        so the sum over the ranks IS each view's slice from its owner -- V broadcasts, half the bytes of an all-reduce."""
-        if self.shard_views and self.world > 1 and grad.dim() == 5 and grad.is_contiguous():
-            self._per_view(grad[0], lambda x, r: self.dist.broadcast(x, src=r, group=self.group, async_op=True))
+        so the sum over the ranks IS the concatenation of the owners' slices -- one all-gather, half the bytes of an
+        all-reduce (an all-reduce when the views do not divide evenly)."""
+        V = grad.shape[1] if grad.dim() == 5 else 0
+        if self.shard_views and self.world > 1 and grad.dim() == 5 and grad.is_contiguous() and self.even(V):
+            lo, hi = self.view_range(V)
+            self.dist.all_gather_into_tensor(grad[0], grad[0, lo:hi].clone(), group=self.group)
         else:
             self.dist.all_reduce(grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._count(grad)
         return grad
 
 
@@ -243,6 +274,10 @@ class PGDAttack:
         self.epsilon = args.epsilon / 255.0
         self.alpha = args.adv_lr / 255.0
         self.delta = delta if delta is not None else init_adv_perturb(args, src_ray_batch, self.epsilon, 1, 0)
+        if shard is not None and shard.world > 1:
+            # delta must start replicated (every rank then applies the identical deterministic update): rank 0's draw wins
+            shard.dist.broadcast(self.delta.data, src=shard.dist.get_global_rank(shard.group, 0) if shard.group is not None else 0,
+                                 group=shard.group)
         self.use_adam = bool(getattr(args, 'use_adam', False))
         if self.use_adam:
             self.exp_avg = torch.zeros_like(self.delta.data)
@@ -257,13 +292,13 @@ class PGDAttack:
 
     def gradient(self, data, select_inds=None, lookahead=True):
         self.delta.grad = None
-        loss, _ = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data,
-                                       return_loss=True, select_inds=select_inds, shard=self.shard, lookahead=lookahead)
+        loss, total = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data,
+                                           return_loss=True, select_inds=select_inds, shard=self.shard, lookahead=lookahead)
         loss.backward()
         grad = self.delta.grad
         if self.shard is not None:
             self.shard.all_reduce_grad(grad)
-        self.last_loss = loss.detach()
+        self.last_loss = total['rgb'].detach()          # the global loss on every rank
         return grad
 
     def apply(self, grad):

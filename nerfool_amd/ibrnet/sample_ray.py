@@ -72,7 +72,7 @@ def parse_camera(params):
 
 class RaySamplerSingleImage(object):
     _cache = {}            # insertion-ordered: oldest first
-    _cache_max = 32        # ~65 MB of rays + images per 756x1008 view
+    _cache_max = 8         # ~65 MB of rays + images per 756x1008 view
 
     def __init__(self, data, device, resize_factor=1, render_stride=1, load_gt_depth=False):
         if resize_factor != 1:
@@ -81,7 +81,6 @@ class RaySamplerSingleImage(object):
             raise NotImplementedError('ground-truth depth (auxiliary depth losses) is outside the attack path')
         self.render_stride = render_stride
         self.device = torch.device(device)
-        self._source = data          # keeps the batch dict alive while this sampler sits in the cache (its id / pointers are the key)
         self.camera = data['camera']
         self.rgb_path = data.get('rgb_path')
         self.depth_range = data['depth_range']
@@ -99,9 +98,17 @@ class RaySamplerSingleImage(object):
 
     @classmethod
     def cached(cls, data, device, **kw):
-        """Same object for the same batch dict (identity of its tensors): the attack loop calls this every iteration."""
-        key = (id(data), str(device), tuple(sorted(kw.items())),
-               tuple(v.data_ptr() for v in data.values() if torch.is_tensor(v)))
+        """Same object for the same target view: the attack loop calls this every iteration, and a DataLoader hands out a
+        fresh dict (fresh tensors) for the same view every epoch.  The key is therefore CONTENT: the image path, the exact
+        camera / depth-range bytes and a strided fingerprint of the image tensors (2 k elements each) -- not object identity,
+        and the cached sampler holds no reference to the batch dict."""
+        def fingerprint(t):
+            flat = t.detach().reshape(-1)
+            return (tuple(t.shape), float(flat[::max(1, flat.numel() // 2048)].double().sum()))
+        key = (tuple(data.get('rgb_path') or ()), str(device), tuple(sorted(kw.items())),
+               data['camera'].detach().cpu().numpy().tobytes(), data['depth_range'].detach().cpu().numpy().tobytes(),
+               None if 'src_cameras' not in data else data['src_cameras'].detach().cpu().numpy().tobytes(),
+               tuple(fingerprint(data[k]) for k in ('rgb', 'src_rgbs') if data.get(k) is not None))
         hit = cls._cache.pop(key, None)           # small LRU: the universal loop cycles over the training views
         if hit is None:
             hit = cls(data, device, **kw)

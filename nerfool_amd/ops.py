@@ -9,11 +9,22 @@ from . import prof
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
+_current_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
+
+
 def _stream(t):
-    """hipStream_t of torch's current stream on t's device (the raw-handle query: a step makes ~250 launches)"""
+    """hipStream_t of torch's current stream on t's device (the raw-handle query: a step makes ~250 launches).  Every
+    launch passes through here right before the C call, so this is also where the tensor's device is made the current HIP
+    device when it is not (a model living on a non-current GPU): kernel launches, the per-device LDS opt-ins and
+    nf_device_cu_count all refer to the current device."""
     if t.is_cuda:
+        idx = t.device.index
+        if idx is None:
+            idx = _current_device()
+        elif idx != _current_device():
+            torch.cuda.set_device(idx)
         if _raw_stream is not None:
-            return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+            return _raw_stream(idx)
         return torch.cuda.current_stream(t.device).cuda_stream
     return 0
 

@@ -314,7 +314,10 @@ def fine_depths(z_vals, weights, N_importance, inv_uniform, det=True):
 
 
 def render_rays(ray_batch, params_coarse, params_fine, featmaps, N_samples, inv_uniform=False, N_importance=0,
-                det=False, white_bkgd=False, src_ray_batch=None, anti_alias_pooling=True):
+                det=False, white_bkgd=False, src_ray_batch=None, anti_alias_pooling=True, z_fine=None):
+    """ref: ibrnet/render_ray.py:173-256.  z_fine (checker hook): use these fine-level depths instead of re-sampling --
+    the inverse-CDF re-sampling is a non-differentiable, discontinuous step (a u_k within rounding of a cdf edge lands in
+    either bin), so a gradient check evaluates the float64 oracle at the depths the checked implementation drew."""
     src = ray_batch if src_ray_batch is None else src_ray_batch
     ret = {'outputs_coarse': None, 'outputs_fine': None}
     pts, z_vals = sample_along_camera_ray(ray_batch['ray_o'], ray_batch['ray_d'], ray_batch['depth_range'],
@@ -326,7 +329,7 @@ def render_rays(ray_batch, params_coarse, params_fine, featmaps, N_samples, inv_
     ret['outputs_coarse'] = raw2outputs(raw, z_vals, pixel_mask, white_bkgd)
     if N_importance > 0:
         assert params_fine is not None
-        z_vals = fine_depths(z_vals, ret['outputs_coarse']['weights'], N_importance, inv_uniform, det)
+        z_vals = fine_depths(z_vals, ret['outputs_coarse']['weights'], N_importance, inv_uniform, det) if z_fine is None else z_fine
         pts = z_vals[:, :, None] * ray_batch['ray_d'][:, None, :] + ray_batch['ray_o'][:, None, :]
         rgb_feat, ray_diff, mask = projector_compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'],
                                                      featmaps[1])

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 / 3, gloo: the sharded PGD step.  Each rank differentiates its slice of the step's rays
+"""CPU, world_size 2 / 3 / 8, gloo: the sharded PGD step.  Each rank differentiates its slice of the step's rays
 through the CPU stand-in build of the kernels; the mask counts are all-reduced before the loss is normalised and
 d(delta) is all-reduced once; with view sharding each rank also runs the feature CNN only for its own source views and
 the feature maps / their gradients are exchanged.  The result must equal the single-process gradient of the union of the
@@ -32,13 +32,20 @@ torch.set_num_threads(2)
 g, args, model, data, sampler, dims = pc._attack_setup('cpu')
 src = sampler.get_all()
 picks = g.np('adam/selected_inds')[0]
-shard = EA.RayShard(shard_views=os.environ['SHARD_VIEWS'] == '1') if world > 1 else None
+draw = os.environ.get('DRAW') == '1'        # the step draws its own pixels: args.N_rand is the GLOBAL batch (split_n_rand)
+shard = EA.RayShard(shard_views=os.environ['SHARD_VIEWS'] == '1', split_n_rand=draw) if world > 1 else None
 atk = EA.PGDAttack(args, model, Projector('cpu'), src, shard=shard, delta=g.t('in/delta0').clone().requires_grad_(True))
-mine = picks if world == 1 else picks[rank::world]
-grad = atk.gradient(data, select_inds=mine).clone()
+if draw:
+    from nerfool_amd.ibrnet import sample_ray
+    sample_ray.rng.seed(234)
+    grad = atk.gradient(data, lookahead=False).clone()
+else:
+    mine = picks if world == 1 else picks[rank::world]
+    grad = atk.gradient(data, select_inds=mine).clone()
 atk.apply(grad)
-np.savez(os.path.join(%(out)r, 'rank%%d_of_%%d_%%s.npz' %% (rank, world, os.environ['SHARD_VIEWS'])), grad=grad.numpy(), delta=atk.delta.detach().numpy(),
-         loss=float(atk.last_loss))
+tag = os.environ['SHARD_VIEWS'] + ('d' if draw else '')
+np.savez(os.path.join(%(out)r, 'rank%%d_of_%%d_%%s.npz' %% (rank, world, tag)), grad=grad.numpy(), delta=atk.delta.detach().numpy(),
+         loss=float(atk.last_loss), collectives=0 if shard is None else shard.collectives)
 if world > 1:
     dist.destroy_process_group()
 '''
@@ -53,14 +60,15 @@ def _build_and_script(tmp_path):
     return script
 
 
-def _run_world(script, env, world, shard_views):
+def _run_world(script, env, world, shard_views, draw=False):
     procs = [subprocess.Popen([sys.executable, str(script)],
-                              env=dict(env, RANK=str(r), WORLD_SIZE=str(world), SHARD_VIEWS='1' if shard_views else '0'))
+                              env=dict(env, RANK=str(r), WORLD_SIZE=str(world), SHARD_VIEWS='1' if shard_views else '0',
+                                       DRAW='1' if draw else '0'))
              for r in range(world)]
     assert all(p.wait() == 0 for p in procs)
 
 
-@pytest.mark.timeout(1500)
+@pytest.mark.timeout(2400)
 def test_sharded_step_equals_single_process(tmp_path):
     script = _build_and_script(tmp_path)
     # the shape-generic kernels emulate ~30x faster than the MFMA ones; the sharding logic under test is the same
@@ -69,18 +77,32 @@ def test_sharded_step_equals_single_process(tmp_path):
     _run_world(script, env, 1, False)
     ref = np.load(tmp_path / 'rank0_of_1_0.npz')
     scale = np.abs(ref['grad']).max()
-    # (world, view sharding): rays only; rays + CNN by view (2 + 2 views); ragged view blocks (2 + 1 + 1)
-    for world, shard_views in ((2, False), (2, True), (3, True)):
-        _run_world(script, dict(env, MASTER_PORT=str(29532 + world + 4 * shard_views)), world, shard_views)
+    # (world, view sharding): rays only = the north-star form (16-byte all-reduce + ONE all-reduce of d delta); rays + CNN by
+    # view with all-gather / reduce-scatter / all-gather (2 + 2 views); ragged view blocks (2 + 1 + 1) and 8 ranks over 4
+    # views (ranks 4-7 own no view) with one all-reduce per exchange
+    port = 29532
+    for world, shard_views in ((2, False), (2, True), (3, True), (8, True)):
+        port += 1
+        _run_world(script, dict(env, MASTER_PORT=str(port), OMP_NUM_THREADS='1' if world > 4 else '2'), world, shard_views)
         ranks = [np.load(tmp_path / ('rank%d_of_%d_%d.npz' % (r, world, shard_views))) for r in range(world)]
         # all-reduced gradient == gradient of the union of the rays (different summation order only)
         assert np.abs(ranks[0]['grad'] - ref['grad']).max() <= 2e-4 * scale, (world, shard_views)
-        for r in ranks[1:]:
+        for r in ranks:
             assert np.array_equal(ranks[0]['grad'], r['grad']), 'ranks must hold the identical all-reduced gradient'
             assert np.array_equal(ranks[0]['delta'], r['delta']), 'delta must stay replicated'
-        # per-rank losses are partial sums over the global denominator: they add up to the single-process loss
-        assert abs(sum(float(r['loss']) for r in ranks) - float(ref['loss'])) <= 1e-5 * abs(float(ref['loss']))
+            # every rank reports the GLOBAL loss (numerators and denominators travel in the same 16-byte all-reduce)
+            assert abs(float(r['loss']) - float(ref['loss'])) <= 1e-5 * abs(float(ref['loss']))
+            assert int(r['collectives']) == (4 if shard_views else 2), 'collectives per step'
         assert np.abs(ranks[0]['delta'] - ref['delta']).mean() <= 1e-6
+    # strong-scaling semantics: args.N_rand is the global batch, the step draws the pixels itself -- exactly the single-process
+    # draw from RandomState(234), split over the ranks
+    _run_world(script, env, 1, False, draw=True)
+    ref_d = np.load(tmp_path / 'rank0_of_1_0d.npz')
+    assert np.abs(ref_d['grad'] - ref['grad']).max() <= 1e-5 * scale      # pick 0 of the stream == the recorded pick (atomics: order noise)
+    _run_world(script, dict(env, MASTER_PORT=str(port + 1)), 2, True, draw=True)
+    got = np.load(tmp_path / 'rank1_of_2_1d.npz')
+    assert np.abs(got['grad'] - ref_d['grad']).max() <= 2e-4 * scale
+    assert abs(float(got['loss']) - float(ref_d['loss'])) <= 1e-5 * abs(float(ref_d['loss']))
 
 
 VIEW_WORKER = r'''
