@@ -15,9 +15,9 @@ from .ibrnet.sample_ray import RaySamplerSingleImage
 
 criterion = Criterion()
 
-_UNSUPPORTED_FLAGS = ('gt_depth_path', 'use_patch_sampling', 'use_pseudo_gt', 'density_loss', 'depth_var_loss',
+_UNSUPPORTED_FLAGS = ('gt_depth_path', 'use_patch_sampling', 'density_loss', 'depth_var_loss',
                       'depth_diff_loss', 'depth_consistency_loss', 'depth_smooth_loss', 'camera_consistency_loss',
-                      'perturb_camera', 'use_pcgrad', 'use_unseen_views')
+                      'perturb_camera', 'use_pcgrad')
 
 
 def _reject_out_of_scope(args):
@@ -50,10 +50,34 @@ def _is_gnt(model):
     return isinstance(getattr(model, 'net_coarse', None), GNT)
 
 
+def _render(gnt, train_ray_batch, model, projector, featmaps, args, src_ray_batch, det):
+    if gnt:         # eval/gnt/eval_adv.py:319-333
+        from .gnt.render_ray import render_rays as gnt_render_rays
+        return gnt_render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
+                               N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
+                               det=det, white_bkgd=args.white_bkgd, ret_alpha=getattr(args, 'ret_alpha', False),
+                               single_net=getattr(args, 'single_net', True), args=args, src_ray_batch=src_ray_batch)
+    return render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
+                       N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
+                       det=det, white_bkgd=args.white_bkgd, args=args, src_ray_batch=src_ray_batch)
+
+
+def clean_featmaps(model, src_ray_batch):
+    """feature maps of the UNPERTURBED source images (no gradient): the pseudo-ground-truth render reads them.  They do not
+    depend on delta, so a PGD loop computes them once (PGDAttack) where the reference re-runs the CNN every iteration."""
+    with torch.no_grad():
+        return model.feature_net(src_ray_batch['src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
+
+
 def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, return_loss=True, select_inds=None,
-                         shard=None, criterion=None, lookahead=False):
+                         shard=None, criterion=None, lookahead=False, featmaps_clean=None):
     """One loss evaluation of the attack (eval_adv.py:258-310,512-519): draw N_rand rays of the target view `data`,
     features from the PERTURBED source images, colours from the CLEAN ones, masked MSE on coarse + fine.
+
+    args.use_pseudo_gt (forced by args.use_unseen_views, eval_adv.py:652-653; the caller supplies the interpolated target
+    camera in data['camera']): the target colours are the model's own render from the clean source images
+    (eval_adv.py:271-290 -- outputs_fine; the GNT flavour takes outputs_coarse, eval/gnt/eval_adv.py:296-315), always with
+    det=True.  featmaps_clean: those clean feature maps if the caller already has them.
 
     select_inds: optional explicit pixel indices (otherwise drawn from the reference's RandomState(234) stream).
     shard: optional `RayShard` -- this rank renders its slice of the drawn rays and the loss denominators are the
@@ -74,20 +98,21 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
         featmaps = shard.view_sharded_featmaps(model.feature_net, src_ray_batch['src_rgbs'], delta)
     else:
         featmaps = model.feature_net((src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
-    if _is_gnt(model):      # eval/gnt/eval_adv.py:319-333: GNT renderer, criterion passed in (unmasked MSE)
+    gnt = _is_gnt(model)
+    if getattr(args, 'use_pseudo_gt', False) or getattr(args, 'use_unseen_views', False):
+        with torch.no_grad():
+            if featmaps_clean is None:
+                featmaps_clean = clean_featmaps(model, src_ray_batch)
+            ret_gt = _render(gnt, train_ray_batch, model, projector, featmaps_clean, args, src_ray_batch, True)
+            level = ret_gt['outputs_coarse'] if gnt else ret_gt['outputs_fine']
+            train_ray_batch['rgb'] = level['rgb']
+            train_ray_batch['depth'] = level['depth']
+    if gnt:         # criterion passed in (unmasked MSE)
         from .gnt.criterion import Criterion as GntCriterion
-        from .gnt.render_ray import render_rays as gnt_render_rays
         crit = criterion if criterion is not None else GntCriterion()
-        ret = gnt_render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
-                              N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
-                              det=getattr(args, 'det', True), white_bkgd=args.white_bkgd,
-                              ret_alpha=getattr(args, 'ret_alpha', False), single_net=getattr(args, 'single_net', True),
-                              args=args, src_ray_batch=src_ray_batch)
     else:
         crit = criterion if criterion is not None else globals()['criterion']
-        ret = render_rays(ray_batch=train_ray_batch, model=model, projector=projector, featmaps=featmaps,
-                          N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
-                          det=getattr(args, 'det', True), white_bkgd=args.white_bkgd, args=args, src_ray_batch=src_ray_batch)
+    ret = _render(gnt, train_ray_batch, model, projector, featmaps, args, src_ray_batch, getattr(args, 'det', True))
     counts, global_loss = None, None
     if shard is not None:
         counts, global_loss = shard.global_counts_and_loss(ret, train_ray_batch)
@@ -284,6 +309,7 @@ class PGDAttack:
             self.exp_avg_sq = torch.zeros_like(self.delta.data)
         self.iters = 0
         self.last_loss = None
+        self._featmaps_clean = None
 
     def lr(self):
         step_size = getattr(self.args, 'lr_step_size', 100)
@@ -292,8 +318,11 @@ class PGDAttack:
 
     def gradient(self, data, select_inds=None, lookahead=True):
         self.delta.grad = None
+        if self._featmaps_clean is None and (getattr(self.args, 'use_pseudo_gt', False) or getattr(self.args, 'use_unseen_views', False)):
+            self._featmaps_clean = clean_featmaps(self.model, self.src)
         loss, total = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data,
-                                           return_loss=True, select_inds=select_inds, shard=self.shard, lookahead=lookahead)
+                                           return_loss=True, select_inds=select_inds, shard=self.shard, lookahead=lookahead,
+                                           featmaps_clean=self._featmaps_clean)
         loss.backward()
         grad = self.delta.grad
         if self.shard is not None:

@@ -1,6 +1,8 @@
-"""Clean / adversarial evaluation loop over target views: the evaluation half of eval/ibrnet/eval.py:65-160 and
-eval/ibrnet/eval_adv.py:861-905 -- render a full image through `render_single_image`, clip, PSNR and SSIM -- without
-TensorFlow / LPIPS / file output.  The metrics restate the TF ops the reference calls (`tf.image.psnr`, `tf.image.ssim`:
+"""Clean / adversarial evaluation and frame-rendering loops over target views: the evaluation half of
+eval/ibrnet/eval.py:65-160, eval/ibrnet/eval_adv.py:861-905 and eval/gnt/eval.py:41-236 (`evaluate_view(s)`: render a full
+image through `render_single_image` of the model's flavour, clip, PSNR and SSIM) and the frame loop of
+eval/ibrnet/render_llff_video.py:156-223 / eval/gnt/render.py:41-98 (`render_frames`: a list of camera batches -> cropped
+uint8 frames, depth and accumulation maps) -- without TensorFlow / LPIPS / image or video file output.  The metrics restate the TF ops the reference calls (`tf.image.psnr`, `tf.image.ssim`:
 11x11 Gaussian window, sigma 1.5, K1 0.01, K2 0.03, VALID filtering, mean over pixels then channels) in torch."""
 import math
 
@@ -40,13 +42,20 @@ def ssim(pred, gt, max_val=1.0, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.
     return float((luminance * cs).mean(dim=(2, 3)).mean())
 
 
-def evaluate_view(args, model, projector, data, delta=None, device=None):
-    """One target view: full-image render (perturbed source images when `delta` [1,V,H,W,3] is given; the clean feature maps
-    are also computed when the clean-colour / clean-density ablation flags are set, eval_adv.py:868-871) -> metrics dict."""
+def _is_gnt(model):
+    from .gnt.transformer_network import GNT
+    return isinstance(getattr(model, 'net_coarse', None), GNT)
+
+
+def render_view(args, model, projector, data, delta=None, device=None):
+    """Full-image render of one target view with the model's own flavour of render_single_image (perturbed source images when
+    `delta` [1,V,H,W,3] is given; the clean feature maps are also computed when the clean-colour / clean-density ablation
+    flags are set, eval_adv.py:868-871).  -> (ret dict of CPU tensors, sampler)"""
     device = device if device is not None else next(model.feature_net.parameters()).device
     model.switch_to_eval()
+    stride = getattr(args, 'render_stride', 1)
     with torch.no_grad():
-        sampler = RaySamplerSingleImage(data, device)
+        sampler = RaySamplerSingleImage(data, device, render_stride=stride)
         ray_batch = sampler.get_all()
         src = ray_batch['src_rgbs']
         featmaps_clean = None
@@ -56,11 +65,23 @@ def evaluate_view(args, model, projector, data, delta=None, device=None):
                 featmaps_clean = model.feature_net(src.squeeze(0).permute(0, 3, 1, 2))
         else:
             featmaps = model.feature_net(src.squeeze(0).permute(0, 3, 1, 2))
-        ret = render_single_image(ray_sampler=sampler, ray_batch=ray_batch, model=model, projector=projector,
-                                  chunk_size=args.chunk_size, det=True, N_samples=args.N_samples,
-                                  inv_uniform=args.inv_uniform, N_importance=args.N_importance, white_bkgd=args.white_bkgd,
-                                  featmaps=featmaps, args=args, featmaps_clean=featmaps_clean)
-    gt = data['rgb'][0].cpu()
+        kw = dict(ray_sampler=sampler, ray_batch=ray_batch, model=model, projector=projector, chunk_size=args.chunk_size, det=True,
+                  N_samples=args.N_samples, inv_uniform=args.inv_uniform, N_importance=args.N_importance,
+                  white_bkgd=args.white_bkgd, render_stride=stride, featmaps=featmaps, args=args, featmaps_clean=featmaps_clean)
+        if _is_gnt(model):      # eval/gnt/eval.py:153-176 (log_view)
+            from .gnt.render_image import render_single_image as gnt_render_single_image
+            ret = gnt_render_single_image(ret_alpha=getattr(args, 'ret_alpha', False), single_net=getattr(args, 'single_net', True), **kw)
+        else:
+            ret = render_single_image(**kw)
+    return ret, sampler
+
+
+def evaluate_view(args, model, projector, data, delta=None, device=None):
+    """One target view -> metrics dict ('coarse_psnr', 'coarse_ssim', and the fine pair when there is a fine level; the GNT
+    flavour reports the level its log_view scores: fine if present, else coarse -- eval/gnt/eval.py:223-231)."""
+    ret, sampler = render_view(args, model, projector, data, delta, device)
+    stride = getattr(args, 'render_stride', 1)
+    gt = data['rgb'][0].cpu()[::stride, ::stride]
     out = {}
     for level in ('coarse', 'fine'):
         o = ret['outputs_' + level]
@@ -70,6 +91,30 @@ def evaluate_view(args, model, projector, data, delta=None, device=None):
         out[level + '_psnr'] = psnr(pred, gt)
         out[level + '_ssim'] = ssim(pred, gt)
     out['ret'] = ret
+    return out
+
+
+def render_frames(args, model, projector, frames, delta=None, crop_ratio=0.075, device=None):
+    """The frame loop of render_llff_video.py:156-223: every element of `frames` is a loader-style batch of one target camera
+    (no ground-truth image needed) with its source views.  Per frame: the 8-bit colour image of the finest level cropped by
+    `crop_ratio` at every border (what the reference appends to the video), and per level the uncropped 8-bit colour, the
+    depth map and the accumulation map (sum of the weights; None for GNT without ret_alpha)."""
+    out = []
+    for data in frames:
+        ret, sampler = render_view(args, model, projector, data, delta, device)
+        frame = {}
+        for level in ('coarse', 'fine'):
+            o = ret['outputs_' + level]
+            if o is None:
+                continue
+            rgb8 = (255 * o['rgb'].detach().cpu().numpy().clip(0.0, 1.0)).astype('uint8')
+            w = o.get('weights')
+            frame[level] = {'rgb8': rgb8, 'depth': o.get('depth'), 'acc': None if w is None else w.sum(dim=-1)}
+        best = frame['fine' if 'fine' in frame else 'coarse']['rgb8']
+        h, w_ = best.shape[:2]
+        ch, cw = int(h * crop_ratio), int(w_ * crop_ratio)
+        frame['video_frame'] = best[ch:h - ch, cw:w_ - cw, :]
+        out.append(frame)
     return out
 
 

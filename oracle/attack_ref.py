@@ -28,7 +28,16 @@ def init_adv_perturb(src_rgbs, epsilon, upper_limit=1.0, lower_limit=0.0, genera
 
 def attack_loss(delta, cnn_state, params_coarse, params_fine, src_ray_batch, train_ray_batch, cfg, cnn_trace=None):
     """ref: eval/ibrnet/eval_adv.py:292-310 -- features from PERTURBED images, colours from CLEAN images.
+    cfg['use_pseudo_gt'] (ref :271-290): the target colours are the fine-level render from the CLEAN source images (no grad).
     cnn_trace: optional feature_net_ref.ReluTrace (evaluate the CNN on a given ReLU activation pattern / record its own)."""
+    if cfg.get('use_pseudo_gt', False):
+        with torch.no_grad():
+            clean = fnet.resunet_forward(cnn_state, src_ray_batch['src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
+            ret_gt = ib.render_rays(train_ray_batch, params_coarse, params_fine, clean, cfg['N_samples'],
+                                    inv_uniform=cfg['inv_uniform'], N_importance=cfg['N_importance'], det=True,
+                                    white_bkgd=cfg.get('white_bkgd', False), src_ray_batch=src_ray_batch,
+                                    anti_alias_pooling=cfg.get('anti_alias_pooling', True))
+        train_ray_batch = dict(train_ray_batch, rgb=ret_gt['outputs_fine']['rgb'], depth=ret_gt['outputs_fine']['depth'])
     imgs = (src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2)
     featmaps = fnet.resunet_forward(cnn_state, imgs, trace=cnn_trace)
     ret = ib.render_rays(train_ray_batch, params_coarse, params_fine, featmaps, cfg['N_samples'],

@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Round-2 golden vectors from the REFERENCE (imported from /root/reference, see _refimport.py):
+
+  attack_extra.npz
+    pseudo/*     eval/ibrnet/eval_adv.py:271-290 -- optimize_adv_perturb with args.use_pseudo_gt on the inputs of
+                 attack_tiny.npz (delta0, first pixel pick of the RandomState(234) stream): the pseudo ground-truth colours,
+                 the loss and d loss / d delta
+    universal/*  eval/ibrnet/eval_adv.py:634-740 -- the universal loop over TWO target views that share the perturbed source
+                 views (adv_iters = 3, so 4 steps: the reference's `iters > adv_iters` test), Adam-ascent + StepLR + both
+                 clamps: per step the pixel pick, loss, gradient and the perturbation after the step
+
+    python tests/golden/make_golden_r02.py
+
+Data only; runs only in the build container."""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import make_golden as mg  # noqa: E402
+from make_golden import EA, Projector, ResUNet, npy, ref_net, ref_sample_ray, reset_pixel_rng  # noqa: E402
+
+from fixtures import second_target_view  # noqa: E402
+from oracle.feature_net_ref import random_resunet_state  # noqa: E402
+
+
+def main():
+    torch.set_num_threads(8)
+    z = np.load(os.path.join(HERE, 'attack_tiny.npz'))
+    H, W, V, R, S, N_imp, cnn_seed, n_adam, n_sign = [int(x) for x in z['cfg']]
+    t = lambda k: torch.from_numpy(z[k])
+    data = {k: t('in/' + k) for k in ('rgb', 'camera', 'src_rgbs', 'src_cameras', 'depth_range')}
+    data['rgb_path'] = ['golden']
+    pc = {k[7:]: t(k) for k in z.files if k.startswith('coarse/')}
+    pf = {k[5:]: t(k) for k in z.files if k.startswith('fine/')}
+    feature_net = ResUNet(coarse_out_ch=32, fine_out_ch=32, coarse_only=False)
+    feature_net.load_state_dict(random_resunet_state(cnn_seed), strict=True)
+    feature_net.eval()
+    model = SimpleNamespace(net_coarse=ref_net(pc, S), net_fine=ref_net(pf, S + N_imp), feature_net=feature_net)
+    projector = Projector(device='cpu')
+    args = SimpleNamespace(gt_depth_path=None, use_patch_sampling=False, N_rand=R, sample_mode='uniform',
+                           center_ratio=0.8, use_pseudo_gt=True, N_samples=S, inv_uniform=True, N_importance=N_imp,
+                           det=True, white_bkgd=False, density_loss=0, depth_var_loss=0, depth_diff_loss=0,
+                           depth_consistency_loss=0, depth_smooth_loss=0, camera_consistency_loss=0,
+                           perturb_camera=False)
+    sampler = ref_sample_ray.RaySamplerSingleImage(data, 'cpu')
+    src_ray_batch = sampler.get_all()
+    delta0 = t('in/delta0')
+    out = {}
+
+    # ---- pseudo ground truth
+    reset_pixel_rng()
+    delta = delta0.clone().requires_grad_(True)
+    loss, _ = EA.optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, return_loss=True)
+    loss.backward()
+    out['pseudo/loss'] = npy(loss)
+    out['pseudo/grad'] = npy(delta.grad)
+    # the pseudo-GT colours themselves: the reference's clean render of the same rays
+    reset_pixel_rng()
+    batch = sampler.random_sample(R, sample_mode='uniform', center_ratio=0.8)
+    from ibrnet.render_ray import render_rays
+    with torch.no_grad():
+        fm = feature_net(src_ray_batch['src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
+        gt = render_rays(ray_batch=batch, model=model, projector=projector, featmaps=fm, N_samples=S, inv_uniform=True,
+                         N_importance=N_imp, det=True, white_bkgd=False, args=args, src_ray_batch=src_ray_batch)
+    out['pseudo/target_rgb'] = npy(gt['outputs_fine']['rgb'])
+    assert np.array_equal(npy(batch['selected_inds']), z['adam/selected_inds'][0])
+    print('pseudo-GT: loss %.6f  |grad| %.4e' % (float(loss), float(delta.grad.norm())))
+
+    # ---- universal loop over two target views (eval_adv.py:646-740)
+    args.use_pseudo_gt = False
+    views = [data, second_target_view(data)]
+    adv_iters = 3
+    eps = torch.tensor(8 / 255.)
+    reset_pixel_rng()
+    delta = delta0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([delta], lr=1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.5)
+    iters, go, losses = 0, True, []
+    while go:
+        for d in views:
+            loss, _ = EA.optimize_adv_perturb(args, delta, model, projector, src_ray_batch, d, return_loss=True)
+            opt.zero_grad()
+            loss.backward()
+            out['universal/grad_%d' % iters] = npy(delta.grad)
+            delta.grad.data *= -1
+            opt.step()
+            sched.step()
+            delta.data = EA.clamp(delta.data, -eps, eps)
+            delta.data = EA.clamp(delta.data, 0 - src_ray_batch['src_rgbs'], 1 - src_ray_batch['src_rgbs'])
+            losses.append(float(loss))
+            out['universal/delta_%d' % (iters + 1)] = npy(delta.data)
+            iters += 1
+            if iters > adv_iters:
+                go = False
+                break
+    out['universal/losses'] = np.array(losses, dtype=np.float64)
+    out['universal/cfg'] = np.array([adv_iters, iters, 2], dtype=np.int64)       # adv_iters, steps actually run, lr step size
+    rs = np.random.RandomState(234)
+    out['universal/selected_inds'] = np.stack([rs.choice(H * W, size=(R,), replace=False) for _ in range(iters)])
+    print('universal: %d steps for adv_iters=%d, losses %s' % (iters, adv_iters, np.round(losses, 5)))
+    path = os.path.join(HERE, 'attack_extra.npz')
+    np.savez_compressed(path, **out)
+    print('%s %.1f KB' % (path, os.path.getsize(path) / 1024.))
+
+
+if __name__ == '__main__':
+    main()

@@ -197,7 +197,7 @@ def check_render_rays(case, dev):
               % (case, name, err, floor))
         assert err <= max(1e-3, 3 * floor), 'd loss / d featmap_%s: rel-L2 %.3e vs float64 (reference fp32 floor %.3e)' % (name, err, floor)
         assert_close(mine, want, 0, 1e-3 * float(want.abs().max()), 'd loss / d featmap_' + name, frac_ok=1e-3)
-    assert abs(float(loss) - float(loss64)) <= 1e-4 * float(loss64), 'loss vs float64'
+    assert abs(float(loss.detach()) - float(loss64.detach())) <= 1e-4 * float(loss64.detach()), 'loss vs float64'
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -264,8 +264,10 @@ def delta_gradient_float64_check(model, data, delta, picks, cfg, run_gradient, t
         grad = run_gradient()
     finally:
         feature_network.TRACE_RELU = None
-    assert len(trace) == 27, 'one feature-network evaluation expected (27 ReLU layers), got %d' % len(trace)
-    masks = [(t > 0).cpu() for t in trace]
+    # 27 ReLU layers per evaluation; the differentiated evaluation is the LAST one (a pseudo-ground-truth step runs the CNN on
+    # the clean images first, without gradient)
+    assert len(trace) in (27, 54), 'unexpected number of traced ReLU layers: %d' % len(trace)
+    masks = [(t > 0).cpu() for t in trace[-27:]]
     cnn = model.feature_net.state_dict()
     pc_, pf_ = model.net_coarse.state_dict(), model.net_fine.state_dict()
     _, g_nat, tr_nat = atk.float64_gradient(delta, cnn, pc_, pf_, data, picks, cfg)
@@ -370,6 +372,88 @@ def check_attack_steps(dev, free_steps=None):
     if n_free == dims[6]:
         assert abs(np.mean(losses[-3:]) - np.mean(ref_losses[-3:])) < 0.2 * np.mean(ref_losses[-3:])
         assert float((d - g.t('adam/delta_%d' % dims[6], dev)).abs().mean()) < 0.1 * eps
+
+
+def check_pseudo_gt(dev):
+    """args.use_pseudo_gt (eval/ibrnet/eval_adv.py:271-290): target colours = the model's own fine-level render from the CLEAN
+    source images; loss / gradient against the reference's capture and the float64 oracle."""
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    gx = Golden('attack_extra')
+    src = sampler.get_all()
+    picks = g.np('adam/selected_inds')[0]
+    args = SimpleNamespace(**dict(vars(args), use_pseudo_gt=True))
+    with torch.no_grad():
+        ret_gt = render_rays(sampler.select(picks), model, EA.clean_featmaps(model, src), Projector(dev), args.N_samples,
+                             inv_uniform=True, N_importance=args.N_importance, det=True, src_ray_batch=src)
+    assert_close(ret_gt['outputs_fine']['rgb'], gx.np('pseudo/target_rgb'), 1e-3, 1e-3, 'pseudo ground-truth colours')
+    delta0 = g.t('in/delta0', dev)
+    attack = EA.PGDAttack(args, model, Projector(dev), src, delta=delta0.clone().requires_grad_(True))
+    run = lambda: attack.gradient(data, select_inds=picks, lookahead=False)
+    if torch.device(dev).type == 'cuda':
+        cfg = dict(N_samples=args.N_samples, N_importance=args.N_importance, inv_uniform=True, white_bkgd=False, use_pseudo_gt=True)
+        delta_gradient_float64_check(model, data, delta0, picks, cfg, run, 'pseudo-GT')
+    else:
+        grad = run()
+        gerr = float(np.linalg.norm(grad.cpu().numpy() - gx.np('pseudo/grad')) / np.linalg.norm(gx.np('pseudo/grad')))
+        print('[grad parity] pseudo-GT (CPU stand-in): rel-L2 vs reference fp32 %.3e' % gerr)
+        assert gerr < 2e-3
+    assert_close(attack.last_loss, gx.np('pseudo/loss'), 1e-3, 1e-6, 'pseudo-GT loss')
+    # use_unseen_views forces the same branch (eval_adv.py:652-653)
+    a2 = EA.PGDAttack(SimpleNamespace(**dict(vars(args), use_pseudo_gt=False, use_unseen_views=True)), model, Projector(dev), src,
+                      delta=delta0.clone().requires_grad_(True))
+    a2.gradient(data, select_inds=picks, lookahead=False)
+    assert_close(a2.last_loss, gx.np('pseudo/loss'), 1e-3, 1e-6, 'use_unseen_views loss')
+
+
+def check_universal_trajectory(dev):
+    """The reference's universal loop over two target views sharing the perturbed sources (eval_adv.py:634-740; adv_iters = 3
+    -> 4 steps), teacher-forced: from the reference's delta_t reproduce loss_t and grad_t, from its grad_t reproduce
+    delta_{t+1} (Adam-ascent, StepLR(2, 0.5), both clamps); then the free-running loop draws the recorded pixel picks."""
+    from fixtures import second_target_view
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    gx = Golden('attack_extra')
+    adv_iters, n_steps, lr_step = [int(x) for x in gx.np('universal/cfg')]
+    assert n_steps == adv_iters + 1
+    args = SimpleNamespace(**dict(vars(args), adv_iters=adv_iters, lr_step_size=lr_step, lr_gamma=0.5))
+    views = [data, second_target_view(data)]
+    src = sampler.get_all()
+    picks = gx.np('universal/selected_inds')
+    deltas = [g.t('in/delta0', dev)] + [gx.t('universal/delta_%d' % (t + 1), dev) for t in range(n_steps)]
+    attack = EA.PGDAttack(args, model, Projector(dev), src, delta=deltas[0].clone().requires_grad_(True))
+    cfg = dict(N_samples=args.N_samples, N_importance=args.N_importance, inv_uniform=True, white_bkgd=False)
+    for t in range(n_steps):
+        attack.delta.data.copy_(deltas[t])
+        view = views[t % 2]
+        run = lambda: attack.gradient(view, select_inds=picks[t], lookahead=False)
+        if torch.device(dev).type == 'cuda':
+            delta_gradient_float64_check(model, view, deltas[t], picks[t], cfg, run, 'universal step %d' % t)
+        else:
+            grad = run()
+            ref = gx.np('universal/grad_%d' % t)
+            gerr = float(np.linalg.norm(grad.cpu().numpy() - ref) / np.linalg.norm(ref))
+            print('[grad parity] universal step %d (CPU stand-in): rel-L2 vs reference fp32 %.3e' % (t, gerr))
+            assert gerr < 2e-3
+        assert_close(attack.last_loss, gx.np('universal/losses')[t], 1e-3, 1e-6, 'universal loss, step %d' % t)
+        attack.apply(gx.t('universal/grad_%d' % t, dev))
+        assert_close(attack.delta.data, deltas[t + 1], 0, 2e-7, 'delta after universal step %d' % (t + 1))
+    # free-running: step count and the pixel stream (each step consumes one pick of RandomState(234))
+    product_sample_ray.rng.seed(234)
+    seen = []
+    free = EA.PGDAttack(args, model, Projector(dev), src, delta=deltas[0].clone().requires_grad_(True))
+    orig = free.gradient
+
+    def spy(d, select_inds=None, lookahead=True):
+        grad = orig(d, select_inds, lookahead)
+        seen.append(float(free.last_loss))
+        return grad
+    free.gradient = spy
+    free.run_universal(views)
+    assert free.iters == n_steps and len(seen) == n_steps
+    assert_close(np.array(seen[:2]), gx.np('universal/losses')[:2], 2e-3, 1e-6, 'first free-running universal losses')
+    expect = np.random.RandomState(234)
+    for _ in range(n_steps):
+        expect.choice(dims[0] * dims[1], size=(dims[3],), replace=False)
+    assert product_sample_ray.rng.randint(1 << 30) == expect.randint(1 << 30), 'the loop must consume exactly one pick per step'
 
 
 def check_init_perturb(dev):
@@ -825,22 +909,89 @@ def check_gnt_attack_step(dev):
     atk_state = GEA.PGDAttack(args, model, Projector(dev), src)
     delta0 = atk_state.delta.detach().clone()
     picks = np.random.RandomState(5).choice(H * W, size=(R,), replace=False)
-    grad = atk_state.gradient(data, select_inds=picks).clone()
+    from nerfool_amd.ibrnet import feature_network
+    feature_network.TRACE_RELU = trace = []
+    try:
+        grad = atk_state.gradient(data, select_inds=picks).clone()
+    finally:
+        feature_network.TRACE_RELU = None
     loss = float(atk_state.last_loss)
     atk_state.apply(grad)
-    # oracle
-    cnn = {k: v.detach().cpu() for k, v in model.feature_net.state_dict().items()}
-    p = {k: v.detach().cpu() for k, v in model.net_coarse.state_dict().items()}
-    batch = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sampler.select(picks).items()}
-    d = delta0.cpu().requires_grad_(True)
-    fm = fnet.resunet_forward(cnn, (data['src_rgbs'] + d).squeeze(0).permute(0, 3, 1, 2), coarse_out_ch=32, fine_out_ch=32)[0]
-    ret = gr.render_rays(batch, p, (fm, fm), S, depth, inv_uniform=True, det=True,
-                         src_ray_batch={'src_rgbs': data['src_rgbs'], 'src_cameras': data['src_cameras']})
-    ref_loss = gr.criterion(ret['outputs_coarse'], batch)
-    ref_grad, = torch.autograd.grad(ref_loss, d)
-    assert abs(loss - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)) + 1e-6, (loss, float(ref_loss))
-    gerr = float((grad.cpu() - ref_grad).norm() / ref_grad.norm())
-    assert gerr < 2e-2, 'GNT d loss / d delta: relative L2 error %.3e' % gerr
-    opt = atk.AdamAscent(d.shape, 1e-3, 100, 0.5)
+    # float64 oracle on the same weights and rays, the feature CNN on the ReLU pattern this evaluation used (when the fused
+    # executor ran: see delta_gradient_float64_check)
+    f64 = lambda t: t.detach().cpu().double() if torch.is_tensor(t) and t.is_floating_point() else (t.cpu() if torch.is_tensor(t) else t)
+    cnn = {k: f64(v) for k, v in model.feature_net.state_dict().items()}
+    p = {k: f64(v) for k, v in model.net_coarse.state_dict().items()}
+    batch = {k: f64(v) for k, v in sampler.select(picks).items()}
+    src64 = {'src_rgbs': f64(data['src_rgbs']), 'src_cameras': f64(data['src_cameras'])}
+    masks = [(t > 0).cpu() for t in trace] or None
+
+    def oracle(masks):
+        d = f64(delta0).requires_grad_(True)
+        tr = fnet.ReluTrace(masks)
+        fm = fnet.resunet_forward(cnn, (src64['src_rgbs'] + d).squeeze(0).permute(0, 3, 1, 2), coarse_out_ch=32, fine_out_ch=32,
+                                  trace=tr)[0]
+        ret = gr.render_rays(batch, p, (fm, fm), S, depth, inv_uniform=True, det=True, src_ray_batch=src64)
+        l = gr.criterion(ret['outputs_coarse'], batch)
+        return float(l.detach()), torch.autograd.grad(l, d)[0], tr
+    ref_loss, g_nat, tr_nat = oracle(None)
+    n_flip, n_units, worst = atk.relu_pattern_flips(tr_nat, masks) if masks else (0, 0, 0.0)
+    ref_grad = oracle(masks)[1] if n_flip else g_nat
+    assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-7, (loss, ref_loss)
+    gerr = float((grad.cpu().double() - ref_grad).norm() / ref_grad.norm())
+    print('[grad parity] GNT step: d loss / d delta rel-L2 vs float64 oracle %.3e (ReLU units flipped: %d of %d, argument <= %.1e of the '
+          'plane rms)' % (gerr, n_flip, n_units, worst))
+    assert gerr <= 1e-3, 'GNT d loss / d delta: relative L2 error %.3e' % gerr
+    assert worst <= 1e-4 and n_flip <= 3
+    opt = atk.AdamAscent(delta0.shape, 1e-3, 100, 0.5)
     want = atk.project(opt.step(delta0.cpu(), grad.cpu()), data['src_rgbs'], 8.0 / 255.0)
     assert_close(atk_state.delta.detach(), want, 0, 2e-7, 'GNT delta after the fused Adam step')
+
+
+def check_eval_views_gnt_and_frames(dev):
+    """eval_views on the GNT flavour (eval/gnt/eval.py:140-236: its own render_single_image, PSNR of the rendered level) and
+    the frame loop of render_llff_video.py:156-223 / eval/gnt/render.py:41-98 (`render_frames`): against render_single_image
+    called directly, the 7.5 % border crop, 8-bit conversion, accumulation map = sum of the weights."""
+    from fixtures import second_target_view
+    from nerfool_amd import eval_views as ev
+    from nerfool_amd.gnt.model import GNTModel
+    from nerfool_amd.gnt.render_image import render_single_image as gnt_render_single_image
+    from nerfool_amd.synthetic import make_scene
+    # IBRNet flavour: two frames
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    model.switch_to_eval = lambda: None
+    H, W = dims[0], dims[1]
+    frames = ev.render_frames(args, model, Projector(dev), [data, second_target_view(data)], device=dev)
+    assert len(frames) == 2
+    ret, _ = ev.render_view(args, model, Projector(dev), data, device=dev)
+    f0 = frames[0]
+    want8 = (255 * ret['outputs_fine']['rgb'].numpy().clip(0, 1)).astype('uint8')
+    # two renders of one view may differ in the last bit (the per-layer convolution choice is timed on first use), i.e. by
+    # one 8-bit level after truncation
+    assert int(np.abs(f0['fine']['rgb8'].astype(np.int32) - want8.astype(np.int32)).max()) <= 1
+    ch, cw = int(H * 0.075), int(W * 0.075)
+    assert f0['video_frame'].shape == (H - 2 * ch, W - 2 * cw, 3)
+    assert np.array_equal(f0['video_frame'], f0['fine']['rgb8'][ch:H - ch, cw:W - cw])
+    assert_close(f0['coarse']['acc'], ret['outputs_coarse']['weights'].sum(-1), 0, 1e-4, 'accumulation map')
+    assert float(np.abs(frames[0]['fine']['rgb8'].astype(np.int32) - frames[1]['fine']['rgb8'].astype(np.int32)).mean()) > 0, 'second camera differs'
+    # GNT flavour
+    torch.manual_seed(0)
+    gargs = SimpleNamespace(netwidth=64, trans_depth=2, single_net=True, ret_alpha=True, coarse_feat_dim=32, fine_feat_dim=32,
+                            N_rand=16, N_samples=8, N_importance=0, inv_uniform=True, det=True, white_bkgd=False, chunk_size=512,
+                            ckpt_path=None)
+    gmodel = GNTModel(gargs, device=dev)
+    gmodel.switch_to_eval()
+    gdata = make_scene(24, 32, 3, seed=21, tilt=0.3)
+    m = ev.evaluate_view(gargs, gmodel, Projector(dev), gdata, device=dev)
+    assert 'coarse_psnr' in m and 'fine_psnr' not in m
+    gs = RaySamplerSingleImage(gdata, dev)
+    rb = gs.get_all()
+    with torch.no_grad():
+        fm = gmodel.feature_net(rb['src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
+        direct = gnt_render_single_image(ray_sampler=gs, ray_batch=rb, model=gmodel, projector=Projector(dev), chunk_size=512,
+                                         N_samples=8, inv_uniform=True, det=True, N_importance=0, white_bkgd=False, featmaps=fm,
+                                         ret_alpha=True, single_net=True)
+    assert_close(m['ret']['outputs_coarse']['rgb'], direct['outputs_coarse']['rgb'], 0, 1e-6, 'GNT evaluate_view render')
+    assert abs(m['coarse_psnr'] - ev.psnr(direct['outputs_coarse']['rgb'].clamp(0, 1), gdata['rgb'][0])) < 1e-6
+    gf = ev.render_frames(gargs, gmodel, Projector(dev), [gdata], device=dev)
+    assert gf[0]['coarse']['depth'] is not None and gf[0]['coarse']['acc'] is not None

@@ -73,6 +73,14 @@ def test_attack_steps():
     pc.check_attack_steps('cpu', free_steps=2)
 
 
+def test_pseudo_gt():
+    pc.check_pseudo_gt('cpu')
+
+
+def test_universal_trajectory():
+    pc.check_universal_trajectory('cpu')
+
+
 def test_hybrid_and_sample_pdf():
     pc.check_hybrid_and_sample_pdf('cpu')
 

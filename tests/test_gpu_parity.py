@@ -91,6 +91,18 @@ def test_delta_gradient_vs_float64(case):
     pc.check_delta_gradient_vs_float64(case, 'cuda')
 
 
+def test_pseudo_gt():
+    pc.check_pseudo_gt('cuda')
+
+
+def test_universal_trajectory():
+    pc.check_universal_trajectory('cuda')
+
+
+def test_eval_views_gnt_and_frames():
+    pc.check_eval_views_gnt_and_frames('cuda')
+
+
 def test_hybrid_and_sample_pdf():
     pc.check_hybrid_and_sample_pdf('cuda')
 
