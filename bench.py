@@ -32,9 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3      # MI355X fp32 MFMA / vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec peak
 PMC_PROFILE = 'profiles/r02_pmc_traffic.json'
-ROOFLINE_KERNELS = ('nf_ibrnet_fwd', 'nf_ibrnet_bwd', 'nf_ibrnet_fwd_mfma', 'nf_ibrnet_bwd_mfma', 'nf_project_gather_fwd',
+ROOFLINE_KERNELS = ('nf_ibrnet_fwd', 'nf_ibrnet_bwd', 'nf_ibrnet_fwd_mfma', 'nf_ibrnet_bwd_mfma', 'nf_ibrnet_fwd_mfma_bf16',
+                    'nf_ibrnet_bwd_mfma_bf16', 'nf_project_gather_fwd',
                     'nf_project_gather_bwd', 'nf_gnt_fwd', 'nf_gnt_fwd_mfma', 'nf_gnt_bwd', 'nf_gnt_bwd_mfma', 'nf_pgd_adam_step',
                     'nf_conv3x3_wino')
 
@@ -86,6 +88,10 @@ def parse():
     ap.add_argument('--render-chunks', type=int, default=4, help='4096-ray chunks for the render-throughput leg (0 = skip)')
     ap.add_argument('--model', choices=('ibrnet', 'gnt'), default='ibrnet',
                     help="'gnt' = BASELINE config 4 (GNT depth 8, 800x800, 10 views, 64 samples) -- not the headline line")
+    ap.add_argument('--config', choices=('c2', 'c4', 'c5'), default='c2',
+                    help="BASELINE config: c2 = the headline line (IBRNet, LLFF-fern shape); c4 = --model gnt; c5 = IBRNet DeepVoxels "
+                         "shape, 512x512, 8 source views, 128 + 128 samples, white background, bf16 matrix-core operands in the row network")
+    ap.add_argument('--precision', choices=('fp32', 'bf16'), default=None, help='IBRNet row-network operand precision (default: fp32; c5: bf16)')
     ap.add_argument('--depth', type=int, default=8, help='GNT trans_depth')
     ap.add_argument('--cnn-shard', choices=('view', 'replicated'), default='view',
                     help='N > 1: feature CNN sharded by source view (exchange of feature maps) or replicated on every rank '
@@ -101,7 +107,9 @@ def make_args(a, n_rand):
     args = SimpleNamespace(anti_alias_pooling=1, N_samples=a.samples, N_importance=a.importance, N_rand=n_rand,
                            inv_uniform=True, det=True, white_bkgd=False, epsilon=8, adv_lr=2, use_adam=True, adam_lr=1e-3,
                            lr_step_size=100, lr_gamma=1.0, adv_iters=1000, local_rank=0, coarse_only=False, ckpt_path=None,
-                           sample_mode='uniform', center_ratio=0.8, chunk_size=4096)
+                           sample_mode='uniform', center_ratio=0.8, chunk_size=4096, ibrnet_precision=a.precision or 'fp32')
+    if a.config == 'c5':
+        args.white_bkgd = True          # configs/ibrnet/eval_deepvoxels.txt:20
     if a.model == 'gnt':
         args.netwidth, args.trans_depth, args.single_net, args.ret_alpha = 64, a.depth, True, False
         args.N_importance = 0
@@ -122,7 +130,8 @@ def build_problem(a, dev, height=None, width=None):
         data = make_scene(H, W, a.views, seed=0, blender=True)
         model = GNTModel(args, device=dev)
     else:
-        data = make_scene(H, W, a.views, seed=0)
+        # c5: DeepVoxels depth range = origin depth +- 0.8 (ibrnet/data_loaders/deepvoxels.py:134-143)
+        data = make_scene(H, W, a.views, seed=0, **({'depth_range': (3.2, 4.8)} if a.config == 'c5' else {}))
         model = IBRNetModel(args, device=dev)
         with torch.no_grad():
             for net in (model.net_coarse, model.net_fine):
@@ -282,6 +291,13 @@ def exchange_microbench(shard, V, C, Hf, Wf, H, W, dev, view_sharded, reps=10):
 
 def main():
     a = parse()
+    if a.config == 'c4':
+        a.model = 'gnt'
+    if a.config == 'c5':          # config 5 defaults unless the user overrode the sizes
+        if (a.height, a.width, a.views, a.samples, a.importance) == (756, 1008, 4, 64, 64):
+            a.height, a.width, a.views, a.samples, a.importance = 512, 512, 8, 128, 128
+        a.precision = a.precision or 'bf16'
+        a.cpu_iters = 0
     if a.model == 'gnt':          # config 4 defaults unless the user overrode the sizes
         if (a.height, a.width, a.views) == (756, 1008, 4):
             a.height, a.width, a.views = 800, 800, 10
@@ -390,7 +406,7 @@ def main():
     if a.extras and rank == 0 and a.render_chunks > 0:
         render = render_leg(model, projector, sampler, src_ray_batch, featmaps, a.render_chunks, a.samples, a.importance,
                             a.model == 'gnt', prof)
-    if a.extras and world == 1 and a.model == 'ibrnet':
+    if a.extras and world == 1 and a.model == 'ibrnet' and a.config == 'c2':
         # N_rand = 4096 attack step (SURVEY 8d asks for 512 and 4096)
         big = make_attack(a.cnn_shard, a.scaling, n_rand=4096)
         n = max(5, a.steps // 2)
@@ -442,6 +458,8 @@ def main():
         for ms, meta in zip(k['ms'], k['meta']):
             if name in ('nf_ibrnet_fwd', 'nf_ibrnet_bwd', 'nf_ibrnet_fwd_mfma', 'nf_ibrnet_bwd_mfma'):
                 per_launch.append(('mfma', ibrnet_flops(meta['R'], meta['S'], meta['V']) / (ms * 1e-3) / 1e12))
+            elif name in ('nf_ibrnet_fwd_mfma_bf16', 'nf_ibrnet_bwd_mfma_bf16'):
+                per_launch.append(('mfma_bf16', ibrnet_flops(meta['R'], meta['S'], meta['V']) / (ms * 1e-3) / 1e12))
             elif name == 'nf_project_gather_fwd':
                 b = meta['n_pts'] * meta['V'] * (4 * (meta['C'] + 3) * 4 + (3 + meta['C'] + 4 + 1) * 4)
                 per_launch.append(('hbm', b / (ms * 1e-3) / 1e9))
@@ -467,7 +485,9 @@ def main():
         if per_launch:
             bound = per_launch[0][0]
             ach = float(np.mean([x[1] for x in per_launch]))
-            peak = PEAK_F32_TFLOPS if bound == 'mfma' else PEAK_HBM_GBS
+            peak = {'mfma': PEAK_F32_TFLOPS, 'mfma_bf16': PEAK_BF16_TFLOPS, 'hbm': PEAK_HBM_GBS}[bound]
+            if bound == 'mfma_bf16':
+                bound = 'mfma'          # priced against the dense bf16 matrix peak
             table[name] = {'bound': bound, 'achieved': round(ach, 4), 'peak': peak, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
                            'frac': round(ach / peak, 5), 'launches': k['launches'], 'mean_ms': round(k['mean_ms'], 4),
                            'total_ms': round(k['total_ms'], 3)}
@@ -500,6 +520,15 @@ def main():
 
     par = 'single GPU' if world == 1 else ('ray-sharded dp%d, %s scaling, feature CNN %s' % (
         world, a.scaling, 'sharded by source view' if a.cnn_shard == 'view' else 'replicated (one all-reduce of d delta)'))
+    if a.model == 'ibrnet':
+        workload = ('BASELINE config %s: IBRNet view-specific attack, %s-shaped synthetic scene %dx%d, %d source views, %d+%d samples/ray, '
+                    'N_rand=%d rays per %s per step, Adam lr 1e-3, eps 8/255%s'
+                    % (('5', 'DeepVoxels') if a.config == 'c5' else ('2', 'LLFF-fern')) + (a.height, a.width, V, Sc, a.importance, a.n_rand,
+                       'rank' if a.scaling == 'weak' else 'step (all ranks)',
+                       ', IBRNet row network on bf16 matrix-core operands' if a.precision == 'bf16' else ''))
+    else:
+        workload = ('BASELINE config 4: GNT depth %d view-specific attack, synthetic scene %dx%d, %d source views, %d samples/ray, '
+                    'N_rand=%d rays per rank per step' % (a.depth, a.height, a.width, V, Sc, a.n_rand))
     out = {
         'metric': 'rays/s through the %s PGD attack step (render fwd+bwd + CNN fwd+bwd + delta update), %d src views'
                   % ('IBRNet' if a.model == 'ibrnet' else 'GNT', a.views),
@@ -507,13 +536,11 @@ def main():
         'unit': 'rays/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': ms_step,
-        'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': ('BASELINE config 2: IBRNet view-specific attack, LLFF-fern-shaped synthetic scene %dx%d, %d source '
-                                'views, %d+%d samples/ray, N_rand=%d rays per %s per step, Adam lr 1e-3, eps 8/255'
-                                % (a.height, a.width, V, Sc, a.importance, a.n_rand, 'rank' if a.scaling == 'weak' else 'step (all ranks)'))
-                   if a.model == 'ibrnet' else
-                   ('BASELINE config 4: GNT depth %d view-specific attack, synthetic scene %dx%d, %d source views, %d '
-                    'samples/ray, N_rand=%d rays per rank per step' % (a.depth, a.height, a.width, V, Sc, a.n_rand)),
+        'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
+        # the arithmetic type of the path: c5 runs the IBRNet row network on bf16 matrix-core operands (fp32 accumulate; CNN, per-ray
+        # part, compositing and update in fp32)
+        'dtype': 'bf16' if (a.precision == 'bf16') else 'f32', 'data': 'synthetic',
+        'config': {'workload': workload,
                    'rays_per_step_all_ranks': rays_per_step, 'parallelism': par,
                    'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step},
         'roofline': roofline,

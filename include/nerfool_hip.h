@@ -116,6 +116,21 @@ int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, const float* p
                        const float* ray_diff, const float* mask, const float* smp, const float* d_raw, int64_t n_rays,
                        int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat, float* d_workspace,
                        nf_stream_t stream);
+/* bf16-operand variant of the matrix-core path (BASELINE config 5, "bf16 MFMA path"): the per-(sample, view) row network of
+ * IBRNet.forward (ibrnet/mlp_network.py:231-257, 268-273: ray_dir_fc, base_fc, vis_fc, vis_fc2, rgb_fc) runs on
+ * v_mfma_f32_32x32x16_bf16 -- weights and activations rounded to bf16 at the matrix-core inputs, fp32 accumulation; pooling,
+ * ELU / sigmoid / softmax and the per-ray part (geometry_fc, ray attention, LayerNorm, density head) stay fp32.
+ * bf16_blob = nf_ibrnet_pack_mfma_bf16(mfma blob) (HOST pointers; nf_ibrnet_mfma_bf16_blob_floats() floats), copied to the
+ * device by the caller.  Same arguments, workspaces and outputs as nf_ibrnet_fwd_mfma / nf_ibrnet_bwd_mfma. */
+int64_t nf_ibrnet_mfma_bf16_blob_floats(void);
+int nf_ibrnet_pack_mfma_bf16(const float* mfma_blob_host, float* bf16_blob_host);
+int nf_ibrnet_fwd_mfma_bf16(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
+                            const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_rays, int n_samples,
+                            int n_views, int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream);
+int nf_ibrnet_bwd_mfma_bf16(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
+                            const float* rgb_feat, const float* ray_diff, const float* mask, const float* smp,
+                            const float* d_raw, int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling,
+                            float* d_rgb_feat, float* d_workspace, nf_stream_t stream);
 /* diagnostics: d[lane][16] = mfma_f32_32x32x2_f32(a[lane], b[lane], c[lane][16]) for one wave -- pins the fragment
  * layout the kernels (and the CPU stand-in of the test-suite) assume */
 int nf_debug_mfma32(const float* a, const float* b, const float* c, float* d, nf_stream_t stream);

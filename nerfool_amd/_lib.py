@@ -42,6 +42,10 @@ _PROTOTYPES = {
     'nf_ibrnet_mfma_workspace_floats': (c_int64, [c_int64, c_int]),
     'nf_ibrnet_fwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_ibrnet_bwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_ibrnet_mfma_bf16_blob_floats': (c_int64, []),
+    'nf_ibrnet_pack_mfma_bf16': (c_int, [_P, _P]),
+    'nf_ibrnet_fwd_mfma_bf16': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_ibrnet_bwd_mfma_bf16': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_debug_mfma32': (c_int, [_P, _P, _P, _P, _P]),
     'nf_composite_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'nf_composite_bwd': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),

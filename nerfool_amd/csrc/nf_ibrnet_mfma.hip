@@ -18,6 +18,8 @@
 //
 // ref: ibrnet/mlp_network.py:222-274.  Cross-checked on device against the generic kernels of nf_ibrnet.hip and against
 // the oracle in tests/.
+#include <string.h>
+
 #include "nf_ibrnet.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -97,6 +99,69 @@ enum {
 enum { BT_DIR0, BT_DIR1, BT_BASE0A, BT_BASE0B, BT_BASE1, BT_VIS0, BT_VIS1, BT_VISB0, BT_RGB0 };
 
 #define NF_SMP_STRIDE 72   // per-sample record written by kernel A: mean2 32 | var2 32 | wmean | rgb 3 | nvalid | vsum | pad
+
+// ---- bf16-operand variant of the row kernels (BASELINE config 5: "bf16 MFMA path") -----------------------------------
+// v_mfma_f32_32x32x16_bf16: bf16 operands, fp32 accumulation, 16x the fp32 matrix rate.  Eight consecutive fp32 k-steps
+// (one lane value each) become ONE bf16 k-step: lane (i, h) element j of a "group" = the fp32 record of step 8g + j, and
+// registers 8g .. 8g+7 of an activation fragment, rounded pairwise to bf16, are its B operand (the accumulator of one layer
+// is still a legal operand of the next: cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").
+// The group image is derived mechanically from the fp32 record image by nf_ibrnet_pack_mfma_bf16, so the two paths cannot
+// drift apart.  Everything on the VALU (pooling, ELU, softmax, the small heads) and the per-ray kernels stay fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define NF_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+struct BfSeg { int start, n; };       // a run of fp32 records consumed by one gemm call: ceil(n / 8) bf16 groups
+__host__ __device__ constexpr BfSeg bf_fwd_seg(int i) {
+    constexpr int b0 = MR_BASE0, b1 = MR_BASE0 + 54;
+    constexpr BfSeg t[] = {{MR_DIR0, 2}, {MR_DIR1, 8},
+                           {b0, 16}, {b0 + 16, 2}, {b0 + 18, 16}, {b0 + 34, 2}, {b0 + 36, 16}, {b0 + 52, 2},
+                           {b1, 16}, {b1 + 16, 2}, {b1 + 18, 16}, {b1 + 34, 2}, {b1 + 36, 16}, {b1 + 52, 2},
+                           {MR_BASE1, 16}, {MR_BASE1 + 16, 16}, {MR_VIS0, 16}, {MR_VIS1, 16}, {MR_VISB0, 16},
+                           {MR_RGB0, 16}, {MR_RGB0 + 16, 3}};
+    return t[i];
+}
+#define BF_FWD_SEGS 21
+__host__ __device__ constexpr BfSeg bf_bwd_seg(int i) {       // record indices relative to MT_BASE
+    constexpr BfSeg t[] = {{MT_RGB0, 8}, {MT_VISB0, 16}, {MT_VIS1, 16}, {MT_VIS0, 16}, {MT_BASE1, 16}, {MT_BASE1 + 16, 16},
+                           {MT_BASE0, 16}, {MT_BASE0 + 16, 16}, {MT_BASE0 + 32, 16}, {MT_BASE0 + 48, 16}, {MT_BASE0 + 64, 16},
+                           {MT_BASE0 + 80, 16}, {MT_BASE0 + 96, 16}, {MT_BASE0 + 112, 16}};
+    return t[i];
+}
+#define BF_BWD_SEGS 14
+__host__ __device__ constexpr int bf_grp_fwd(int rec) {       // fp32 record index -> bf16 group index
+    int g = 0;
+    for (int i = 0; i < BF_FWD_SEGS; ++i) {
+        BfSeg s = bf_fwd_seg(i);
+        if (rec >= s.start && rec < s.start + s.n) return g + (rec - s.start) / 8;
+        g += (s.n + 7) / 8;
+    }
+    return -1;
+}
+__host__ __device__ constexpr int bf_grp_bwd(int rec) {
+    int g = 0;
+    for (int i = 0; i < BF_BWD_SEGS; ++i) {
+        BfSeg s = bf_bwd_seg(i);
+        if (rec >= s.start && rec < s.start + s.n) return g + (rec - s.start) / 8;
+        g += (s.n + 7) / 8;
+    }
+    return -1;
+}
+enum {
+    BF_FWD_GROUPS = 33, BF_BWD_GROUPS = 27,
+    BF_GROUP_FLOATS = 256,                                   // 64 lanes x 8 bf16 = 1 KB
+    // LDS / blob image of the bf16 row kernels, in floats: forward groups at 0; the fp32 VALU tables at their usual offsets
+    // [MS_BASE, MS_END); the transposed groups fill the gap in between and continue behind the tables
+    BF_BWD_IN_GAP = (MS_BASE - BF_FWD_GROUPS * BF_GROUP_FLOATS) / BF_GROUP_FLOATS,          // 21
+    NF_BF_FWD_FLOATS = MS_END,                               // what the forward kernel stages (58 KB, as the fp32 one)
+    NF_BF_BLOB_FLOATS = MS_END + (BF_BWD_GROUPS - BF_BWD_IN_GAP) * BF_GROUP_FLOATS          // 64 KB: forward + backward
+};
+static_assert(bf_grp_fwd(MR_RGB0 + 16) == BF_FWD_GROUPS - 1, "forward group count");
+static_assert(bf_grp_bwd(MT_BASE0 + 120) == BF_BWD_GROUPS - 1, "backward group count");
+static_assert(BF_BWD_IN_GAP >= 1 && BF_BWD_IN_GAP < BF_BWD_GROUPS && MS_END % 4 == 0, "bf16 image layout");
+__host__ __device__ constexpr int bf_fwd_off(int g) { return g * BF_GROUP_FLOATS; }
+__host__ __device__ constexpr int bf_bwd_off(int g) {
+    return g < BF_BWD_IN_GAP ? (BF_FWD_GROUPS + g) * BF_GROUP_FLOATS : MS_END + (g - BF_BWD_IN_GAP) * BF_GROUP_FLOATS;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // host: natural blob (nf_ibrnet.h layout) -> MFMA-order blob
@@ -276,6 +341,37 @@ extern "C" int nf_ibrnet_pack_mfma(const float* nat, float* out) {
     return 0;
 }
 
+extern "C" int64_t nf_ibrnet_mfma_bf16_blob_floats(void) { return NF_BF_BLOB_FLOATS; }
+
+static uint16_t bf16_rne(float f) {       // round to nearest even, NaN kept a NaN (the blob holds finite weights)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+/* mfma_blob: output of nf_ibrnet_pack_mfma (host memory); out: nf_ibrnet_mfma_bf16_blob_floats() floats (host memory) */
+extern "C" int nf_ibrnet_pack_mfma_bf16(const float* mfma_blob, float* out) {
+    for (int i = 0; i < NF_BF_BLOB_FLOATS; ++i) out[i] = 0.f;
+    for (int i = MS_BASE; i < MS_END; ++i) out[i] = mfma_blob[i];
+    auto pack = [&](const float* recs, BfSeg sg, int g0, bool bwd) {
+        for (int g = 0; g < (sg.n + 7) / 8; ++g) {
+            uint16_t* dst = (uint16_t*)(out + (bwd ? bf_bwd_off(g0 + g) : bf_fwd_off(g0 + g)));
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    int st = 8 * g + j;
+                    dst[lane * 8 + j] = st < sg.n ? bf16_rne(recs[(size_t)(sg.start + st) * 64 + lane]) : (uint16_t)0;
+                }
+        }
+    };
+    int g = 0;
+    for (int i = 0; i < BF_FWD_SEGS; ++i) { pack(mfma_blob, bf_fwd_seg(i), g, false); g += (bf_fwd_seg(i).n + 7) / 8; }
+    if (g != BF_FWD_GROUPS) return 1;
+    g = 0;
+    for (int i = 0; i < BF_BWD_SEGS; ++i) { pack(mfma_blob + MT_BASE, bf_bwd_seg(i), g, true); g += (bf_bwd_seg(i).n + 7) / 8; }
+    return g == BF_BWD_GROUPS ? 0 : 2;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------
@@ -313,11 +409,46 @@ __device__ __forceinline__ f32x16 bias_tile(const float* lds, int tile, int h) {
     return a;
 }
 
-// acc += W(records rec .. rec+NSTEPS-1) . x  (k-step r consumes register r of the fragment x)
-template <int NSTEPS>
+__device__ __forceinline__ bf16x8 pack_bf8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    bf16x8 b;
+    b[0] = (__bf16)v0; b[1] = (__bf16)v1; b[2] = (__bf16)v2; b[3] = (__bf16)v3;
+    b[4] = (__bf16)v4; b[5] = (__bf16)v5; b[6] = (__bf16)v6; b[7] = (__bf16)v7;
+    return b;
+}
+
+// acc += W(records rec .. rec+NSTEPS-1) . x  (k-step r consumes register r of the fragment x); BF: one bf16 MFMA per 8 steps.
+// `rec` must be a compile-time constant in the BF form (it is after unrolling: the group lookup folds away).
+template <bool BF, int NSTEPS>
 __device__ __forceinline__ f32x16 gemm_frag(const float* lds, int rec, int lane, const f32x16& x, f32x16 acc) {
+    if constexpr (BF) {
+        static_assert(NSTEPS % 8 == 0, "whole groups");
+        const int g0 = bf_grp_fwd(rec);
 #pragma unroll
-    for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(lds[(rec + r) * 64 + lane], x[r], acc);
+        for (int g = 0; g < NSTEPS / 8; ++g) {
+            const bf16x8 w = *(const bf16x8*)(lds + bf_fwd_off(g0 + g) + lane * 4);
+            acc = NF_MFMA_BF(w, pack_bf8(x[8 * g], x[8 * g + 1], x[8 * g + 2], x[8 * g + 3], x[8 * g + 4], x[8 * g + 5],
+                                         x[8 * g + 6], x[8 * g + 7]), acc);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(lds[(rec + r) * 64 + lane], x[r], acc);
+    }
+    return acc;
+}
+
+// the same for N <= 8 loose per-lane values (inputs that are not a fragment: ray_diff, colour statistics)
+template <bool BF, int N>
+__device__ __forceinline__ f32x16 gemm_small(const float* lds, int rec, int lane, const float (&v)[N], f32x16 acc) {
+    if constexpr (BF) {
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = j < N ? v[j] : 0.f;
+        const bf16x8 w = *(const bf16x8*)(lds + bf_fwd_off(bf_grp_fwd(rec)) + lane * 4);
+        acc = NF_MFMA_BF(w, pack_bf8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]), acc);
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc = NF_MFMA(lds[(rec + j) * 64 + lane], v[j], acc);
+    }
     return acc;
 }
 
@@ -362,17 +493,36 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rgb_feat, con
     in.mk = mask[row];
 }
 
-template <int V>
+// base_fc.0 (105 -> 64), output tile NT: the [mean | var | f] feature blocks of 32 inputs and their 3 colour inputs each
+template <bool BF, int NT>
+__device__ __forceinline__ f32x16 base0_tile(const float* lds, int lane, int h, const RowActs& a) {
+    constexpr int rec = MR_BASE0 + NT * 54;
+    f32x16 acc = bias_tile(lds, BT_BASE0A + NT, h);
+    acc = gemm_frag<BF, 16>(lds, rec, lane, a.MEAN, acc);
+    const float m2[2] = {h ? a.mc[1] : a.mc[0], h ? 0.f : a.mc[2]};
+    acc = gemm_small<BF, 2>(lds, rec + 16, lane, m2, acc);
+    acc = gemm_frag<BF, 16>(lds, rec + 18, lane, a.VAR, acc);
+    const float v2[2] = {h ? a.vc[1] : a.vc[0], h ? 0.f : a.vc[2]};
+    acc = gemm_small<BF, 2>(lds, rec + 34, lane, v2, acc);
+    acc = gemm_frag<BF, 16>(lds, rec + 36, lane, a.F, acc);
+    const float f2[2] = {h ? a.fc[1] : a.fc[0], h ? 0.f : a.fc[2]};
+    acc = gemm_small<BF, 2>(lds, rec + 52, lane, f2, acc);
+    return acc;
+}
+
+template <int V, bool BF>
 __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, int aa, const RowIn& in, RowActs& a) {
     const float s_abs = lds[MS_RGB2 + 9];
     // ---- direction MLP 4 -> 16 -> 35, f = rgb_feat + dir_feat   (mlp_network.py:231-233)
     f32x16 d1 = bias_tile(lds, BT_DIR0, h);
-    d1 = NF_MFMA(lds[(MR_DIR0 + 0) * 64 + lane], h ? in.rd[1] : in.rd[0], d1);
-    d1 = NF_MFMA(lds[(MR_DIR0 + 1) * 64 + lane], h ? in.rd[3] : in.rd[2], d1);
+    {
+        const float v2[2] = {h ? in.rd[1] : in.rd[0], h ? in.rd[3] : in.rd[2]};
+        d1 = gemm_small<BF, 2>(lds, MR_DIR0, lane, v2, d1);
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) d1[r] = mf_elu(d1[r]);
     {
-        f32x16 df = gemm_frag<8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h));
+        f32x16 df = gemm_frag<BF, 8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h));
 #pragma unroll
         for (int r = 0; r < 16; ++r) a.F[r] = in.feat[r] + mf_elu(df[r]);
     }
@@ -410,25 +560,12 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
         a.vc[c] = grp_sum<V>(w * (d * d));
     }
     // ---- base_fc.0 (105 -> 64) as two 32-output tiles, base_fc.2 (64 -> 32)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        int rec = MR_BASE0 + nt * 54;
-        f32x16 acc = bias_tile(lds, BT_BASE0A + nt, h);
-        acc = gemm_frag<16>(lds, rec, lane, a.MEAN, acc);
-        acc = NF_MFMA(lds[(rec + 16) * 64 + lane], h ? a.mc[1] : a.mc[0], acc);
-        acc = NF_MFMA(lds[(rec + 17) * 64 + lane], h ? 0.f : a.mc[2], acc);
-        acc = gemm_frag<16>(lds, rec + 18, lane, a.VAR, acc);
-        acc = NF_MFMA(lds[(rec + 34) * 64 + lane], h ? a.vc[1] : a.vc[0], acc);
-        acc = NF_MFMA(lds[(rec + 35) * 64 + lane], h ? 0.f : a.vc[2], acc);
-        acc = gemm_frag<16>(lds, rec + 36, lane, a.F, acc);
-        acc = NF_MFMA(lds[(rec + 52) * 64 + lane], h ? a.fc[1] : a.fc[0], acc);
-        acc = NF_MFMA(lds[(rec + 53) * 64 + lane], h ? 0.f : a.fc[2], acc);
-        if (nt == 0) a.H1a = elu16(acc); else a.H1b = elu16(acc);
-    }
+    a.H1a = elu16(base0_tile<BF, 0>(lds, lane, h, a));
+    a.H1b = elu16(base0_tile<BF, 1>(lds, lane, h, a));
     {
         f32x16 acc = bias_tile(lds, BT_BASE1, h);
-        acc = gemm_frag<16>(lds, MR_BASE1, lane, a.H1a, acc);
-        acc = gemm_frag<16>(lds, MR_BASE1 + 16, lane, a.H1b, acc);
+        acc = gemm_frag<BF, 16>(lds, MR_BASE1, lane, a.H1a, acc);
+        acc = gemm_frag<BF, 16>(lds, MR_BASE1 + 16, lane, a.H1b, acc);
         a.H = elu16(acc);
     }
     // ---- vis_fc on h * w, residual; vis_fc2 on x2 * vis1   (:249-254)
@@ -436,8 +573,8 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = a.H[r] * w;
-        a.V1 = elu16(gemm_frag<16>(lds, MR_VIS0, lane, t, bias_tile(lds, BT_VIS0, h)));
-        a.XV = elu16(gemm_frag<16>(lds, MR_VIS1, lane, a.V1, bias_tile(lds, BT_VIS1, h)));
+        a.V1 = elu16(gemm_frag<BF, 16>(lds, MR_VIS0, lane, t, bias_tile(lds, BT_VIS0, h)));
+        a.XV = elu16(gemm_frag<BF, 16>(lds, MR_VIS1, lane, a.V1, bias_tile(lds, BT_VIS1, h)));
         a.logit = mf_elu(dot_frag16(lds + MS_VIS1L + h * 16, a.V1) + lds[MS_VIS1L + 32]);
         a.sig1 = mf_sigmoid(a.logit);
         a.vis1 = a.sig1 * in.mk;
@@ -446,7 +583,7 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
             a.X2[r] = a.H[r] + a.XV[r];
             t[r] = a.X2[r] * a.vis1;
         }
-        a.U = elu16(gemm_frag<16>(lds, MR_VISB0, lane, t, bias_tile(lds, BT_VISB0, h)));
+        a.U = elu16(gemm_frag<BF, 16>(lds, MR_VISB0, lane, t, bias_tile(lds, BT_VISB0, h)));
         float z2 = dot_frag16(lds + MS_VISB1 + h * 16, a.U) + lds[MS_VISB1 + 32];
         a.sig2 = mf_sigmoid(z2);
         a.vis2 = a.sig2 * in.mk;
@@ -466,10 +603,9 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
     // ---- colour head: rgb_fc 37 -> 16 -> 8 -> 1, softmax over views, blend of the clean colours  (:268-273)
     float y;
     {
-        f32x16 acc = gemm_frag<16>(lds, MR_RGB0, lane, a.X2, bias_tile(lds, BT_RGB0, h));
-        acc = NF_MFMA(lds[(MR_RGB0 + 16) * 64 + lane], h ? in.rd[0] : a.vis2, acc);
-        acc = NF_MFMA(lds[(MR_RGB0 + 17) * 64 + lane], h ? in.rd[2] : in.rd[1], acc);
-        acc = NF_MFMA(lds[(MR_RGB0 + 18) * 64 + lane], h ? 0.f : in.rd[3], acc);
+        f32x16 acc = gemm_frag<BF, 16>(lds, MR_RGB0, lane, a.X2, bias_tile(lds, BT_RGB0, h));
+        const float v3[3] = {h ? in.rd[0] : a.vis2, h ? in.rd[2] : in.rd[1], h ? 0.f : in.rd[3]};
+        acc = gemm_small<BF, 3>(lds, MR_RGB0 + 16, lane, v3, acc);
 #pragma unroll
         for (int r = 0; r < 8; ++r) a.r1[r] = mf_elu(acc[r]);
         y = lds[MS_RGB2 + 8];
@@ -490,12 +626,13 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
     for (int c = 0; c < 3; ++c) a.rgb[c] = grp_sum<V>(a.beta * in.c[c]);
 }
 
-template <int V>
+template <int V, bool BF>
 __global__ void __launch_bounds__(64 * NF_ROWS_FWD_WAVES, NF_ROWS_FWD_OCC) k_ibr_rows_fwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                          int64_t n_samples, int aa, float* __restrict__ smp) {
     HIP_DYNAMIC_SHARED(float, lds)
-    for (int i = threadIdx.x; i < NF_MFMA_FWD_FLOATS; i += blockDim.x) lds[i] = wblob[i];
+    static_assert(NF_BF_FWD_FLOATS == NF_MFMA_FWD_FLOATS, "both forward images are MS_END floats");
+    for (int i = threadIdx.x; i < NF_MFMA_FWD_FLOATS; i += blockDim.x) lds[i] = wblob[i];      // BF: wblob is the bf16 image
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
@@ -512,7 +649,7 @@ __global__ void __launch_bounds__(64 * NF_ROWS_FWD_WAVES, NF_ROWS_FWD_OCC) k_ibr
         RowIn in;
         load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
         RowActs a;
-        rows_forward<V>(lds, lane, h, aa, in, a);
+        rows_forward<V, BF>(lds, lane, h, aa, in, a);
         // per-sample record; the lane holding view 0 writes (both lane halves, 16 features each)
         float* out = smp + sample * NF_SMP_STRIDE;
         if (live && v == 0) {
@@ -546,16 +683,27 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-template <int NSTEPS>
+template <bool BF, int NSTEPS>
 __device__ __forceinline__ f32x16 gemm_frag_T(const float* lds, int rec, int lane, const f32x16& dy, f32x16 acc) {
-    const float* base = lds + MT_BASE;
+    if constexpr (BF) {
+        static_assert(NSTEPS % 8 == 0, "whole groups");
+        const int g0 = bf_grp_bwd(rec);
 #pragma unroll
-    for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(base[(rec + r) * 64 + lane], dy[r], acc);
+        for (int g = 0; g < NSTEPS / 8; ++g) {
+            const bf16x8 w = *(const bf16x8*)(lds + bf_bwd_off(g0 + g) + lane * 4);
+            acc = NF_MFMA_BF(w, pack_bf8(dy[8 * g], dy[8 * g + 1], dy[8 * g + 2], dy[8 * g + 3], dy[8 * g + 4], dy[8 * g + 5],
+                                         dy[8 * g + 6], dy[8 * g + 7]), acc);
+        }
+    } else {
+        const float* base = lds + MT_BASE;
+#pragma unroll
+        for (int r = 0; r < NSTEPS; ++r) acc = NF_MFMA(base[(rec + r) * 64 + lane], dy[r], acc);
+    }
     return acc;
 }
 
 // d_feat[r] = d rgb_feat[row][3 + n(r,h)], d_col[c] = d rgb_feat[row][c]
-template <int V>
+template <int V, bool BF>
 __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h, const RowIn& in, const RowActs& a,
                                               const f32x16& d_mean2, const f32x16& d_var2, float d_wmean,
                                               const float (&d_rgb)[3], f32x16& d_feat, float (&d_col)[3]) {
@@ -577,7 +725,7 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
             for (int j = 0; j < 8; ++j) t = fmaf(lds[MS_RGB1 + j * 16 + h * 8 + r], d_r2[j], t);
             d_r1[r] = t * mf_elu_grad(a.r1[r]);
         }
-        d_x2 = gemm_frag_T<8>(lds, MT_RGB0, lane, d_r1, zero16());
+        d_x2 = gemm_frag_T<BF, 8>(lds, MT_RGB0, lane, d_r1, zero16());
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) t = fmaf(lds[MS_RGB0V + h * 8 + r], d_r1[r], t);
@@ -606,7 +754,7 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
         f32x16 d_u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d_u[r] = lds[MS_VISB1 + h * 16 + r] * d_z2 * mf_elu_grad(a.U[r]);
-        f32x16 d_xvis = gemm_frag_T<16>(lds, MT_VISB0, lane, d_u, zero16());
+        f32x16 d_xvis = gemm_frag_T<BF, 16>(lds, MT_VISB0, lane, d_u, zero16());
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -622,28 +770,28 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
         f32x16 d_xv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d_xv[r] = d_x2[r] * mf_elu_grad(a.XV[r]);
-        f32x16 d_v1 = gemm_frag_T<16>(lds, MT_VIS1, lane, d_xv, zero16());
+        f32x16 d_v1 = gemm_frag_T<BF, 16>(lds, MT_VIS1, lane, d_xv, zero16());
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             d_v1[r] = fmaf(lds[MS_VIS1L + h * 16 + r], d_logit, d_v1[r]) * mf_elu_grad(a.V1[r]);
-        f32x16 d_t = gemm_frag_T<16>(lds, MT_VIS0, lane, d_v1, zero16());
+        f32x16 d_t = gemm_frag_T<BF, 16>(lds, MT_VIS0, lane, d_v1, zero16());
 #pragma unroll
         for (int r = 0; r < 16; ++r) d_h[r] = (d_x2[r] + d_t[r] * a.w) * mf_elu_grad(a.H[r]);
     }
     // ---- base_fc (32 <- 64 <- 105)
     f32x16 g_mean, g_var, g_f, g_col;
     {
-        f32x16 d_h1a = gemm_frag_T<16>(lds, MT_BASE1, lane, d_h, zero16());
-        f32x16 d_h1b = gemm_frag_T<16>(lds, MT_BASE1 + 16, lane, d_h, zero16());
+        f32x16 d_h1a = gemm_frag_T<BF, 16>(lds, MT_BASE1, lane, d_h, zero16());
+        f32x16 d_h1b = gemm_frag_T<BF, 16>(lds, MT_BASE1 + 16, lane, d_h, zero16());
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             d_h1a[r] *= mf_elu_grad(a.H1a[r]);
             d_h1b[r] *= mf_elu_grad(a.H1b[r]);
         }
-        g_mean = gemm_frag_T<16>(lds, MT_BASE0 + 16, lane, d_h1b, gemm_frag_T<16>(lds, MT_BASE0, lane, d_h1a, zero16()));
-        g_var = gemm_frag_T<16>(lds, MT_BASE0 + 48, lane, d_h1b, gemm_frag_T<16>(lds, MT_BASE0 + 32, lane, d_h1a, zero16()));
-        g_f = gemm_frag_T<16>(lds, MT_BASE0 + 80, lane, d_h1b, gemm_frag_T<16>(lds, MT_BASE0 + 64, lane, d_h1a, zero16()));
-        g_col = gemm_frag_T<16>(lds, MT_BASE0 + 112, lane, d_h1b, gemm_frag_T<16>(lds, MT_BASE0 + 96, lane, d_h1a, zero16()));
+        g_mean = gemm_frag_T<BF, 16>(lds, MT_BASE0 + 16, lane, d_h1b, gemm_frag_T<BF, 16>(lds, MT_BASE0, lane, d_h1a, zero16()));
+        g_var = gemm_frag_T<BF, 16>(lds, MT_BASE0 + 48, lane, d_h1b, gemm_frag_T<BF, 16>(lds, MT_BASE0 + 32, lane, d_h1a, zero16()));
+        g_f = gemm_frag_T<BF, 16>(lds, MT_BASE0 + 80, lane, d_h1b, gemm_frag_T<BF, 16>(lds, MT_BASE0 + 64, lane, d_h1a, zero16()));
+        g_col = gemm_frag_T<BF, 16>(lds, MT_BASE0 + 112, lane, d_h1b, gemm_frag_T<BF, 16>(lds, MT_BASE0 + 96, lane, d_h1a, zero16()));
     }
     // ---- first pooling (the weights w are constants): feature channels
 #pragma unroll
@@ -677,13 +825,13 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
     }
 }
 
-template <int V>
-__global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, NF_ROWS_BWD_OCC) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
+template <int V, bool BF>
+__global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_OCC) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                          const float* __restrict__ d_smp, int64_t n_samples, int aa,
                                                          float* __restrict__ d_rgb_feat) {
     HIP_DYNAMIC_SHARED(float, lds)
-    for (int i = threadIdx.x; i < NF_ROWS_BLOB_FLOATS; i += blockDim.x) lds[i] = wblob[i];
+    for (int i = threadIdx.x; i < (BF ? (int)NF_BF_BLOB_FLOATS : (int)NF_ROWS_BLOB_FLOATS); i += blockDim.x) lds[i] = wblob[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
@@ -698,7 +846,7 @@ __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, NF_ROWS_BWD_OCC) k_ibr
         RowIn in;
         load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
         RowActs a;
-        rows_forward<V>(lds, lane, h, aa, in, a);
+        rows_forward<V, BF>(lds, lane, h, aa, in, a);
         const float* g = d_smp + sample * NF_SMP_STRIDE;
         f32x16 d_mean2, d_var2;
 #pragma unroll
@@ -709,7 +857,7 @@ __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, NF_ROWS_BWD_OCC) k_ibr
         float d_rgb[3] = {g[65], g[66], g[67]};
         f32x16 d_feat;
         float d_col[3];
-        rows_backward<V>(lds, lane, h, in, a, d_mean2, d_var2, g[64], d_rgb, d_feat, d_col);
+        rows_backward<V, BF>(lds, lane, h, in, a, d_mean2, d_var2, g[64], d_rgb, d_feat, d_col);
         if (live) {
             float* o = d_rgb_feat + row * 35;
 #pragma unroll
@@ -1231,14 +1379,14 @@ __device__ __forceinline__ float ray_forward_b(const float* rs, int lane, int h,
     return a.nval < 1.f ? 0.f : sigma;
 }
 
-template <int WPR>      // waves (32-sample tiles) per ray: S = 32 * WPR
-__global__ void __launch_bounds__(256, 2) k_ibr_ray_fwd_mfma(const float* __restrict__ wblob, const float* __restrict__ pos_enc,
+template <int WPR>      // waves (32-sample tiles) per ray: S = 32 * WPR; workgroup = max(4, WPR) waves
+__global__ void __launch_bounds__(WPR > 4 ? 64 * WPR : 256, 2) k_ibr_ray_fwd_mfma(const float* __restrict__ wblob, const float* __restrict__ pos_enc,
                                                              const float* __restrict__ smp, int64_t n_rays,
                                                              float* __restrict__ raw) {
     HIP_DYNAMIC_SHARED(float, lds)
-    constexpr int S = 32 * WPR, RPI = 4 / WPR;           // rays per workgroup iteration
+    constexpr int S = 32 * WPR, NW = WPR > 4 ? WPR : 4, RPI = NW / WPR;      // rays per workgroup iteration
     float* rs = lds;                                      // [0, RYF_FLOATS): forward part of the ray section
-    float* kv = lds + RYF_FLOATS;                         // 4 waves x 32 samples x (16 K + 16 V)
+    float* kv = lds + RYF_FLOATS;                         // NW waves x 32 samples x (16 K + 16 V)
     for (int i = threadIdx.x; i < RYF_FLOATS; i += blockDim.x) rs[i] = wblob[RY_BASE + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1289,11 +1437,11 @@ __device__ __forceinline__ f32x16 ray_gemm8_T(const float* rs, int rec, int lane
 #define RAY_BWD_LDS_PER_SAMPLE (4 * 16 + 3 * 4)
 
 template <int WPR>
-__global__ void __launch_bounds__(256, 1) k_ibr_ray_bwd_mfma(const float* __restrict__ wblob, const float* __restrict__ pos_enc,
+__global__ void __launch_bounds__(WPR > 4 ? 64 * WPR : 256, WPR > 4 ? 2 : 1) k_ibr_ray_bwd_mfma(const float* __restrict__ wblob, const float* __restrict__ pos_enc,
                                                              const float* __restrict__ smp, const float* __restrict__ d_raw,
                                                              int64_t n_rays, float* __restrict__ d_smp) {
     HIP_DYNAMIC_SHARED(float, lds)
-    constexpr int S = 32 * WPR, RPI = 4 / WPR;
+    constexpr int S = 32 * WPR, NW = WPR > 4 ? WPR : 4, RPI = NW / WPR;
     float* rs = lds;
     float* ray_lds = lds + RY_FLOATS;
     for (int i = threadIdx.x; i < RY_FLOATS; i += blockDim.x) rs[i] = wblob[RY_BASE + i];
@@ -1454,43 +1602,58 @@ extern "C" int64_t nf_ibrnet_mfma_workspace_floats(int64_t n_rays, int n_samples
 }
 
 template <int V>
-static void launch_rows_fwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
+static void launch_rows_fwd(const float* wblob, const float* bf_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
                             int64_t n_samples, int aa, float* smp, hipStream_t st) {
     int64_t tiles = (n_samples * V + 31) / 32;
     int64_t blocks = (tiles + NF_ROWS_FWD_WAVES - 1) / NF_ROWS_FWD_WAVES;
     if (blocks > 1024) blocks = 1024;     // persistent-ish: 2 workgroups per CU hold the 58 KB weight image each
-    hipLaunchKernelGGL(k_ibr_rows_fwd<V>, dim3((unsigned)blocks), dim3(64 * NF_ROWS_FWD_WAVES), NF_MFMA_FWD_FLOATS * sizeof(float), st, wblob,
-                       rgb_feat, ray_diff, mask, n_samples, aa, smp);
+    if (bf_blob)
+        hipLaunchKernelGGL((k_ibr_rows_fwd<V, true>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_FWD_WAVES), NF_BF_FWD_FLOATS * sizeof(float), st,
+                           bf_blob, rgb_feat, ray_diff, mask, n_samples, aa, smp);
+    else
+        hipLaunchKernelGGL((k_ibr_rows_fwd<V, false>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_FWD_WAVES), NF_MFMA_FWD_FLOATS * sizeof(float), st,
+                           wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp);
 }
 
-extern "C" int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
-                                  const float* ray_diff, const float* mask, int64_t n_rays, int n_samples, int n_views,
-                                  int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream) {
-    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "nf_ibrnet_fwd_mfma: V must be a power of two <= 32 (got %d)",
-               n_views);
+static int ibrnet_fwd_impl(const char* who, const float* bf_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
+                           const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_rays, int n_samples, int n_views,
+                           int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream) {
+    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: V must be a power of two <= 32 (got %d)", who, n_views);
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int64_t ns = n_rays * n_samples;
     switch (n_views) {
-        case 1: launch_rows_fwd<1>(mfma_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        case 2: launch_rows_fwd<2>(mfma_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        case 4: launch_rows_fwd<4>(mfma_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        case 8: launch_rows_fwd<8>(mfma_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        case 16: launch_rows_fwd<16>(mfma_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        default: launch_rows_fwd<32>(mfma_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
+        case 1: launch_rows_fwd<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
+        case 2: launch_rows_fwd<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
+        case 4: launch_rows_fwd<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
+        case 8: launch_rows_fwd<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
+        case 16: launch_rows_fwd<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
+        default: launch_rows_fwd<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
     }
     NF_LAUNCH_CHECK("nf_ibrnet_fwd_mfma (rows)");
-    if (n_samples == 32 || n_samples == 64 || n_samples == 128) {       // per-ray part on the matrix cores as well
-        const int wpr = n_samples / 32, rpi = 4 / wpr;
+    if (n_samples == 32 || n_samples == 64 || n_samples == 128 || n_samples == 256) {       // per-ray part on the matrix cores as well
+        const int wpr = n_samples / 32, nw = wpr > 4 ? wpr : 4, rpi = nw / wpr;
         int64_t iters = (n_rays + rpi - 1) / rpi;
         unsigned blocks = (unsigned)(iters < 512 ? iters : 512);
-        size_t smem_ray = (size_t)(RYF_FLOATS + 4 * 32 * 32) * sizeof(float);
+        size_t smem_ray = (size_t)(RYF_FLOATS + nw * 32 * 32) * sizeof(float);
         if (wpr == 1)
             hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<1>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);
         else if (wpr == 2)
             hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<2>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);
-        else
+        else if (wpr == 4)
             hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<4>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);
+        else {
+            static bool configured_on[NF_MAX_DEVICES] = {};
+            bool& configured = configured_on[nf_current_device()];
+            if (!configured) {
+                if (hipFuncSetAttribute((const void*)k_ibr_ray_fwd_mfma<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ray) != hipSuccess) {
+                    nf_set_error("%s: cannot reserve %zu bytes of LDS", who, smem_ray);
+                    return 1;
+                }
+                configured = true;
+            }
+            hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<8>, dim3(blocks), dim3(512), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);
+        }
         NF_LAUNCH_CHECK("nf_ibrnet_fwd_mfma (ray, mfma)");
         return 0;
     }
@@ -1506,14 +1669,31 @@ extern "C" int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, con
     return 0;
 }
 
-template <int V>
+extern "C" int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
+                                  const float* ray_diff, const float* mask, int64_t n_rays, int n_samples, int n_views,
+                                  int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream) {
+    return ibrnet_fwd_impl("nf_ibrnet_fwd_mfma", nullptr, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, n_rays, n_samples, n_views,
+                           anti_alias_pooling, raw, workspace, stream);
+}
+
+/* bf16_blob: device copy of nf_ibrnet_pack_mfma_bf16's output; the per-(sample, view) row network runs on bf16 operands with
+ * fp32 accumulation, everything else as nf_ibrnet_fwd_mfma */
+extern "C" int nf_ibrnet_fwd_mfma_bf16(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
+                                       const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_rays, int n_samples,
+                                       int n_views, int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream) {
+    NF_REQUIRE(bf16_blob != nullptr, "nf_ibrnet_fwd_mfma_bf16: bf16 blob missing");
+    return ibrnet_fwd_impl("nf_ibrnet_fwd_mfma_bf16", bf16_blob, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, n_rays, n_samples,
+                           n_views, anti_alias_pooling, raw, workspace, stream);
+}
+
+template <int V, bool BF>
 static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
                            const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, hipStream_t st) {
     static bool configured_on[NF_MAX_DEVICES] = {};      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel and device
     bool& configured = configured_on[nf_current_device()];
-    const size_t smem = NF_ROWS_BLOB_FLOATS * sizeof(float);
+    const size_t smem = (BF ? (size_t)NF_BF_BLOB_FLOATS : (size_t)NF_ROWS_BLOB_FLOATS) * sizeof(float);
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
             hipSuccess) {
             nf_set_error("nf_ibrnet_bwd_mfma: cannot reserve %zu bytes of LDS", smem);
             return 1;
@@ -1522,9 +1702,82 @@ static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const floa
     }
     int64_t tiles = (n_samples * V + 31) / 32;
     int64_t blocks = (tiles + NF_ROWS_BWD_WAVES - 1) / NF_ROWS_BWD_WAVES;
-    if (blocks > 512) blocks = 512;        // one workgroup per CU holds the 113 KB weight image (fwd + transposed)
-    hipLaunchKernelGGL(k_ibr_rows_bwd<V>, dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask, d_smp,
-                       n_samples, aa, d_rgb_feat);
+    // fp32: one workgroup per CU holds the 113 KB weight image (fwd + transposed); bf16: 64 KB, two per CU
+    const int64_t cap = BF ? 1024 : 512;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask,
+                       d_smp, n_samples, aa, d_rgb_feat);
+    return 0;
+}
+
+template <int V>
+static int launch_rows_bwd_any(const float* wblob, const float* bf_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
+                               const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, hipStream_t st) {
+    return bf_blob ? launch_rows_bwd<V, true>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, st)
+                   : launch_rows_bwd<V, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, st);
+}
+
+template <int WPR>
+static int launch_ray_bwd(const float* mfma_blob, const float* pos_enc, const float* smp, const float* d_raw, int64_t n_rays,
+                          float* d_workspace, hipStream_t st) {
+    constexpr int nw = WPR > 4 ? WPR : 4, rpi = nw / WPR;
+    int64_t iters = (n_rays + rpi - 1) / rpi;
+    unsigned blocks = (unsigned)(iters < 256 ? iters : 256);
+    size_t smem_ray = (size_t)(RY_FLOATS + nw * 32 * RAY_BWD_LDS_PER_SAMPLE) * sizeof(float);
+    static bool configured_on[NF_MAX_DEVICES] = {};
+    bool& configured = configured_on[nf_current_device()];
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)k_ibr_ray_bwd_mfma<WPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ray) != hipSuccess) {
+            nf_set_error("nf_ibrnet_bwd_mfma: cannot reserve %zu bytes of LDS", smem_ray);
+            return 1;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_ibr_ray_bwd_mfma<WPR>, dim3(blocks), dim3(64 * nw), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
+    return 0;
+}
+
+static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
+                           const float* rgb_feat, const float* ray_diff, const float* mask, const float* smp, const float* d_raw,
+                           int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat,
+                           float* d_workspace, nf_stream_t stream) {
+    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: V must be a power of two <= 32 (got %d)", who, n_views);
+    if (n_rays == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int threads = ((n_samples + 63) / 64) * 64;
+    size_t smem = (size_t)n_samples * 77 * sizeof(float);
+    const bool ray_mfma = n_samples == 32 || n_samples == 64 || n_samples == 128 || n_samples == 256;
+    if (ray_mfma) {
+        int rc;
+        switch (n_samples / 32) {
+            case 1: rc = launch_ray_bwd<1>(mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace, st); break;
+            case 2: rc = launch_ray_bwd<2>(mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace, st); break;
+            case 4: rc = launch_ray_bwd<4>(mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace, st); break;
+            default: rc = launch_ray_bwd<8>(mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace, st); break;
+        }
+        if (rc) return rc;
+    } else {
+        NF_REQUIRE(smem <= 64 * 1024, "%s: S=%d exceeds the LDS budget of the ray kernel", who, n_samples);
+        if (threads <= 256)
+            hipLaunchKernelGGL(k_ibr_ray_bwd<256>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc, smp, d_raw,
+                               n_samples, d_workspace);
+        else
+            hipLaunchKernelGGL(k_ibr_ray_bwd<NF_IBR_MAX_S>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc, smp,
+                               d_raw, n_samples, d_workspace);
+    }
+    NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (ray)");
+    int64_t ns = n_rays * n_samples;
+    int rc;
+    switch (n_views) {
+        case 1: rc = launch_rows_bwd_any<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 2: rc = launch_rows_bwd_any<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 4: rc = launch_rows_bwd_any<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 8: rc = launch_rows_bwd_any<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 16: rc = launch_rows_bwd_any<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        default: rc = launch_rows_bwd_any<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+    }
+    if (rc) return rc;
+    NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (rows)");
     return 0;
 }
 
@@ -1533,59 +1786,17 @@ extern "C" int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, con
                                   const float* ray_diff, const float* mask, const float* smp, const float* d_raw,
                                   int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat,
                                   float* d_workspace, nf_stream_t stream) {
-    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "nf_ibrnet_bwd_mfma: V must be a power of two <= 32 (got %d)",
-               n_views);
-    if (n_rays == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    int threads = ((n_samples + 63) / 64) * 64;
-    size_t smem = (size_t)n_samples * 77 * sizeof(float);
-    const bool ray_mfma = n_samples == 32 || n_samples == 64 || n_samples == 128;
-    if (ray_mfma) {
-        const int wpr = n_samples / 32, rpi = 4 / wpr;
-        int64_t iters = (n_rays + rpi - 1) / rpi;
-        unsigned blocks = (unsigned)(iters < 256 ? iters : 256);
-        size_t smem_ray = (size_t)(RY_FLOATS + 4 * 32 * RAY_BWD_LDS_PER_SAMPLE) * sizeof(float);
-        static bool configured_on[NF_MAX_DEVICES][3] = {};
-        bool* configured = configured_on[nf_current_device()];
-        const void* fn = wpr == 1 ? (const void*)k_ibr_ray_bwd_mfma<1> : (wpr == 2 ? (const void*)k_ibr_ray_bwd_mfma<2>
-                                                                                   : (const void*)k_ibr_ray_bwd_mfma<4>);
-        int slot = wpr == 1 ? 0 : (wpr == 2 ? 1 : 2);
-        if (!configured[slot]) {
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ray) != hipSuccess) {
-                nf_set_error("nf_ibrnet_bwd_mfma: cannot reserve %zu bytes of LDS", smem_ray);
-                return 1;
-            }
-            configured[slot] = true;
-        }
-        if (wpr == 1)
-            hipLaunchKernelGGL(k_ibr_ray_bwd_mfma<1>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
-        else if (wpr == 2)
-            hipLaunchKernelGGL(k_ibr_ray_bwd_mfma<2>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
-        else
-            hipLaunchKernelGGL(k_ibr_ray_bwd_mfma<4>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
-    } else {
-    NF_REQUIRE(smem <= 64 * 1024, "nf_ibrnet_bwd_mfma: S=%d exceeds the LDS budget of the ray kernel", n_samples);
-    if (threads <= 256)
-        hipLaunchKernelGGL(k_ibr_ray_bwd<256>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc, smp, d_raw,
-                           n_samples, d_workspace);
-    else
-        hipLaunchKernelGGL(k_ibr_ray_bwd<NF_IBR_MAX_S>, dim3((unsigned)n_rays), dim3(threads), smem, st, blob, pos_enc, smp,
-                           d_raw, n_samples, d_workspace);
-    }
-    NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (ray)");
-    int64_t ns = n_rays * n_samples;
-    int rc;
-    switch (n_views) {
-        case 1: rc = launch_rows_bwd<1>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        case 2: rc = launch_rows_bwd<2>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        case 4: rc = launch_rows_bwd<4>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        case 8: rc = launch_rows_bwd<8>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        case 16: rc = launch_rows_bwd<16>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        default: rc = launch_rows_bwd<32>(mfma_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-    }
-    if (rc) return rc;
-    NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (rows)");
-    return 0;
+    return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma", nullptr, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, n_rays, n_samples,
+                           n_views, anti_alias_pooling, d_rgb_feat, d_workspace, stream);
+}
+
+extern "C" int nf_ibrnet_bwd_mfma_bf16(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
+                                       const float* rgb_feat, const float* ray_diff, const float* mask, const float* smp,
+                                       const float* d_raw, int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling,
+                                       float* d_rgb_feat, float* d_workspace, nf_stream_t stream) {
+    NF_REQUIRE(bf16_blob != nullptr, "nf_ibrnet_bwd_mfma_bf16: bf16 blob missing");
+    return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma_bf16", bf16_blob, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, n_rays,
+                           n_samples, n_views, anti_alias_pooling, d_rgb_feat, d_workspace, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

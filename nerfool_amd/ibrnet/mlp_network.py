@@ -45,14 +45,22 @@ def sinusoid_table(n_samples, d_hid=16):
 KERNEL_PATH = os.environ.get('NERFOOL_IBRNET_KERNELS', 'auto')
 
 
+# 'fp32' (default: exact fp32 matrix-core arithmetic, the parity path) or 'bf16' (BASELINE config 5: bf16 operands with fp32
+# accumulation in the per-(sample, view) row network -- 16x the matrix rate, ~1e-2 accuracy; never chosen silently)
+PRECISION = os.environ.get('NERFOOL_IBRNET_PRECISION', 'fp32')
+
+
 class _IBRNetFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb_feat, ray_diff, mask, blob, mfma_blob, pos_enc, anti_alias):
+    def forward(ctx, rgb_feat, ray_diff, mask, blob, mfma_blob, pos_enc, anti_alias, bf16_blob=None):
         S, V = rgb_feat.shape[1], rgb_feat.shape[2]
         ctx.mfma = KERNEL_PATH != 'generic' and mfma_blob is not None and ops.ibrnet_mfma_supported(S, V)
+        if bf16_blob is not None and not ctx.mfma:
+            raise RuntimeError('the bf16 IBRNet path needs the matrix-core kernels (V a power of two <= 32; got V=%d)' % V)
+        ctx.bf16 = bf16_blob is not None
         if ctx.mfma:
-            raw, smp = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
-            ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp)
+            raw, smp = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias, bf16_blob=bf16_blob)
+            ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp, *((bf16_blob,) if ctx.bf16 else ()))
         else:
             raw = ops.ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
             ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc)
@@ -62,12 +70,13 @@ class _IBRNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_raw):
         if ctx.mfma:
-            rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp = ctx.saved_tensors
-            d_rgb_feat = ops.ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, ctx.anti_alias)
+            rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp = ctx.saved_tensors[:7]
+            d_rgb_feat = ops.ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, ctx.anti_alias,
+                                             bf16_blob=ctx.saved_tensors[7] if ctx.bf16 else None)
         else:
             rgb_feat, ray_diff, mask, blob, pos_enc = ctx.saved_tensors
             d_rgb_feat = ops.ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, ctx.anti_alias)
-        return d_rgb_feat, None, None, None, None, None, None
+        return d_rgb_feat, None, None, None, None, None, None, None
 
 
 class IBRNet(nn.Module):
@@ -96,14 +105,20 @@ class IBRNet(nn.Module):
                     nn.init.zeros_(m.bias.data)
         self._blob = None
         self._mfma_blob = None
+        self._bf16_blob = None
         self._blob_key = None
+        # args.ibrnet_precision ('fp32' | 'bf16') overrides the NERFOOL_IBRNET_PRECISION default for this network
+        self.precision = getattr(args, 'ibrnet_precision', None) or PRECISION
+        if self.precision not in ('fp32', 'bf16'):
+            raise ValueError("ibrnet_precision must be 'fp32' or 'bf16' (got %r)" % (self.precision,))
 
     def _packed(self, device):
         """Flat parameter blob in the kernels' layout, re-packed only when a parameter changed."""
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._blob is None or key != self._blob_key:
             self._blob = ops.pack_ibrnet_blob(self.state_dict(), device)
             self._mfma_blob = ops.pack_ibrnet_mfma_blob(self._blob)
+            self._bf16_blob = ops.pack_ibrnet_bf16_blob(self._mfma_blob) if self.precision == 'bf16' else None
             self._blob_key = key
         return self._blob, self._mfma_blob
 
@@ -116,4 +131,4 @@ class IBRNet(nn.Module):
         """
         blob, mfma_blob = self._packed(rgb_feat.device)
         return _IBRNetFunction.apply(rgb_feat, ray_diff, mask[..., 0], blob, mfma_blob, self.pos_encoding,
-                                     bool(self.anti_alias_pooling))
+                                     bool(self.anti_alias_pooling), self._bf16_blob if self.precision == 'bf16' else None)

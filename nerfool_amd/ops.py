@@ -158,11 +158,21 @@ def pack_ibrnet_mfma_blob(natural_blob):
     return out.to(natural_blob.device)
 
 
+def pack_ibrnet_bf16_blob(mfma_blob):
+    """MFMA-order fp32 blob -> bf16 group image of the row kernels (config 5), on the same device"""
+    L = _lib.lib()
+    src = mfma_blob.detach().to('cpu', torch.float32).contiguous()
+    out = torch.empty(L.nf_ibrnet_mfma_bf16_blob_floats(), dtype=torch.float32)
+    _lib.check(L.nf_ibrnet_pack_mfma_bf16(src.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma_bf16')
+    return out.to(mfma_blob.device)
+
+
 def ibrnet_mfma_supported(S, V):
     return bool(_lib.lib().nf_ibrnet_mfma_supported(int(S), int(V)))
 
 
-def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias):
+def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias, bf16_blob=None):
+    """bf16_blob: run the per-(sample, view) row network on bf16 matrix-core operands (fp32 accumulate)"""
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     R, S, V, F = rgb_feat.shape
     if F != 35:
@@ -173,19 +183,32 @@ def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_ali
     L = _lib.lib()
     ws = torch.empty(L.nf_ibrnet_mfma_workspace_floats(R, S), dtype=torch.float32, device=rgb_feat.device)
     raw = torch.empty(R, S, 4, dtype=torch.float32, device=rgb_feat.device)
+    if bf16_blob is not None:
+        with prof.launch('nf_ibrnet_fwd_mfma_bf16', raw, R=R, S=S, V=V):
+            _lib.check(L.nf_ibrnet_fwd_mfma_bf16(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff),
+                                                 _ptr(mask), R, S, V, int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)),
+                       'nf_ibrnet_fwd_mfma_bf16')
+        return raw, ws
     with prof.launch('nf_ibrnet_fwd_mfma', raw, R=R, S=S, V=V):
         _lib.check(L.nf_ibrnet_fwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S,
                                         V, int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd_mfma')
     return raw, ws
 
 
-def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias):
+def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias, bf16_blob=None):
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     d_raw = _c(d_raw, 'd_raw')
     R, S, V, _ = rgb_feat.shape
     pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
     d_ws = torch.empty_like(smp)
     d_rgb_feat = torch.empty_like(rgb_feat)
+    if bf16_blob is not None:
+        with prof.launch('nf_ibrnet_bwd_mfma_bf16', d_raw, R=R, S=S, V=V):
+            _lib.check(_lib.lib().nf_ibrnet_bwd_mfma_bf16(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat),
+                                                          _ptr(ray_diff), _ptr(mask), _ptr(smp), _ptr(d_raw), R, S, V,
+                                                          int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(d_ws), _stream(d_raw)),
+                       'nf_ibrnet_bwd_mfma_bf16')
+        return d_rgb_feat
     with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
         _lib.check(_lib.lib().nf_ibrnet_bwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
                                                  _ptr(smp), _ptr(d_raw), R, S, V, int(bool(anti_alias)), _ptr(d_rgb_feat),

@@ -66,9 +66,10 @@ def reset_pixel_rng():
 
 
 def stage_case(name, H, W, V, R, S, N_imp, inv_uniform, white_bkgd, seed, aa=1, tilt=0.0, push_forward=0.0,
-               Hf=None, Wf=None, store_stages=True):
+               Hf=None, Wf=None, store_stages=True, depth_range=None):
     torch.manual_seed(seed)
-    data = make_scene(H, W, V, seed=seed, tilt=tilt, push_forward=push_forward)
+    data = make_scene(H, W, V, seed=seed, tilt=tilt, push_forward=push_forward,
+                      **({} if depth_range is None else {'depth_range': depth_range}))
     Hf = Hf or max(6, H // 4)
     Wf = Wf or max(8, W // 4)
     fm_c = smooth_featmaps(V, 32, Hf, Wf, seed=seed).requires_grad_(True)

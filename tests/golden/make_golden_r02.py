@@ -9,6 +9,8 @@
                  views (adv_iters = 3, so 4 steps: the reference's `iters > adv_iters` test), Adam-ascent + StepLR + both
                  clamps: per step the pixel pick, loss, gradient and the perturbation after the step
 
+  ibrnet_c5_v8.npz  see the end of this file
+
     python tests/golden/make_golden_r02.py
 
 Data only; runs only in the build container."""
@@ -112,3 +114,9 @@ def main():
 
 if __name__ == '__main__':
     main()
+    # BASELINE config 5 shape (IBRNet DeepVoxels: 8 source views, 128 coarse + 128 importance samples, white background,
+    # depth range = origin depth +- 0.8, ibrnet/data_loaders/deepvoxels.py:134-143) at fixture size: the reference's fp32
+    # end-to-end capture (outputs, loss, d loss / d feature maps); pins the fp32 kernels at V = 8 / S = 128 + 256 to 1e-3 and
+    # is the yardstick the bf16 path's stated tolerance is measured on
+    mg.stage_case('ibrnet_c5_v8', 48, 48, 8, 24, 128, 128, True, True, seed=5, tilt=0.3, store_stages=False,
+                  depth_range=(3.2, 4.8))

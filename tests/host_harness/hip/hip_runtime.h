@@ -171,6 +171,24 @@ static inline nf_emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
     return d;
 }
 
+// D = A(32x16) * B(16x32) + C, bf16 operands, fp32 accumulation.  lane l (r = l&31, h = l>>5) holds A[row r][k = 8h + j] and
+// B[k = 8h + j][col r] in element j of its fragment; C/D as the 32x32x2 form (cdna_hip_programming.md section 3).
+typedef __bf16 nf_emu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline nf_emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(nf_emu_bf16x8 a, nf_emu_bf16x8 b, nf_emu_f32x16 c, int, int, int) {
+    float A[8][64], B[8][64];
+    for (int j = 0; j < 8; ++j) nf_emu_publish_ab((float)a[j], (float)b[j], A[j], B[j]);
+    nf_emu_f32x16 d = c;
+    int l = hip_emu::lane(), col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 8; ++j) acc = fmaf(A[j][row + 32 * h], B[j][col + 32 * h], acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
 // D = A(16x4) * B(4x16) + C.  lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; c[r] = C[row = 4*(l>>4) + r][col = l&15]
 static inline nf_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, nf_emu_f32x4 c, int, int, int) {
     float A[64], B[64];

@@ -7,11 +7,11 @@ import subprocess
 import pytest
 
 import parity_cases as pc
-from fixtures import STAGE_CASES
+from fixtures import END_TO_END_ONLY, STAGE_CASES
 
 HARNESS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'host_harness')
 CLANG = '/opt/rocm/lib/llvm/bin/clang++'
-TINY = [c for c in STAGE_CASES if c != 'ibrnet_medium']
+TINY = [c for c in STAGE_CASES if c not in END_TO_END_ONLY]
 
 
 @pytest.fixture(scope='module', autouse=True)

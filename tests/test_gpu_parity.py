@@ -5,10 +5,10 @@ import pytest
 import torch
 
 import parity_cases as pc
-from fixtures import STAGE_CASES
+from fixtures import END_TO_END_ONLY, STAGE_CASES
 
 pytestmark = pytest.mark.gpu
-TINY = [c for c in STAGE_CASES if c != 'ibrnet_medium']
+TINY = [c for c in STAGE_CASES if c not in END_TO_END_ONLY]
 
 
 @pytest.fixture(scope='module', autouse=True)
@@ -36,9 +36,13 @@ def test_gather_and_composite_backward(case):
     pc.check_gather_and_composite_backward(case, 'cuda')
 
 
-@pytest.mark.parametrize('case', STAGE_CASES)
+@pytest.mark.parametrize('case', STAGE_CASES + ['ibrnet_c5_v8'])
 def test_render_rays(case):
     pc.check_render_rays(case, 'cuda')
+
+
+def test_bf16_row_network_config5():
+    pc.check_bf16_config5('cuda')
 
 
 def test_ray_sampler():

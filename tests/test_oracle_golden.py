@@ -6,13 +6,13 @@ import numpy as np
 import pytest
 import torch
 
-from fixtures import Golden, STAGE_CASES, assert_close
+from fixtures import END_TO_END_ONLY, Golden, STAGE_CASES, assert_close
 from oracle import attack_ref as atk
 from oracle import feature_net_ref as fnet
 from oracle import ibrnet_ref as ib
 
 
-@pytest.mark.parametrize('case', [c for c in STAGE_CASES if c != 'ibrnet_medium'])
+@pytest.mark.parametrize('case', [c for c in STAGE_CASES if c not in END_TO_END_ONLY])
 def test_stages_match_reference(case):
     g = Golden(case)
     cfg = g.stage_cfg()
@@ -49,7 +49,7 @@ def test_manual_bilinear_equals_grid_sample():
     assert_close(mine, ref, 1e-4, 2e-5, 'manual bilinear')
 
 
-@pytest.mark.parametrize('case', STAGE_CASES)
+@pytest.mark.parametrize('case', STAGE_CASES + ['ibrnet_c5_v8'])
 def test_render_rays_loss_and_grads(case):
     g = Golden(case)
     cfg = g.stage_cfg()
