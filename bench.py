@@ -523,9 +523,9 @@ def main():
     if a.model == 'ibrnet':
         workload = ('BASELINE config %s: IBRNet view-specific attack, %s-shaped synthetic scene %dx%d, %d source views, %d+%d samples/ray, '
                     'N_rand=%d rays per %s per step, Adam lr 1e-3, eps 8/255%s'
-                    % (('5', 'DeepVoxels') if a.config == 'c5' else ('2', 'LLFF-fern')) + (a.height, a.width, V, Sc, a.importance, a.n_rand,
-                       'rank' if a.scaling == 'weak' else 'step (all ranks)',
-                       ', IBRNet row network on bf16 matrix-core operands' if a.precision == 'bf16' else ''))
+                    % ((('5', 'DeepVoxels') if a.config == 'c5' else ('2', 'LLFF-fern')) + (
+                        a.height, a.width, V, Sc, a.importance, a.n_rand, 'rank' if a.scaling == 'weak' else 'step (all ranks)',
+                        ', IBRNet row network on bf16 matrix-core operands' if a.precision == 'bf16' else '')))
     else:
         workload = ('BASELINE config 4: GNT depth %d view-specific attack, synthetic scene %dx%d, %d source views, %d samples/ray, '
                     'N_rand=%d rays per rank per step' % (a.depth, a.height, a.width, V, Sc, a.n_rand))

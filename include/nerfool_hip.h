@@ -198,6 +198,21 @@ int nf_conv1x1(const float* records, const float* bias, const float* x, int64_t 
                float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, int n_img, int H, int W, int c_in, int c_out,
                const float* x2, int c_split, nf_stream_t stream);
 
+/* The network's stride-2 convolutions -- the 7x7 stem and the first 3x3 convolution of layer1 / layer2 / layer3
+ * (ibrnet/feature_network.py:188, :192-195 via :51) -- on pre-padded activations (padding 0), forward and backward-data, as
+ * direct implicit-GEMM convolutions on the fp32 matrix cores (csrc/nf_conv_s2.hip; replaces MIOpen / rocBLAS + col2im).
+ *   records = nf_conv_s2_pack(weight [c_out][c_in][ks][ks], ks in {3, 7}, backward) (HOST pointers, nf_conv_s2_pack_floats floats)
+ *   forward:  y [N, c_out, Ho, Wo], Ho = (Hi - ks) / 2 + 1;  the 7x7 form takes c_in <= 3
+ *   backward: dx [N, c_in, Hi, Wi] from dy [N, c_out, Ho, Wo]; every element of dx is written (zeros where the convolution
+ *             never read the input)
+ * x / y / dx / dy: element strides (image, channel, row), unit column stride. */
+int64_t nf_conv_s2_pack_floats(int c_out, int c_in, int ks, int backward);
+int nf_conv_s2_pack(const float* weight_host, int c_out, int c_in, int ks, int backward, float* records_host);
+int nf_conv_s2_fwd(const float* records, int ks, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, float* y,
+                   int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out, nf_stream_t stream);
+int nf_conv_s2_bwd(const float* records, int ks, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int Ho, int Wo, float* dx,
+                   int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, int n_img, int c_in, int c_out, nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * a14  ResUNet 3x3 stride-1 convolutions as Winograd F(2x2, 3x3) on the fp32 matrix cores.
  *      ref: ibrnet/feature_network.py:28-36, 38-78, 127-151 (reflect padding is already in the input, see nf_in_act_pad_fwd).

@@ -68,6 +68,12 @@ _PROTOTYPES = {
     'nf_conv1x1_pack': (c_int, [_P, c_int, c_int, c_int, _P]),
     'nf_conv1x1': (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                            c_int, c_int, c_int, _P, c_int, _P]),
+    'nf_conv_s2_pack_floats': (c_int64, [c_int, c_int, c_int, c_int]),
+    'nf_conv_s2_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
+    'nf_conv_s2_fwd': (c_int, [_P, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                               c_int, c_int, _P]),
+    'nf_conv_s2_bwd': (c_int, [_P, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                               c_int, c_int, _P]),
     'nf_wino_pack_floats': (c_int64, [c_int, c_int, c_int]),
     'nf_wino_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
     'nf_conv3x3_wino': (c_int, [_P, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int,

@@ -1,5 +1,7 @@
-"""ResUNet feature extractor on PyTorch-ROCm (MIOpen convolutions) -- SURVEY a14: delegated to the vendor library in
-this round; the ray path behind it is the hand-written part.  Module paths equal those of ibrnet/feature_network.py
+"""ResUNet feature extractor as a fused executor over hand-written kernels: Winograd F(2x2,3x3) for the stride-1
+3x3 convolutions (csrc/nf_wino.hip), direct matrix-core convolutions for the four stride-2 ones (csrc/nf_conv_s2.hip), MFMA
+GEMMs for the 1x1 ones (csrc/nf_conv1x1.hip), fused InstanceNorm / activation / padding / upsampling glue (csrc/nf_cnn.hip).
+Module paths equal those of ibrnet/feature_network.py
 (conv1, bn1, layer{1,2,3}.N.{conv1,bn1,conv2,bn2,downsample.{0,1}}, upconv{3,2}.conv.{conv,bn}, iconv{3,2}.{conv,bn},
 out_conv) so that reference checkpoints load by key.
 
@@ -194,9 +196,11 @@ class _Act:
         self.gs = g if self.gs is None else self.gs + g
 
 
-# 3x3 stride-1 convolutions: 'auto' times MIOpen against the Winograd matrix-core kernel (csrc/nf_wino.hip) with 64 and with 32
-# output channels per workgroup, once per (shape, direction) on first use, and keeps the fastest; 'wino' / 'wino32' / 'miopen'
-# force a side (NERFOOL_CONV3X3)
+# 3x3 stride-1 convolutions: 'auto' times the Winograd matrix-core kernel (csrc/nf_wino.hip) with 64 and with 32 output
+# channels per workgroup, once per (shape, direction) on first use, and keeps the faster -- both forms compute every output
+# with the same arithmetic in the same order, so the choice does not change a single bit of the result; 'wino' / 'wino32'
+# force one, 'miopen' (NERFOOL_CONV3X3) runs the vendor library instead (comparison runs only: its small-plane kernels are
+# not run-to-run reproducible, tools/diag_determinism.py)
 CONV3X3 = os.environ.get('NERFOOL_CONV3X3', 'auto')
 _CONV_CHOICE = {}
 
@@ -220,6 +224,8 @@ def _pick(key, candidates, timed):
     """which implementation runs this convolution (candidates: name -> thunk): decided once per key"""
     if CONV3X3 in candidates:
         return CONV3X3
+    if len(candidates) == 1:
+        return next(iter(candidates))
     if not timed:                       # CPU stand-in build: no timing, the default Winograd form
         return 'wino'
     if key not in _CONV_CHOICE:
@@ -246,20 +252,49 @@ def _conv3x3(tape, inp, w, sink):
     """3x3 stride-1 convolution on a pre-padded activation (padding 0) and its backward-data pass"""
     c_out, c_in = w.shape[0], w.shape[1]
     timed = inp.is_cuda
-    fwd = {'miopen': lambda: _aten.convolution(inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1),
-           'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out))[0], inp, c_out, 0, k_per_group=ops.wino_group(c_out))}
+    fwd = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out))[0], inp, c_out, 0, k_per_group=ops.wino_group(c_out))}
     if c_out > 64:                      # narrower workgroups only matter when they add workgroups to a thin grid
         fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[0], inp, c_out, 0, k_per_group=32)
+    if CONV3X3 == 'miopen':
+        fwd['miopen'] = lambda: _aten.convolution(inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
     out = _Slot(fwd[_pick(('f', c_in, c_out) + tuple(inp.shape), fwd, timed)]())
 
     def bwd():
         g_out = out.g
-        cand = {'miopen': lambda: _aten.convolution_backward(g_out, inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                             [True, False, False])[0],
-                'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_in))[1], g_out, c_in, 2, k_per_group=ops.wino_group(c_in))}
+        cand = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_in))[1], g_out, c_in, 2, k_per_group=ops.wino_group(c_in))}
         if c_in > 64:
             cand['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[1], g_out, c_in, 2, k_per_group=32)
+        if CONV3X3 == 'miopen':
+            cand['miopen'] = lambda: _aten.convolution_backward(g_out, inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                                [True, False, False])[0]
         sink(cand[_pick(('b', c_in, c_out) + tuple(inp.shape), cand, timed)]())
+        out.g = None
+    tape.append(bwd)
+    return out
+
+
+def _s2_records(conv_w):
+    """(forward, backward-data) records of a stride-2 convolution weight for csrc/nf_conv_s2.hip, kept on the weight tensor"""
+    key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
+    cache = getattr(conv_w, '_nf_s2', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.conv_s2_pack(conv_w, False, conv_w.device), ops.conv_s2_pack(conv_w, True, conv_w.device))
+        conv_w._nf_s2 = cache
+    return cache[1], cache[2]
+
+
+# stride-2 convolutions (7x7 stem, first 3x3 of layer1-3): 'own' = csrc/nf_conv_s2.hip (default), 'miopen' = the vendor library
+CONV_S2 = os.environ.get('NERFOOL_CONV_S2', 'own')
+
+
+def _conv_s2(tape, inp, w, sink):
+    c_out, c_in, ks = w.shape[0], w.shape[1], w.shape[2]
+    rf, rb = _s2_records(w)
+    out = _Slot(ops.conv_s2_fwd(rf, inp, c_out, ks))
+    Hi, Wi = inp.shape[2], inp.shape[3]
+
+    def bwd():
+        sink(ops.conv_s2_bwd(rb, out.g, c_in, ks, Hi, Wi))
         out.g = None
     tape.append(bwd)
     return out
@@ -268,6 +303,8 @@ def _conv3x3(tape, inp, w, sink):
 def _conv(tape, inp, w, stride, sink, bias=None):
     if stride == 1 and bias is None and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 32 == 0:
         return _conv3x3(tape, inp, w, sink)
+    if stride == 2 and bias is None and CONV_S2 == 'own' and tuple(w.shape[2:]) in ((3, 3), (7, 7)) and (w.shape[2] == 3 or w.shape[1] <= 3):
+        return _conv_s2(tape, inp, w, sink)
     out = _Slot(_aten.convolution(inp, w, bias, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1))
 
     def bwd():

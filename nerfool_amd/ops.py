@@ -480,6 +480,49 @@ def wino_group(c_out):
     return 32 if c_out <= 32 else 64
 
 
+def conv_s2_pack(weight, backward, device):
+    """weight [c_out, c_in, ks, ks] (ks 3 or 7) -> MFMA records of the stride-2 direct convolution (backward: its
+    backward-data pass)"""
+    L = _lib.lib()
+    w = weight.detach().to('cpu', torch.float32).contiguous()
+    c_out, c_in, ks = w.shape[0], w.shape[1], w.shape[2]
+    n = L.nf_conv_s2_pack_floats(c_out, c_in, ks, int(bool(backward)))
+    if n < 0:
+        raise ValueError('stride-2 convolution kernels exist for 3x3 and 7x7 (got %dx%d)' % (ks, ks))
+    out = torch.empty(n, dtype=torch.float32)
+    _lib.check(L.nf_conv_s2_pack(w.data_ptr(), c_out, c_in, ks, int(bool(backward)), out.data_ptr()), 'nf_conv_s2_pack')
+    return out.to(device)
+
+
+def conv_s2_fwd(records, x, c_out, ks):
+    """stride-2, padding-0 convolution of the pre-padded x [N, c_in, Hi, Wi] (unit column stride) -> [N, c_out, Ho, Wo]"""
+    _f32(x, 'x')
+    if x.stride(3) != 1:
+        x = x.contiguous()
+    N, c_in, Hi, Wi = x.shape
+    Ho, Wo = (Hi - ks) // 2 + 1, (Wi - ks) // 2 + 1
+    y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
+    xs, ys = x.stride(), y.stride()
+    with prof.launch('nf_conv_s2_fwd', x, n_img=N, c_in=c_in, c_out=c_out, ks=ks, Ho=Ho, Wo=Wo):
+        _lib.check(_lib.lib().nf_conv_s2_fwd(_ptr(records), int(ks), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, _ptr(y), ys[0], ys[1], ys[2],
+                                             Ho, Wo, N, c_in, c_out, _stream(x)), 'nf_conv_s2_fwd')
+    return y
+
+
+def conv_s2_bwd(records, dy, c_in, ks, Hi, Wi):
+    """backward-data of conv_s2_fwd: dy [N, c_out, Ho, Wo] -> dx [N, c_in, Hi, Wi] (all of it written)"""
+    _f32(dy, 'dy')
+    if dy.stride(3) != 1:
+        dy = dy.contiguous()
+    N, c_out, Ho, Wo = dy.shape
+    dx = torch.empty(N, c_in, Hi, Wi, dtype=torch.float32, device=dy.device)
+    ds, xs = dy.stride(), dx.stride()
+    with prof.launch('nf_conv_s2_bwd', dy, n_img=N, c_in=c_in, c_out=c_out, ks=ks, Ho=Ho, Wo=Wo):
+        _lib.check(_lib.lib().nf_conv_s2_bwd(_ptr(records), int(ks), _ptr(dy), ds[0], ds[1], ds[2], Ho, Wo, _ptr(dx), xs[0], xs[1], xs[2],
+                                             Hi, Wi, N, c_in, c_out, _stream(dy)), 'nf_conv_s2_bwd')
+    return dx
+
+
 def wino_pack(weight, backward, device, k_per_group=None):
     """weight [c_out, c_in, 3, 3] -> Winograd-domain MFMA records (backward: the backward-data convolution);
     k_per_group: output channels per workgroup, 64 or 32 (default wino_group)"""

@@ -967,13 +967,13 @@ def check_eval_views_gnt_and_frames(dev):
     ret, _ = ev.render_view(args, model, Projector(dev), data, device=dev)
     f0 = frames[0]
     want8 = (255 * ret['outputs_fine']['rgb'].numpy().clip(0, 1)).astype('uint8')
-    # two renders of one view may differ in the last bit (the per-layer convolution choice is timed on first use), i.e. by
-    # one 8-bit level after truncation
-    assert int(np.abs(f0['fine']['rgb8'].astype(np.int32) - want8.astype(np.int32)).max()) <= 1
+    # the forward path is bitwise reproducible run to run (no atomics; the timed choice between the two Winograd workgroup widths
+    # does not change a bit: tools/diag_determinism.py)
+    assert np.array_equal(f0['fine']['rgb8'], want8)
     ch, cw = int(H * 0.075), int(W * 0.075)
     assert f0['video_frame'].shape == (H - 2 * ch, W - 2 * cw, 3)
     assert np.array_equal(f0['video_frame'], f0['fine']['rgb8'][ch:H - ch, cw:W - cw])
-    assert_close(f0['coarse']['acc'], ret['outputs_coarse']['weights'].sum(-1), 0, 1e-4, 'accumulation map')
+    assert_close(f0['coarse']['acc'], ret['outputs_coarse']['weights'].sum(-1), 0, 1e-6, 'accumulation map')
     assert float(np.abs(frames[0]['fine']['rgb8'].astype(np.int32) - frames[1]['fine']['rgb8'].astype(np.int32)).mean()) > 0, 'second camera differs'
     # GNT flavour
     torch.manual_seed(0)
@@ -1040,3 +1040,32 @@ def check_bf16_config5(dev):
         err = float((b - a).norm() / a.norm())
         print('[config 5] d loss / d featmap_%s: bf16 vs fp32 kernels rel-L2 %.3e' % (name, err))
         assert err <= 1.5e-1
+
+
+def check_conv_s2(dev, shapes=None):
+    """csrc/nf_conv_s2.hip (the stride-2 7x7 stem and 3x3 convolutions on pre-padded input, forward and backward-data) against
+    a float64 CPU convolution: ragged sizes, odd remainders (rows / columns the convolution never reads must get zero
+    gradient), channel counts that do not fill a tile."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(11)
+    shapes = shapes or ((1, 64, 64, 3, 21, 25), (2, 16, 64, 3, 38, 70), (1, 3, 64, 7, 29, 41), (1, 64, 128, 3, 12, 17),
+                        (2, 3, 64, 7, 75, 139), (1, 128, 256, 3, 33, 66), (1, 24, 40, 3, 19, 23))
+    for (N, cin, cout, ks, Hi, Wi) in shapes:
+        x = torch.randn(N, cin, Hi, Wi, generator=gen)
+        w = torch.randn(cout, cin, ks, ks, generator=gen) * 0.1
+        rf, rb = ops.conv_s2_pack(w, False, dev), ops.conv_s2_pack(w, True, dev)
+        xr = x.double().requires_grad_(True)
+        ref = F.conv2d(xr, w.double(), stride=2)
+        g = torch.randn(ref.shape, generator=gen)
+        gref, = torch.autograd.grad(ref, xr, g.double())
+        y = ops.conv_s2_fwd(rf, x.to(dev), cout, ks)
+        dx = ops.conv_s2_bwd(rb, g.to(dev), cin, ks, Hi, Wi)
+        ef = float((y.cpu().double() - ref.detach()).abs().max() / ref.abs().max())
+        eb = float((dx.cpu().double() - gref).abs().max() / gref.abs().max())
+        assert ef <= 5e-6 and eb <= 5e-6, ('conv_s2', N, cin, cout, ks, Hi, Wi, ef, eb)
+        # a strided (non-contiguous) input view: the executor hands the kernel interior views of padded buffers
+        big = torch.randn(N, cin, Hi + 3, Wi + 4, generator=gen).to(dev)
+        view = big[:, :, 1:1 + Hi, 2:2 + Wi]
+        y2 = ops.conv_s2_fwd(rf, view, cout, ks)
+        ref2 = F.conv2d(view.cpu().double(), w.double(), stride=2)
+        assert float((y2.cpu().double() - ref2).abs().max() / ref2.abs().max()) <= 5e-6

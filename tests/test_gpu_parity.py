@@ -53,6 +53,10 @@ def test_feature_net():
     pc.check_feature_net('cuda')
 
 
+def test_conv_s2():
+    pc.check_conv_s2('cuda')
+
+
 def test_fused_cnn_glue():
     pc.check_fused_cnn_glue('cuda')
 
