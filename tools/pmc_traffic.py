@@ -1,4 +1,4 @@
-"""profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes of bench.py (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 PMC passes of bench.py (`--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, each in
 its own run, csv output): HBM bytes per launch of every hand-written kernel in the timed steps, FETCH_SIZE doubled as
 MI355X_MICROARCH.md prescribes for gfx950, and the per-launch sum for the C-ABI entry points bench.py reports on.
 usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <timed steps> <out.json>"""
@@ -10,7 +10,8 @@ import sys
 ABI = {'nf_ibrnet_fwd_mfma': ('k_ibr_rows_fwd', 'k_ibr_ray_fwd'),
        'nf_ibrnet_bwd_mfma': ('k_ibr_rows_bwd', 'k_ibr_ray_bwd'),
        'nf_project_gather_fwd': ('k_project_gather_fwd',), 'nf_project_gather_bwd': ('k_project_gather_bwd',),
-       'nf_pgd_adam_step': ('k_pgd_adam_step',), 'nf_conv3x3_wino': ('k_wino3x3',)}
+       'nf_pgd_adam_step': ('k_pgd_adam_step',), 'nf_conv3x3_wino': ('k_wino3x3',),
+       'nf_conv_s2_fwd': ('k_conv_s2_fwd',), 'nf_conv_s2_bwd': ('k_conv_s2_bwd',)}
 
 
 def load(path, counter, steps):
@@ -49,7 +50,7 @@ def main():
             if name.startswith(prefixes):
                 tot += k['hbm_bytes_per_launch'] * k['launches_per_step']
         calls = 1 if entry == 'nf_pgd_adam_step' else 2          # coarse + fine level per step
-        if entry == 'nf_conv3x3_wino':                           # one kernel launch per call: every stride-1 3x3 layer, both directions
+        if entry in ('nf_conv3x3_wino', 'nf_conv_s2_fwd', 'nf_conv_s2_bwd'):     # one kernel launch per call
             calls = sum(k['launches_per_step'] for name, k in kernels.items() if name.startswith(prefixes)) or 1
         abi[entry] = {'hbm_bytes_per_launch': int(tot / calls), 'calls_per_step': calls}
         if entry in alg[64]:
