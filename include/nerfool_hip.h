@@ -198,6 +198,19 @@ int nf_conv1x1(const float* records, const float* bias, const float* x, int64_t 
                float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, int n_img, int H, int W, int c_in, int c_out,
                const float* x2, int c_split, nf_stream_t stream);
 
+/* Layout / padding glue of the ResUNet executor (csrc/nf_pad.hip; ibrnet/feature_network.py:188 reflect padding of the input,
+ * :231-243 skipconnect zero padding, :143-151 upsampling in front of a reflect-padded convolution -- its backward):
+ *   nf_pad_gather_fwd: out[n][c] (contiguous (H+2p) x (W+2p) planes at os_n / os_c) = reflect-pad_p( Z ), Z = the H x W plane holding
+ *       the eh x ew source window at (top, left), zeros elsewhere; source addressed by element strides (n, c, row, column)
+ *   nf_pad_gather_bwd: its adjoint, din written through element strides
+ *   nf_upsample2x_pad_bwd: adjoint of nf_upsample2x_pad_fwd (folds the reflect padding, transposed bilinear interpolation) */
+int nf_pad_gather_fwd(const float* src, int64_t ss_n, int64_t ss_c, int64_t ss_h, int64_t ss_w, int n_img, int C, int eh, int ew, int top,
+                      int left, int H, int W, int pad, float* out, int64_t os_n, int64_t os_c, nf_stream_t stream);
+int nf_pad_gather_bwd(const float* dout, int64_t os_n, int64_t os_c, int n_img, int C, int H, int W, int pad, int eh, int ew, int top,
+                      int left, float* din, int64_t ds_n, int64_t ds_c, int64_t ds_h, int64_t ds_w, nf_stream_t stream);
+int nf_upsample2x_pad_bwd(const float* d_y_padded, int64_t planes, int h, int w, int pad, float* dx, int64_t xs_plane, int64_t xs_row,
+                          nf_stream_t stream);
+
 /* The network's stride-2 convolutions -- the 7x7 stem and the first 3x3 convolution of layer1 / layer2 / layer3
  * (ibrnet/feature_network.py:188, :192-195 via :51) -- on pre-padded activations (padding 0), forward and backward-data, as
  * direct implicit-GEMM convolutions on the fp32 matrix cores (csrc/nf_conv_s2.hip; replaces MIOpen / rocBLAS + col2im).

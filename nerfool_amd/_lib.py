@@ -68,6 +68,11 @@ _PROTOTYPES = {
     'nf_conv1x1_pack': (c_int, [_P, c_int, c_int, c_int, _P]),
     'nf_conv1x1': (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                            c_int, c_int, c_int, _P, c_int, _P]),
+    'nf_pad_gather_fwd': (c_int, [_P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                  c_int64, c_int64, _P]),
+    'nf_pad_gather_bwd': (c_int, [_P, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, c_int64,
+                                  c_int64, c_int64, _P]),
+    'nf_upsample2x_pad_bwd': (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P]),
     'nf_conv_s2_pack_floats': (c_int64, [c_int, c_int, c_int, c_int]),
     'nf_conv_s2_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
     'nf_conv_s2_fwd': (c_int, [_P, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int,

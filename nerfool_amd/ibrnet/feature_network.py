@@ -385,15 +385,18 @@ def _resblock(tape, blk, xin):
 
 def _upsample_pad(tape, a, pad):
     """F.interpolate(x2, bilinear, align_corners) + the reflect padding of the following convolution in one kernel; the
-    backward folds the padded gradient (fused kernel) and applies the transposed interpolation (ATen)."""
+    backward folds the padded gradient and applies the transposed interpolation in one kernel (nf_upsample2x_pad_bwd)."""
     src = a.interior()
     up = _Act(ops.upsample2x_pad_fwd(src, pad), pad)
     in_size = list(src.shape)
     out_hw = [2 * in_size[2], 2 * in_size[3]]
 
     def bwd():
-        g, _ = ops.in_act_pad_bwd(up.gp, up.gi, up.yp, None, None, None, None, ops.ACT_NONE, pad, False)
-        a.add_i(_aten.upsample_bilinear2d_backward(g, out_hw, in_size, True, None, None))
+        if up.gi is None:           # the only consumer is the convolution: fold + transposed interpolation in one kernel
+            a.add_i(ops.upsample2x_pad_bwd(up.gp, in_size[2], in_size[3], pad))
+        else:
+            g, _ = ops.in_act_pad_bwd(up.gp, up.gi, up.yp, None, None, None, None, ops.ACT_NONE, pad, False)
+            a.add_i(_aten.upsample_bilinear2d_backward(g, out_hw, in_size, True, None, None))
         up.gp = up.gi = None
     tape.append(bwd)
     return up
@@ -405,20 +408,20 @@ def _join_pad(tape, enc, dec, pad):
     e, d = enc.interior(), dec.interior()
     dy, dx = d.shape[2] - e.shape[2], d.shape[3] - e.shape[3]
     top, left = dy // 2, dx // 2
-    ez = F.pad(e, (left, dx - left, top, dy - top)) if (dy or dx) else e
     N, cd, H, W = d.shape
     ce, eh, ew = e.shape[1], e.shape[2], e.shape[3]
     buf = torch.empty(N, cd + ce, H + 2 * pad, W + 2 * pad, dtype=d.dtype, device=d.device)
     ops.in_act_pad_fwd(d, None, None, None, ops.ACT_NONE, pad, out=buf, c_off=0)
-    ops.in_act_pad_fwd(ez, None, None, None, ops.ACT_NONE, pad, out=buf, c_off=cd)
+    # the encoder tensor is read where it lies (interior view of its padded activation) and lands zero-extended to H x W at
+    # (top, left), reflect-padded, in its channel slice of the buffer: no F.pad copy, no separate padding pass
+    ops.pad_gather_fwd(e, H, W, pad, top, left, out=buf[:, cd:])
     out = _Act(buf, pad)
 
     def bwd():
         g = out.gp
         dd, _ = ops.in_act_pad_bwd(g[:, :cd], None, None, None, None, None, None, ops.ACT_NONE, pad, False, shape=(N, cd, H, W))
-        de, _ = ops.in_act_pad_bwd(g[:, cd:], None, None, None, None, None, None, ops.ACT_NONE, pad, False, shape=(N, ce, H, W))
         dec.add_i(dd)
-        enc.add_i(de[:, :, top:top + eh, left:left + ew] if (dy or dx) else de)
+        enc.add_i(ops.pad_gather_bwd(g[:, cd:], H, W, pad, eh, ew, top, left))
         out.gp = None
     tape.append(bwd)
     return out
@@ -435,8 +438,16 @@ class _NoTape:
 def fused_forward(net, x, need_grad=True):
     """x [V,3,H,W] -> (out [V,64,Hf,Wf] NCHW, tape, input slot)."""
     tape = [] if need_grad else _NoTape()
-    xin = _Slot(x.contiguous())
-    a = _fuse(tape, xin, None, None, ops.ACT_NONE, 3)
+    # the input image is read in whatever layout it comes (the attack hands over a permuted view of the channels-last
+    # src + delta) and leaves reflect-padded for the 7x7 stem; its gradient is written back in the same layout
+    xin = _Slot(x)
+    H0, W0 = x.shape[2], x.shape[3]
+    a_in = a = _Act(ops.pad_gather_fwd(x, H0, W0, 3), 3)
+
+    def input_bwd():
+        xin.g = ops.pad_gather_bwd(a_in.gp, H0, W0, 3, H0, W0, like=x)
+        a_in.gp = None
+    tape.append(input_bwd)
     t = _conv(tape, a.yp, net.conv1.weight, 2, a.add_p)
     a = _fuse(tape, t, net.bn1, None, ops.ACT_RELU, 1)
     feats = []

@@ -480,6 +480,51 @@ def wino_group(c_out):
     return 32 if c_out <= 32 else 64
 
 
+def pad_gather_fwd(src, H, W, pad, top=0, left=0, out=None):
+    """reflect_pad(Z, pad) with Z = the [N,C,H,W] tensor that holds src [N,C,eh,ew] (ANY strides: a channels-last image, the
+    interior view of a padded activation) at (top, left) and zeros elsewhere -> [N,C,H+2pad,W+2pad] (or written into `out`, a
+    channel slice of a larger contiguous padded buffer)"""
+    _f32(src, 'src')
+    N, C, eh, ew = src.shape
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    if out is None:
+        out = torch.empty(N, C, Hp, Wp, dtype=torch.float32, device=src.device)
+    assert tuple(out.shape) == (N, C, Hp, Wp) and out.stride(3) == 1 and out.stride(2) == Wp
+    ss = src.stride()
+    with prof.launch('nf_pad_gather_fwd', src, n=out.numel()):
+        _lib.check(_lib.lib().nf_pad_gather_fwd(_ptr(src), ss[0], ss[1], ss[2], ss[3], N, C, eh, ew, int(top), int(left), int(H), int(W), int(pad),
+                                                _ptr(out), out.stride(0), out.stride(1), _stream(src)), 'nf_pad_gather_fwd')
+    return out
+
+
+def pad_gather_bwd(d_out, H, W, pad, eh, ew, top=0, left=0, like=None):
+    """adjoint of pad_gather_fwd: d_out [N,C,H+2pad,W+2pad] (contiguous planes, any image / channel stride) -> d src [N,C,eh,ew],
+    laid out like `like` (same strides) when given, else contiguous"""
+    _f32(d_out, 'd_out')
+    N, C, Hp, Wp = d_out.shape
+    assert d_out.stride(3) == 1 and d_out.stride(2) == Wp and Hp == H + 2 * pad and Wp == W + 2 * pad
+    if like is not None:
+        din = torch.empty_strided((N, C, eh, ew), like.stride(), dtype=torch.float32, device=d_out.device)
+    else:
+        din = torch.empty(N, C, eh, ew, dtype=torch.float32, device=d_out.device)
+    ds = din.stride()
+    with prof.launch('nf_pad_gather_bwd', d_out, n=d_out.numel()):
+        _lib.check(_lib.lib().nf_pad_gather_bwd(_ptr(d_out), d_out.stride(0), d_out.stride(1), N, C, int(H), int(W), int(pad), int(eh), int(ew),
+                                                int(top), int(left), _ptr(din), ds[0], ds[1], ds[2], ds[3], _stream(d_out)), 'nf_pad_gather_bwd')
+    return din
+
+
+def upsample2x_pad_bwd(d_yp, h, w, pad):
+    """adjoint of upsample2x_pad_fwd: d_yp [N,C,2h+2pad,2w+2pad] -> [N,C,h,w]"""
+    d_yp = _c(d_yp, 'd_yp')
+    N, C = d_yp.shape[0], d_yp.shape[1]
+    dx = torch.empty(N, C, h, w, dtype=torch.float32, device=d_yp.device)
+    with prof.launch('nf_upsample2x_pad_bwd', d_yp, n=d_yp.numel()):
+        _lib.check(_lib.lib().nf_upsample2x_pad_bwd(_ptr(d_yp), N * C, int(h), int(w), int(pad), _ptr(dx), h * w, w, _stream(d_yp)),
+                   'nf_upsample2x_pad_bwd')
+    return dx
+
+
 def conv_s2_pack(weight, backward, device):
     """weight [c_out, c_in, ks, ks] (ks 3 or 7) -> MFMA records of the stride-2 direct convolution (backward: its
     backward-data pass)"""

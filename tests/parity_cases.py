@@ -1069,3 +1069,48 @@ def check_conv_s2(dev, shapes=None):
         y2 = ops.conv_s2_fwd(rf, view, cout, ks)
         ref2 = F.conv2d(view.cpu().double(), w.double(), stride=2)
         assert float((y2.cpu().double() - ref2).abs().max() / ref2.abs().max()) <= 5e-6
+
+
+def check_pad_glue(dev):
+    """csrc/nf_pad.hip against ATen: reflect padding of a channels-last image read in place (and its gradient written back
+    channels-last), the zero-extended + reflect-padded skip tensor read from an interior view, the adjoint of the fused bilinear x2
+    upsampling + reflect padding."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(3)
+    # channels-last input image, pad 3
+    img = torch.rand(2, 13, 17, 3, generator=gen)
+    x = img.permute(0, 3, 1, 2)                                   # NCHW view of NHWC storage
+    ref = F.pad(x, (3, 3, 3, 3), mode='reflect')
+    got = ops.pad_gather_fwd(x.to(dev), 13, 17, 3)
+    assert_close(got, ref, 0, 0, 'input reflect pad')
+    gup = torch.randn(ref.shape, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    want, = torch.autograd.grad(F.pad(xr, (3, 3, 3, 3), mode='reflect'), xr, gup)
+    xd = img.to(dev).permute(0, 3, 1, 2)
+    din = ops.pad_gather_bwd(gup.to(dev), 13, 17, 3, 13, 17, like=xd)
+    assert din.stride() == xd.stride(), 'gradient must come back in the layout of the input'
+    assert_close(din, want, 1e-6, 1e-6, 'input reflect pad backward')
+    # skip tensor: interior view of a padded activation, zero-extended to the decoder size, reflect pad 1, into a channel slice
+    act = torch.randn(2, 5, 9 + 2, 14 + 2, generator=gen)
+    e = act[:, :, 1:-1, 1:-1]
+    H, W, top, left = 12, 16, 1, 1
+    ez = F.pad(e, (left, W - 14 - left, top, H - 9 - top))
+    ref = F.pad(ez, (1, 1, 1, 1), mode='reflect')
+    buf = torch.zeros(2, 8, H + 2, W + 2).to(dev)
+    ops.pad_gather_fwd(act.to(dev)[:, :, 1:-1, 1:-1], H, W, 1, top, left, out=buf[:, 3:])
+    assert_close(buf[:, 3:], ref, 0, 0, 'skip zero + reflect pad')
+    assert float(buf[:, :3].abs().max()) == 0
+    g = torch.randn(2, 8, H + 2, W + 2, generator=gen)
+    er = e.clone().requires_grad_(True)
+    want, = torch.autograd.grad(F.pad(F.pad(er, (left, W - 14 - left, top, H - 9 - top)), (1, 1, 1, 1), mode='reflect'), er, g[:, 3:])
+    got = ops.pad_gather_bwd(g.to(dev)[:, 3:], H, W, 1, 9, 14, top, left)
+    assert_close(got, want, 1e-6, 1e-6, 'skip pad backward')
+    # upsample x2 (align_corners) + reflect pad: adjoint
+    for (h, w, pad) in ((7, 9, 1), (16, 33, 1), (1, 2, 0), (5, 5, 2)):
+        xs = torch.randn(2, 3, h, w, generator=gen, dtype=torch.float64).requires_grad_(True)
+        up = F.interpolate(xs, scale_factor=2, mode='bilinear', align_corners=True)
+        yp = F.pad(up, (pad, pad, pad, pad), mode='reflect') if pad else up
+        gy = torch.randn(yp.shape, generator=gen)
+        want, = torch.autograd.grad(yp, xs, gy.double())
+        got = ops.upsample2x_pad_bwd(gy.to(dev), h, w, pad)
+        assert_close(got, want, 1e-5, 1e-5 * float(want.abs().max()), 'upsample + pad backward %dx%d pad %d' % (h, w, pad))

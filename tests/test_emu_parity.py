@@ -65,6 +65,10 @@ def test_conv_s2():
     pc.check_conv_s2('cpu', shapes=((1, 64, 64, 3, 21, 25), (1, 3, 64, 7, 29, 41), (1, 24, 40, 3, 19, 23)))
 
 
+def test_pad_glue():
+    pc.check_pad_glue('cpu')
+
+
 def test_fused_cnn_glue():
     pc.check_fused_cnn_glue('cpu')
 

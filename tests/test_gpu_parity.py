@@ -57,6 +57,10 @@ def test_conv_s2():
     pc.check_conv_s2('cuda')
 
 
+def test_pad_glue():
+    pc.check_pad_glue('cuda')
+
+
 def test_fused_cnn_glue():
     pc.check_fused_cnn_glue('cuda')
 
