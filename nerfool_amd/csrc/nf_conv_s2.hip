@@ -48,7 +48,7 @@ extern "C" int64_t nf_conv_s2_pack_floats(int c_out, int c_in, int ks, int backw
         const int64_t groups = (c_out + 63) / 64, chunks = (c_in + cc - 1) / cc;
         return groups * chunks * steps * 2 * 64;
     }
-    if (ks == 7) return (int64_t)((c_out + S2_STEM_CK - 1) / S2_STEM_CK) * (S2_STEM_CK / 2) * 16 * 64;      // stem form, see below
+    if (ks == 7) return (int64_t)((c_out + S2_STEM_CK - 1) / S2_STEM_CK) * (S2_STEM_CK / 4) * 16 * 64;      // stem form, see below
     const int ck = 16;
     const int64_t groups = (c_in + 31) / 32, chunks = (c_out + ck - 1) / ck;
     return groups * chunks * (ck / 2) * ks * ks * 64;
@@ -58,8 +58,9 @@ extern "C" int64_t nf_conv_s2_pack_floats(int c_out, int c_in, int ks, int backw
  * forward:  [group of 64 outputs][chunk][step][tile t][lane (i, h)] = W[64 g + 32 t + i][c][a][b]
  * backward: [group of 32 inputs ][chunk of CK outputs][class (ya, xb)][tap (i, j)][pair p][lane (i_c, h)]
  *           = W[k = chunk CK + 2 p + h][c = 32 g + i_c][a = 2 i + ya][b = 2 j + xb]
- * backward, 7x7 (c_in <= 8): [chunk of 8 outputs][pair p][tap (i, j) of 4 x 4][lane (m, h)], m = 4 c + 2 ya + xb
- *           = W[k = chunk 8 + 2 p + h][c][2 i + ya][2 j + xb]  (zero where the tap lies outside the 7 x 7 kernel) */
+ * backward, 7x7 (c_in <= 4): [chunk of 8 outputs][group of 4 outputs gq][tap (i, j) of 4 x 4][lane (m, q)], m = 4 c + 2 ya + xb
+ *           = W[k = chunk 8 + 4 gq + q][c][2 i + ya][2 j + xb]  (v_mfma_f32_16x16x4_f32 A operand: row m = lane & 15, k = lane >> 4;
+ *           zero where the tap lies outside the 7 x 7 kernel or m >= 4 c_in) */
 extern "C" int nf_conv_s2_pack(const float* weight, int c_out, int c_in, int ks, int backward, float* out) {
     if (ks != 3 && ks != 7) return 1;
     auto W = [&](int k, int c, int a, int b) -> float {
@@ -92,12 +93,12 @@ extern "C" int nf_conv_s2_pack(const float* weight, int c_out, int c_in, int ks,
     } else if (ks == 7) {
         const int chunks = (c_out + S2_STEM_CK - 1) / S2_STEM_CK;
         for (int ch = 0; ch < chunks; ++ch)
-            for (int p = 0; p < S2_STEM_CK / 2; ++p)
+            for (int gq = 0; gq < S2_STEM_CK / 4; ++gq)
                 for (int i = 0; i < 4; ++i)
                     for (int j = 0; j < 4; ++j)
                         for (int lane = 0; lane < 64; ++lane, ++rec) {
-                            const int m = lane & 31, c = m >> 2, ya = (m >> 1) & 1, xb = m & 1;
-                            *rec = W(ch * S2_STEM_CK + 2 * p + (lane >> 5), c, 2 * i + ya, 2 * j + xb);
+                            const int m = lane & 15, c = m >> 2, ya = (m >> 1) & 1, xb = m & 1;
+                            *rec = W(ch * S2_STEM_CK + 4 * gq + (lane >> 4), c, 2 * i + ya, 2 * j + xb);
                         }
     } else {
         const int ck = 16;
@@ -152,50 +153,88 @@ __global__ void __launch_bounds__(256, 2) k_conv_s2_fwd(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
 
-    for (int ch = 0; ch < chunks; ++ch) {
-        __syncthreads();        // the previous chunk's operands are consumed
-        // ---- stage the raw window of this chunk, columns split by parity; zeros outside the tensor.  The window starts at an
-        // even column of an even-width row, so a lane moves one 8-byte column pair: 32 lanes cover columns 0..63 of a window
-        // row (the two halves of a wave take two rows), element 2 l goes to parity plane 0, 2 l + 1 to plane 1, both at index l
-        {
-            const int l = lane & 31, sub = lane >> 5;
-            for (int r0 = 0; r0 < CC * WR; r0 += 8) {
-                const int rr = r0 + 2 * w + sub;                       // window row (channel-major)
-                if (rr < CC * WR) {
-                    const int c = rr / WR, r = rr - c * WR;
-                    const int gc = ch * CC + c, gy = iy0 + r, gx = ix0 + 2 * l;
-                    s2_f2 v = {0.f, 0.f};
-                    if (gc < C && gy < Hi) {
-                        const float* src = xn + gc * xi.cs + gy * xi.rs + gx;
-                        if (pair_ok && gx + 1 < Wi) v = *reinterpret_cast<const s2_f2*>(src);
-                        else {
-                            if (gx < Wi) v[0] = src[0];
-                            if (gx + 1 < Wi) v[1] = src[1];
-                        }
+    // Staging is software-pipelined: the global loads of chunk ch + 1 (window pairs, extra columns, weight records) are issued
+    // into registers right behind the barrier that publishes chunk ch and are only waited for when they are committed to LDS
+    // at the top of the next iteration, i.e. they fly under chunk ch's matrix-core work.
+    constexpr int NROW = (CC * WR + 7) / 8;                       // window-row iterations per thread (8 rows per sweep)
+    constexpr int XC = WC - 64, NXC = (CC * WR * XC + 255) / 256; // columns beyond 63 (1 for 3x3, 6 for 7x7): one element per item
+    constexpr int NWG = (G::STEPS * 32 + 255) / 256;              // 16-byte weight pieces per thread
+    s2_f2 pre_w[NROW];
+    float pre_x[NXC];
+    s2_f4 pre_g[NWG];
+    const int l32 = lane & 31, sub = lane >> 5;
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int it = 0; it < NROW; ++it) {
+            const int rr = it * 8 + 2 * w + sub;                   // window row (channel-major)
+            s2_f2 v = {0.f, 0.f};
+            if (rr < CC * WR) {
+                const int c = rr / WR, r = rr - c * WR;
+                const int gc = ch * CC + c, gy = iy0 + r, gx = ix0 + 2 * l32;
+                if (gc < C && gy < Hi) {
+                    const float* src = xn + gc * xi.cs + gy * xi.rs + gx;
+                    if (pair_ok && gx + 1 < Wi) v = *reinterpret_cast<const s2_f2*>(src);
+                    else {
+                        if (gx < Wi) v[0] = src[0];
+                        if (gx + 1 < Wi) v[1] = src[1];
                     }
-                    float* dst = win + c * CHF + r * ROWF + l;
-                    dst[0] = v[0];
-                    dst[S2_PW] = v[1];
                 }
             }
-            // the columns beyond 63 (1 for 3x3, 6 for 7x7): one element per thread
-            constexpr int XC = WC - 64;
-            for (int i = threadIdx.x; i < CC * WR * XC; i += 256) {
+            pre_w[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NXC; ++it) {
+            const int i = it * 256 + threadIdx.x;
+            float v = 0.f;
+            if (i < CC * WR * XC) {
                 const int rr = i / XC, col = 64 + (i - rr * XC);
                 const int c = rr / WR, r = rr - c * WR;
                 const int gc = ch * CC + c, gy = iy0 + r, gx = ix0 + col;
-                float v = 0.f;
                 if (gc < C && gy < Hi && gx < Wi) v = xn[gc * xi.cs + gy * xi.rs + gx];
-                win[c * CHF + r * ROWF + (col & 1) * S2_PW + (col >> 1)] = v;
+            }
+            pre_x[it] = v;
+        }
+        const s2_f4* src = reinterpret_cast<const s2_f4*>(wsrc + (size_t)ch * (G::STEPS * 128));
+#pragma unroll
+        for (int it = 0; it < NWG; ++it) {
+            const int i = it * 256 + threadIdx.x;
+            pre_g[it] = i < G::STEPS * 32 ? src[i] : s2_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // window layout: columns split by parity -- element 2 l of a row goes to plane 0, 2 l + 1 to plane 1, both at index l
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < NROW; ++it) {
+            const int rr = it * 8 + 2 * w + sub;
+            if (rr < CC * WR) {
+                const int c = rr / WR, r = rr - c * WR;
+                float* dst = win + c * CHF + r * ROWF + l32;
+                dst[0] = pre_w[it][0];
+                dst[S2_PW] = pre_w[it][1];
             }
         }
-        // ---- and its weight records (contiguous, 16-byte pieces)
-        {
-            const s2_f4* src = reinterpret_cast<const s2_f4*>(wsrc + (size_t)ch * (G::STEPS * 128));
-            s2_f4* dst = reinterpret_cast<s2_f4*>(wgt);
-            for (int i = threadIdx.x; i < G::STEPS * 32; i += 256) dst[i] = src[i];
+#pragma unroll
+        for (int it = 0; it < NXC; ++it) {
+            const int i = it * 256 + threadIdx.x;
+            if (i < CC * WR * XC) {
+                const int rr = i / XC, col = 64 + (i - rr * XC);
+                const int c = rr / WR, r = rr - c * WR;
+                win[c * CHF + r * ROWF + (col & 1) * S2_PW + (col >> 1)] = pre_x[it];
+            }
         }
+        s2_f4* dst = reinterpret_cast<s2_f4*>(wgt);
+#pragma unroll
+        for (int it = 0; it < NWG; ++it) {
+            const int i = it * 256 + threadIdx.x;
+            if (i < G::STEPS * 32) dst[i] = pre_g[it];
+        }
+    };
+    fetch(0);
+    for (int ch = 0; ch < chunks; ++ch) {
+        __syncthreads();        // the previous chunk's operands are consumed
+        commit();
         __syncthreads();
+        if (ch + 1 < chunks) fetch(ch + 1);
         // ---- k-steps, fully unrolled: every LDS offset below is an immediate
         auto step = [&](int s, int imm) {
             const float a0 = wgt[(2 * s) * 64 + lane], a1 = wgt[(2 * s + 1) * 64 + lane];
@@ -298,6 +337,76 @@ template <int KS> struct S2Bwd {
     static constexpr int FLOATS = WIN + STEPS * 64;
 };
 
+// ---- software-pipelined staging of the backward kernels: the dy window of CK channels (WR rows x WCOLS columns, zeros outside
+// the tensor) and WFLOATS floats of weight records travel global -> registers (fetch, issued under the previous chunk's
+// matrix-core work) -> LDS (commit, behind the barrier that retires the previous chunk)
+template <int CK, int WR, int WCOLS, int T0, int WFLOATS>
+struct S2BwdStage {
+    static constexpr int NROW = (CK * WR + 7) / 8, XC = WCOLS - 32, NXC = (CK * WR * XC + 255) / 256, NWG = (WFLOATS / 4 + 255) / 256;
+    static constexpr int CHF = WR * S2_PW;
+    float pre_w[NROW], pre_x[NXC];
+    s2_f4 pre_g[NWG];
+    __device__ __forceinline__ void fetch(const float* __restrict__ dn, S2Tensor di, int Ho, int Wo, int K, int ch, int u0, int v0,
+                                          const float* __restrict__ wsrc, int w, int lane) {
+        const int l = lane & 31, sub = lane >> 5;
+#pragma unroll
+        for (int it = 0; it < NROW; ++it) {
+            const int rr = it * 8 + 2 * w + sub;
+            float v = 0.f;
+            if (rr < CK * WR) {
+                const int c = rr / WR, r = rr - c * WR;
+                const int gk = ch * CK + c, gu = u0 - (T0 - 1) + r, gv = v0 - (T0 - 1) + l;
+                if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = dn[gk * di.cs + gu * di.rs + gv];
+            }
+            pre_w[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NXC; ++it) {
+            const int i = it * 256 + (int)threadIdx.x;
+            float v = 0.f;
+            if (i < CK * WR * XC) {
+                const int rr = i / XC, cc = 32 + (i - rr * XC);
+                const int c = rr / WR, r = rr - c * WR;
+                const int gk = ch * CK + c, gu = u0 - (T0 - 1) + r, gv = v0 - (T0 - 1) + cc;
+                if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = dn[gk * di.cs + gu * di.rs + gv];
+            }
+            pre_x[it] = v;
+        }
+        const s2_f4* src = reinterpret_cast<const s2_f4*>(wsrc + (size_t)ch * WFLOATS);
+#pragma unroll
+        for (int it = 0; it < NWG; ++it) {
+            const int i = it * 256 + (int)threadIdx.x;
+            pre_g[it] = i < WFLOATS / 4 ? src[i] : s2_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void commit(float* win, float* wgt, int w, int lane) const {
+        const int l = lane & 31, sub = lane >> 5;
+#pragma unroll
+        for (int it = 0; it < NROW; ++it) {
+            const int rr = it * 8 + 2 * w + sub;
+            if (rr < CK * WR) {
+                const int c = rr / WR, r = rr - c * WR;
+                win[c * CHF + r * S2_PW + l] = pre_w[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NXC; ++it) {
+            const int i = it * 256 + (int)threadIdx.x;
+            if (i < CK * WR * XC) {
+                const int rr = i / XC, cc = 32 + (i - rr * XC);
+                const int c = rr / WR, r = rr - c * WR;
+                win[c * CHF + r * S2_PW + cc] = pre_x[it];
+            }
+        }
+        s2_f4* dst = reinterpret_cast<s2_f4*>(wgt);
+#pragma unroll
+        for (int it = 0; it < NWG; ++it) {
+            const int i = it * 256 + (int)threadIdx.x;
+            if (i < WFLOATS / 4) dst[i] = pre_g[it];
+        }
+    }
+};
+
 template <int KS>
 __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd(const float* __restrict__ rec, const float* __restrict__ dy, S2Tensor di, int Ho, int Wo,
                                                         float* __restrict__ dx, S2Tensor xo, int Hi, int Wi, int C, int K, int groups,
@@ -329,37 +438,13 @@ __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ya][xb][r] = 0.f;
 
+    S2BwdStage<CK, WR, G::WCOLS, T0, G::STEPS * 64> stage;
+    stage.fetch(dn, di, Ho, Wo, K, 0, u0, v0, wsrc, w, lane);
     for (int ch = 0; ch < chunks; ++ch) {
         __syncthreads();
-        // dy window: the two halves of a wave take two window rows, lane l column l; the columns beyond 31 in a second sweep
-        {
-            const int l = lane & 31, sub = lane >> 5;
-            for (int r0 = 0; r0 < CK * WR; r0 += 8) {
-                const int rr = r0 + 2 * w + sub;
-                if (rr < CK * WR) {
-                    const int c = rr / WR, r = rr - c * WR;
-                    const int gk = ch * CK + c, gu = u0 - (T0 - 1) + r, gv = v0 - (T0 - 1) + l;
-                    float v = 0.f;
-                    if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = dn[gk * di.cs + gu * di.rs + gv];
-                    win[c * CHF + r * S2_PW + l] = v;
-                }
-            }
-            constexpr int XC = G::WCOLS - 32;
-            for (int i = threadIdx.x; i < CK * WR * XC; i += 256) {
-                const int rr = i / XC, col = 32 + (i - rr * XC);
-                const int c = rr / WR, r = rr - c * WR;
-                const int gk = ch * CK + c, gu = u0 - (T0 - 1) + r, gv = v0 - (T0 - 1) + col;
-                float v = 0.f;
-                if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = dn[gk * di.cs + gu * di.rs + gv];
-                win[c * CHF + r * S2_PW + col] = v;
-            }
-        }
-        {
-            const s2_f4* src = reinterpret_cast<const s2_f4*>(wsrc + (size_t)ch * (G::STEPS * 64));
-            s2_f4* dst = reinterpret_cast<s2_f4*>(wgt);
-            for (int i = threadIdx.x; i < G::STEPS * 16; i += 256) dst[i] = src[i];
-        }
+        stage.commit(win, wgt, w, lane);
         __syncthreads();
+        if (ch + 1 < chunks) stage.fetch(dn, di, Ho, Wo, K, ch + 1, u0, v0, wsrc, w, lane);
         int s = 0;
 #pragma unroll
         for (int ya = 0; ya < 2; ++ya)
@@ -396,17 +481,20 @@ __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd(const float* __restrict_
     }
 }
 
-// ---- backward-data of the 7x7 stem (at most 8 input channels): the four parity classes share ONE accumulator tile -- row
-// m = 4 c + 2 ya + xb -- and one 4 x 4 tap grid (zero weights where a class has only 3 taps), so a (u, v) position costs 16
-// matrix-core products per dy channel pair instead of the 49 of the per-class form above (measured: 1.30 ms -> see DESIGN)
+// ---- backward-data of the 7x7 stem (at most 4 input channels): the four parity classes share ONE accumulator tile -- row
+// m = 4 c + 2 ya + xb -- and one 4 x 4 tap grid (zero weights where a class has only 3 taps), on v_mfma_f32_16x16x4_f32: 16 rows
+// (12 used by the 3 colour channels) x 16 pixels x 4 dy channels per instruction, a wave = one row u x 32 columns v = two
+// accumulator tiles.  Per (u, v) position and dy channel this is 16 x 0.5 matrix-core cycles against 49 x 1 in the per-class
+// 32 x 32 form (measured on the stem: 1.30 ms per-class, 0.45 ms merged on 32 x 32 x 2, see DESIGN for this form).
+typedef float s2_f4v __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd_stem(const float* __restrict__ rec, const float* __restrict__ dy, S2Tensor di, int Ho,
                                                              int Wo, float* __restrict__ dx, S2Tensor xo, int Hi, int Wi, int C, int K,
                                                              int tiles_x, int tiles_y) {
-    constexpr int CK = S2_STEM_CK, T0 = 4, WR = 4 + T0 - 1, WCOLS = 32 + T0 - 1, CHF = WR * S2_PW, WIN = CK * CHF, STEPS = (CK / 2) * 16;
+    constexpr int CK = S2_STEM_CK, T0 = 4, WR = 4 + T0 - 1, WCOLS = 32 + T0 - 1, CHF = WR * S2_PW, WIN = CK * CHF, STEPS = (CK / 4) * 16;
     HIP_DYNAMIC_SHARED(float, smem)
     float* win = smem;
     float* wgt = smem + WIN;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 15, q = lane >> 4;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x;
     bid /= tiles_x;
@@ -414,58 +502,48 @@ __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd_stem(const float* __rest
     const int u0 = ty * 4, v0 = tx * 32;
     const int chunks = (K + CK - 1) / CK;
     const float* dn = dy + n * di.ns;
-    const int bbase = h * CHF + (T0 - 1 + w) * S2_PW + (T0 - 1) + j;
-    s2_f16 acc;
+    const int bbase = q * CHF + (T0 - 1 + w) * S2_PW + (T0 - 1) + col;
+    s2_f4v acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    S2BwdStage<CK, WR, WCOLS, T0, STEPS * 64> stage;
+    stage.fetch(dn, di, Ho, Wo, K, 0, u0, v0, rec, w, lane);
     for (int ch = 0; ch < chunks; ++ch) {
         __syncthreads();
-        {
-            const int l = lane & 31, sub = lane >> 5;
-            for (int r0 = 0; r0 < CK * WR; r0 += 8) {
-                const int rr = r0 + 2 * w + sub;
-                if (rr < CK * WR) {
-                    const int c = rr / WR, r = rr - c * WR;
-                    const int gk = ch * CK + c, gu = u0 - (T0 - 1) + r, gv = v0 - (T0 - 1) + l;
-                    float v = 0.f;
-                    if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = dn[gk * di.cs + gu * di.rs + gv];
-                    win[c * CHF + r * S2_PW + l] = v;
-                }
-            }
-            constexpr int XC = WCOLS - 32;
-            for (int i = threadIdx.x; i < CK * WR * XC; i += 256) {
-                const int rr = i / XC, col = 32 + (i - rr * XC);
-                const int c = rr / WR, r = rr - c * WR;
-                const int gk = ch * CK + c, gu = u0 - (T0 - 1) + r, gv = v0 - (T0 - 1) + col;
-                float v = 0.f;
-                if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = dn[gk * di.cs + gu * di.rs + gv];
-                win[c * CHF + r * S2_PW + col] = v;
-            }
-        }
-        {
-            const s2_f4* src = reinterpret_cast<const s2_f4*>(rec + (size_t)ch * (STEPS * 64));
-            s2_f4* dst = reinterpret_cast<s2_f4*>(wgt);
-            for (int i = threadIdx.x; i < STEPS * 16; i += 256) dst[i] = src[i];
-        }
+        stage.commit(win, wgt, w, lane);
         __syncthreads();
+        if (ch + 1 < chunks) stage.fetch(dn, di, Ho, Wo, K, ch + 1, u0, v0, rec, w, lane);
         int s = 0;
 #pragma unroll
-        for (int p = 0; p < CK / 2; ++p)
+        for (int gq = 0; gq < CK / 4; ++gq)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj, ++s) acc = S2_MFMA(wgt[s * 64 + lane], win[bbase + 2 * p * CHF - i * S2_PW - jj], acc);
-    }
-    float* xn = dx + n * xo.ns;
-    const int u = u0 + w, v = v0 + j, X = 2 * v;
+                for (int jj = 0; jj < 4; ++jj, ++s) {
+                    const float a = wgt[s * 64 + lane];
 #pragma unroll
-    for (int rr = 0; rr < 16; rr += 2) {
-        const int m = s2_nidx(rr, h), c = m >> 2, ya = (m >> 1) & 1;       // rows m, m + 1 = the two column classes
-        const int Y = 2 * u + ya;
-        if (c < C && Y < Hi && X < Wi) {
-            float* p = xn + c * xo.cs + Y * xo.rs + X;
-            if (X + 1 < Wi) *reinterpret_cast<s2_f2*>(p) = s2_f2{acc[rr], acc[rr + 1]};
-            else p[0] = acc[rr];
+                    for (int t = 0; t < 2; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, win[bbase + 4 * gq * CHF - i * S2_PW - jj + 16 * t], acc[t], 0, 0, 0);
+                }
+    }
+    // accumulator register r of lane (col, q): row m = 4 q + r = (c = q, ya = r >> 1, xb = r & 1), pixel v = v0 + 16 t + col
+    float* xn = dx + n * xo.ns;
+    const int u = u0 + w;
+    if (q < C) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int X = 2 * (v0 + 16 * t + col);
+#pragma unroll
+            for (int ya = 0; ya < 2; ++ya) {
+                const int Y = 2 * u + ya;
+                if (Y < Hi && X < Wi) {
+                    float* p = xn + q * xo.cs + Y * xo.rs + X;
+                    if (X + 1 < Wi) *reinterpret_cast<s2_f2*>(p) = s2_f2{acc[t][2 * ya], acc[t][2 * ya + 1]};
+                    else p[0] = acc[t][2 * ya];
+                }
+            }
         }
     }
 }
@@ -491,9 +569,9 @@ extern "C" int nf_conv_s2_bwd(const float* records, int ks, const float* dy, int
     hipStream_t st = (hipStream_t)stream;
     const S2Tensor di{ds_n, ds_c, ds_h}, xo{xs_n, xs_c, xs_h};
     if (ks == 7) {
-        NF_REQUIRE(c_in <= 8, "nf_conv_s2_bwd: the 7x7 form takes at most 8 input channels (got %d)", c_in);
+        NF_REQUIRE(c_in <= 4, "nf_conv_s2_bwd: the 7x7 form takes at most 4 input channels (got %d)", c_in);
         const int tiles_x = ((Wi + 1) / 2 + 31) / 32, tiles_y = ((Hi + 1) / 2 + 3) / 4;
-        constexpr size_t smem = sizeof(float) * (S2_STEM_CK * 7 * S2_PW + (S2_STEM_CK / 2) * 16 * 64);
+        constexpr size_t smem = sizeof(float) * (S2_STEM_CK * 7 * S2_PW + (S2_STEM_CK / 4) * 16 * 64);
         hipLaunchKernelGGL(k_conv_s2_bwd_stem, dim3((unsigned)(tiles_x * tiles_y * n_img)), dim3(256), smem, st, records, dy, di, Ho, Wo, dx, xo,
                            Hi, Wi, c_in, c_out, tiles_x, tiles_y);
     } else {
