@@ -200,7 +200,8 @@ class _Act:
 # channels per workgroup, once per (shape, direction) on first use, and keeps the faster -- both forms compute every output
 # with the same arithmetic in the same order, so the choice does not change a single bit of the result; 'wino' / 'wino32'
 # force one, 'miopen' (NERFOOL_CONV3X3) runs the vendor library instead (comparison runs only: its small-plane kernels are
-# not run-to-run reproducible, tools/diag_determinism.py)
+# not run-to-run reproducible, tools/diag_determinism.py), 'wino4' the F(4x4,3x3) kernel of csrc/nf_wino4.hip (correct, 2-4e-6
+# accurate, but 1.7x slower than F(2x2) in its present form: never chosen automatically)
 CONV3X3 = os.environ.get('NERFOOL_CONV3X3', 'auto')
 _CONV_CHOICE = {}
 
@@ -248,6 +249,16 @@ def _wino_records(conv_w, k_per_group):
     return cache[1], cache[2]
 
 
+def _wino4_records(conv_w):
+    """F(4x4,3x3) records (csrc/nf_wino4.hip; NERFOOL_CONV3X3=wino4 only), kept on the weight tensor"""
+    key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
+    cache = getattr(conv_w, '_nf_wino4', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.wino4_pack(conv_w, False, conv_w.device), ops.wino4_pack(conv_w, True, conv_w.device))
+        conv_w._nf_wino4 = cache
+    return cache[1], cache[2]
+
+
 def _conv3x3(tape, inp, w, sink):
     """3x3 stride-1 convolution on a pre-padded activation (padding 0) and its backward-data pass"""
     c_out, c_in = w.shape[0], w.shape[1]
@@ -257,6 +268,8 @@ def _conv3x3(tape, inp, w, sink):
         fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[0], inp, c_out, 0, k_per_group=32)
     if CONV3X3 == 'miopen':
         fwd['miopen'] = lambda: _aten.convolution(inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+    if CONV3X3 == 'wino4':
+        fwd['wino4'] = lambda: ops.conv3x3_wino4(_wino4_records(w)[0], inp, c_out, 0)
     out = _Slot(fwd[_pick(('f', c_in, c_out) + tuple(inp.shape), fwd, timed)]())
 
     def bwd():
@@ -267,6 +280,8 @@ def _conv3x3(tape, inp, w, sink):
         if CONV3X3 == 'miopen':
             cand['miopen'] = lambda: _aten.convolution_backward(g_out, inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                                 [True, False, False])[0]
+        if CONV3X3 == 'wino4':
+            cand['wino4'] = lambda: ops.conv3x3_wino4(_wino4_records(w)[1], g_out, c_in, 2)
         sink(cand[_pick(('b', c_in, c_out) + tuple(inp.shape), cand, timed)]())
         out.g = None
     tape.append(bwd)

@@ -568,6 +568,32 @@ def conv_s2_bwd(records, dy, c_in, ks, Hi, Wi):
     return dx
 
 
+def wino4_pack(weight, backward, device):
+    """weight [c_out, c_in, 3, 3] -> Winograd F(4x4,3x3)-domain MFMA records (backward: the backward-data convolution)"""
+    L = _lib.lib()
+    w = weight.detach().to('cpu', torch.float32).contiguous()
+    c_out, c_in = w.shape[0], w.shape[1]
+    n_out, n_in = (c_in, c_out) if backward else (c_out, c_in)
+    out = torch.empty(L.nf_wino4_pack_floats(n_out, n_in), dtype=torch.float32)
+    _lib.check(L.nf_wino4_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), out.data_ptr()), 'nf_wino4_pack')
+    return out.to(device)
+
+
+def conv3x3_wino4(records, x, c_out, pad):
+    """conv3x3_wino in F(4x4,3x3) form (same arguments, records from wino4_pack)"""
+    _f32(x, 'x')
+    if x.stride(3) != 1:
+        x = x.contiguous()
+    N, c_in, Hi, Wi = x.shape
+    Ho, Wo = Hi - 2 + 2 * pad, Wi - 2 + 2 * pad
+    y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
+    xs, ys = x.stride(), y.stride()
+    with prof.launch('nf_conv3x3_wino', x, n_img=N, c_in=c_in, c_out=c_out, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, m=4):
+        _lib.check(_lib.lib().nf_conv3x3_wino4(_ptr(records), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y), ys[0], ys[1], ys[2], Ho, Wo,
+                                               N, c_in, c_out, _stream(x)), 'nf_conv3x3_wino4')
+    return y
+
+
 def wino_pack(weight, backward, device, k_per_group=None):
     """weight [c_out, c_in, 3, 3] -> Winograd-domain MFMA records (backward: the backward-data convolution);
     k_per_group: output channels per workgroup, 64 or 32 (default wino_group)"""

@@ -1114,3 +1114,23 @@ def check_pad_glue(dev):
         want, = torch.autograd.grad(yp, xs, gy.double())
         got = ops.upsample2x_pad_bwd(gy.to(dev), h, w, pad)
         assert_close(got, want, 1e-5, 1e-5 * float(want.abs().max()), 'upsample + pad backward %dx%d pad %d' % (h, w, pad))
+
+
+def check_conv3x3_wino4(dev, shapes=None):
+    """csrc/nf_wino4.hip (Winograd F(4x4,3x3), forward on pre-padded input and backward-data) against a float64 CPU convolution:
+    ragged tile counts and channel counts; error budget 3e-5 of full scale (F(4x4) in fp32: 2-4e-6 typical)."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(13)
+    shapes = shapes or ((1, 8, 32, 18, 34), (2, 64, 64, 21, 37), (2, 20, 40, 9, 13), (1, 4, 32, 5, 6), (1, 128, 96, 35, 70))
+    for (N, cin, cout, H, W) in shapes:
+        w = torch.randn(cout, cin, 3, 3, generator=gen) * 0.1
+        x = torch.randn(N, cin, H, W, generator=gen)
+        g = torch.randn(N, cout, H, W, generator=gen)
+        rf, rb = ops.wino4_pack(w, False, dev), ops.wino4_pack(w, True, dev)
+        ref = F.conv2d(x.double(), w.double())
+        gref = F.conv_transpose2d(g.double(), w.double())
+        y = ops.conv3x3_wino4(rf, x.to(dev), cout, 0)
+        dx = ops.conv3x3_wino4(rb, g.to(dev), cin, 2)
+        ef = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
+        eb = float((dx.cpu().double() - gref).abs().max() / gref.abs().max())
+        assert ef <= 3e-5 and eb <= 3e-5, ('wino4', N, cin, cout, H, W, ef, eb)

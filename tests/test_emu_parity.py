@@ -69,6 +69,10 @@ def test_pad_glue():
     pc.check_pad_glue('cpu')
 
 
+def test_conv3x3_wino4():
+    pc.check_conv3x3_wino4('cpu', shapes=((1, 8, 32, 18, 34), (1, 20, 40, 9, 13)))
+
+
 def test_fused_cnn_glue():
     pc.check_fused_cnn_glue('cpu')
 

@@ -61,6 +61,10 @@ def test_pad_glue():
     pc.check_pad_glue('cuda')
 
 
+def test_conv3x3_wino4():
+    pc.check_conv3x3_wino4('cuda')
+
+
 def test_fused_cnn_glue():
     pc.check_fused_cnn_glue('cuda')
 

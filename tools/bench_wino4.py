@@ -1,0 +1,49 @@
+"""F(4x4,3x3) (csrc/nf_wino4.hip) against F(2x2,3x3) (csrc/nf_wino.hip) on the stride-1 3x3 layers of the ResUNet at BASELINE config 2
+(4 images), forward and backward-data; accuracy against a float64 CPU convolution on a crop.  usage: python tools/bench_wino4.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+from nerfool_amd import ops
+
+
+def timed(fn, n=10):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3, out
+
+
+gen = torch.Generator().manual_seed(1)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+for (ci, co, H, W) in ((64, 64, 189, 252), (128, 128, 95, 126), (256, 256, 48, 63), (256, 128, 96, 126), (128, 64, 192, 252)):
+    w = (torch.randn(co, ci, 3, 3, generator=gen) * 0.05).cuda()
+    x = torch.randn(N, ci, H + 2, W + 2, generator=gen).cuda()
+    gy = torch.randn(N, co, H, W, generator=gen).cuda()
+    r4f, r4b = ops.wino4_pack(w, False, 'cuda'), ops.wino4_pack(w, True, 'cuda')
+    best2f = best2b = 1e9
+    for kg in (64, 32):
+        if co % kg == 0:
+            rf = ops.wino_pack(w, False, 'cuda', kg)
+            best2f = min(best2f, timed(lambda: ops.conv3x3_wino(rf, x, co, 0, k_per_group=kg))[0])
+        if ci % kg == 0:
+            rb = ops.wino_pack(w, True, 'cuda', kg)
+            best2b = min(best2b, timed(lambda: ops.conv3x3_wino(rb, gy, ci, 2, k_per_group=kg))[0])
+    t4f, y4 = timed(lambda: ops.conv3x3_wino4(r4f, x, co, 0))
+    t4b, d4 = timed(lambda: ops.conv3x3_wino4(r4b, gy, ci, 2))
+    xc = x[:1, :, :40, :70].cpu().double()
+    ref = F.conv2d(xc, w.cpu().double())
+    ef = float((ops.conv3x3_wino4(r4f, x[:1, :, :40, :70].contiguous(), co, 0).cpu().double() - ref).abs().max() / ref.abs().max())
+    gc = gy[:1, :, :38, :68].contiguous()
+    gref = F.conv_transpose2d(gc.cpu().double(), w.cpu().double())
+    eb = float((ops.conv3x3_wino4(r4b, gc, ci, 2).cpu().double() - gref).abs().max() / gref.abs().max())
+    fl = 2.0 * N * co * ci * 9 * H * W
+    print('%3d -> %3d at %3dx%-3d: fwd F(2x2) %6.1f us  F(4x4) %6.1f us (%.0f TFLOP/s direct-equivalent) | bwd-data F(2x2) %6.1f us  F(4x4) %6.1f us | '
+          'err fwd %.1e bwd %.1e' % (ci, co, H, W, best2f, t4f, fl / t4f / 1e6, best2b, t4b, ef, eb), flush=True)
