@@ -14,7 +14,7 @@
 // wave, the row half (6 waves -> 4 output rows) through LDS in two rounds of 8 accumulator registers, 16-byte stores.
 // Staging in the style of csrc/nf_conv_s2.hip: 8-channel chunks (4 k-steps); the next chunk's window is fetched into registers
 // under the current chunk's matrix-core work and committed behind one barrier pair; the weight records go from L2 straight into
-// registers one k-step ahead (a lane needs exactly one dword per product); two workgroups (12 waves) per CU.  fp32 error of F(4x4): 2-4e-6 of full scale (F(2x2): 2e-7) -- inside every tolerance of the parity tests;
+// registers one k-step ahead (a lane needs exactly one dword per product).  fp32 error of F(4x4): 2-4e-6 of full scale (F(2x2): 2e-7) -- inside every tolerance of the parity tests;
 // chosen per layer shape against the F(2x2) kernel by the executor's one-off timing.
 #include "nf_common.h"
 
@@ -25,7 +25,13 @@ typedef float q4u __attribute__((ext_vector_type(4), aligned(4)));
 #define W4_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 __host__ __device__ constexpr int w4_nidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+#ifndef W4_CC
 #define W4_CC 8             // input channels per chunk (4 k-steps)
+#endif
+#ifndef W4_OCC
+#define W4_OCC 2            // waves per SIMD the register allocation aims at.  3 (two 6-wave workgroups per CU) needs <= 168 registers:
+                            // 12 vector + 41 scalar spills and 141 us on the 64 -> 64 layer; 2 (one workgroup per CU, no spills): 116 us
+#endif
 #define W4_WR 18            // window rows of a 16-row output block
 #define W4_WC 34            // window columns of a 32-column output block
 #define W4_WS 36            // LDS row stride of the window
@@ -87,7 +93,7 @@ __device__ __forceinline__ int w4_uniform(int v) {        // wave-uniform value 
 #endif
 }
 
-__global__ void __launch_bounds__(384, 3) k_wino4(const float* __restrict__ rec, const float* __restrict__ x, W4Tensor xi, int Hi, int Wi, int pad,
+__global__ void __launch_bounds__(384, W4_OCC) k_wino4(const float* __restrict__ rec, const float* __restrict__ x, W4Tensor xi, int Hi, int Wi, int pad,
                                                   float* __restrict__ y, W4Tensor yo, int Ho, int Wo, int C, int K, int groups,
                                                   int tiles_x, int tiles_y) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -182,7 +188,7 @@ __global__ void __launch_bounds__(384, 3) k_wino4(const float* __restrict__ rec,
     wp += 36 * 64;
 
 #ifndef W4_PREFETCH
-#define W4_PREFETCH 0
+#define W4_PREFETCH 1          // next chunk's window fetched into registers under this chunk's products (125 -> 116 us at W4_OCC 2)
 #endif
     if (W4_PREFETCH) fetch(0);
     for (int ch = 0; ch < chunks; ++ch) {

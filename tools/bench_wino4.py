@@ -5,7 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F
-from nerfool_amd import ops
+from nerfool_amd import _lib, ops
+if os.environ.get('NF_VARIANT_LIB'):
+    _lib.use_library_for_tests(os.environ['NF_VARIANT_LIB'], emulated=False)
 
 
 def timed(fn, n=10):
