@@ -76,6 +76,15 @@ int nf_pixel_mask(const float* mask, int64_t n_pts, int n_views, uint8_t* pixel_
 int nf_project_gather_bwd(const float* xyz, int64_t n_pts, const float* cam_ws, int n_views, int H, int W,
                           const float* d_rgb_feat, int C, int Hf, int Wf, int64_t fs_v, int64_t fs_c, int64_t fs_h,
                           int64_t fs_w, float* d_featmap, nf_stream_t stream);
+/* deterministic (sorted / segmented) form of nf_project_gather_bwd: no float atomics, bitwise reproducible.  Two calls around a
+ * STABLE ascending sort of `keys` the caller performs (its permutation as int64): keys / weights [n_pts * V * 4] per bilinear tap
+ * (key = (v * Hf + y) * Wf + x, 0x7fffffff outside the map); then every feature-map pixel that received a tap is written once
+ * with its contributions summed in sorted order.  d_featmap must be zero-initialised. */
+int nf_project_gather_keys(const float* xyz, int64_t n_pts, const float* cam_ws, int n_views, int Hf, int Wf, int* keys, float* weights,
+                           nf_stream_t stream);
+int nf_project_gather_bwd_sorted(const int* sorted_keys, const int64_t* perm, const float* weights, int64_t n_taps,
+                                 const float* d_rgb_feat, int C, int Hf, int Wf, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
+                                 float* d_featmap, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a4/a5  IBRNet.forward (+ MultiHeadAttention)      ref: ibrnet/mlp_network.py:222-274, :69-119, :23-43

@@ -30,6 +30,8 @@ _PROTOTYPES = {
     'nf_pixel_mask': (c_int, [_P, c_int64, c_int, _P, _P]),
     'nf_project_gather_bwd': (c_int, [_P, c_int64, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int64, c_int64,
                                       c_int64, c_int64, _P, _P]),
+    'nf_project_gather_keys': (c_int, [_P, c_int64, _P, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_project_gather_bwd_sorted': (c_int, [_P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, _P, _P]),
     'nf_ibrnet_blob_floats': (c_int64, []),
     'nf_ibrnet_blob_entry': (c_int, [c_int, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int),
                                      POINTER(c_int)]),

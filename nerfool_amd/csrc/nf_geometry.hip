@@ -280,6 +280,76 @@ extern "C" int nf_project_gather_bwd(const float* xyz, int64_t n_pts, const floa
     return 0;
 }
 
+// ---- deterministic form of the scatter (opt-in): keys -> stable sort by feature-map pixel (host side: torch.sort) -> one
+// 32-lane group per pixel segment sums its contributions in sorted order.  No atomics: bitwise reproducible run to run.
+__global__ void __launch_bounds__(256) k_project_gather_keys(const float* __restrict__ xyz, int64_t n_pts, const float* __restrict__ cam_ws,
+                                                             int V, int Hf, int Wf, int* __restrict__ keys, float* __restrict__ wts) {
+    int64_t pv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pv >= n_pts * V) return;
+    int64_t n = pv / V;
+    int v = (int)(pv - n * V);
+    const float* cam = cam_ws + (int64_t)v * NF_CAM_STRIDE;
+    const float* qc = cam_ws + (int64_t)V * NF_CAM_STRIDE;
+    float px, py;
+    bool front;
+    nf_project_point(cam, xyz[n * 3 + 0], xyz[n * 3 + 1], xyz[n * 3 + 2], px, py, front);
+    NfTaps tf = nf_bilinear_taps(px, py, qc[0], qc[1], Hf, Wf);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int xx = tf.x0 + (t & 1), yy = tf.y0 + (t >> 1);
+        keys[pv * 4 + t] = tf.in[t] ? (v * Hf + yy) * Wf + xx : 0x7fffffff;      // taps outside the map sort to the end
+        wts[pv * 4 + t] = tf.w[t];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_project_gather_bwd_sorted(const int* __restrict__ skeys, const int64_t* __restrict__ perm,
+                                                                   const float* __restrict__ wts, int64_t n_taps,
+                                                                   const float* __restrict__ d_rgb_feat, int C, int Hf, int Wf,
+                                                                   int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
+                                                                   float* __restrict__ d_featmap) {
+    int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = gid / NF_SUB_BWD;
+    int sub = (int)(gid - i * NF_SUB_BWD);
+    if (i >= n_taps) return;
+    const int key = skeys[i];
+    if (key == 0x7fffffff || (i > 0 && skeys[i - 1] == key)) return;      // not the head of a pixel's segment
+    const int xx = key % Wf, yy = (key / Wf) % Hf, v = key / (Wf * Hf);
+    for (int c = sub; c < C; c += NF_SUB_BWD) {
+        float acc = 0.f;
+        for (int64_t j = i; j < n_taps && skeys[j] == key; ++j) {
+            const int64_t src = perm[j];                                       // tap index: (point, view) * 4 + tap
+            acc = fmaf(wts[src], d_rgb_feat[(src >> 2) * (int64_t)(3 + C) + 3 + c], acc);
+        }
+        d_featmap[(int64_t)v * fs_v + (int64_t)c * fs_c + (int64_t)yy * fs_h + (int64_t)xx * fs_w] = acc;
+    }
+}
+
+/* Deterministic variant of nf_project_gather_bwd in two calls around a stable sort the caller performs:
+ *   nf_project_gather_keys: keys [n_pts * V * 4] int32 (feature-map pixel index (v * Hf + y) * Wf + x of each bilinear tap,
+ *     0x7fffffff for taps outside the map) and weights [n_pts * V * 4]
+ *   nf_project_gather_bwd_sorted: sorted keys + the sort's permutation (int64) -> d_featmap (zero-initialised by the caller;
+ *     every touched pixel is written once, summed in sorted order) */
+extern "C" int nf_project_gather_keys(const float* xyz, int64_t n_pts, const float* cam_ws, int n_views, int Hf, int Wf, int* keys,
+                                      float* weights, nf_stream_t stream) {
+    NF_REQUIRE(n_pts >= 0 && n_views >= 1 && Hf >= 1 && Wf >= 1 && (int64_t)n_views * Hf * Wf < 0x7fffffff, "nf_project_gather_keys: bad sizes");
+    if (n_pts == 0) return 0;
+    hipLaunchKernelGGL(k_project_gather_keys, dim3(nf_blocks(n_pts * n_views, 256)), dim3(256), 0, (hipStream_t)stream, xyz, n_pts, cam_ws,
+                       n_views, Hf, Wf, keys, weights);
+    NF_LAUNCH_CHECK("nf_project_gather_keys");
+    return 0;
+}
+
+extern "C" int nf_project_gather_bwd_sorted(const int* sorted_keys, const int64_t* perm, const float* weights, int64_t n_taps,
+                                            const float* d_rgb_feat, int C, int Hf, int Wf, int64_t fs_v, int64_t fs_c, int64_t fs_h,
+                                            int64_t fs_w, float* d_featmap, nf_stream_t stream) {
+    NF_REQUIRE(n_taps >= 0 && C >= 1 && Hf >= 1 && Wf >= 1, "nf_project_gather_bwd_sorted: bad sizes");
+    if (n_taps == 0) return 0;
+    hipLaunchKernelGGL(k_project_gather_bwd_sorted, dim3(nf_blocks(n_taps * NF_SUB_BWD, 256)), dim3(256), 0, (hipStream_t)stream, sorted_keys,
+                       perm, weights, n_taps, d_rgb_feat, C, Hf, Wf, fs_v, fs_c, fs_h, fs_w, d_featmap);
+    NF_LAUNCH_CHECK("nf_project_gather_bwd_sorted");
+    return 0;
+}
+
 // pixel_mask[n] = (sum_v mask[n,v]) > 1        ref: ibrnet/render_ray.py:210
 __global__ void __launch_bounds__(256) k_pixel_mask(const float* __restrict__ mask, int64_t n_pts, int V,
                                                     uint8_t* __restrict__ out) {

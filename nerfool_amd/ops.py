@@ -97,6 +97,11 @@ def project_gather_fwd(xyz, cam_ws, src_rgbs, featmaps, want_pix=False):
     return rgb_feat, ray_diff, mask, pix
 
 
+# 'atomic' (default): float atomics, summation order varies run to run (last-bit differences in d featmaps);
+# 'deterministic': keys -> stable sort by feature-map pixel -> segmented sum in sorted order (bitwise reproducible, ~3x the time)
+GATHER_BWD = __import__('os').environ.get('NERFOOL_GATHER_BWD', 'atomic')
+
+
 def project_gather_bwd(xyz, cam_ws, V, H, W, d_rgb_feat, feat_shape):
     """Returns d_featmaps [V,C,Hf,Wf] stored channels-last (one 128-byte record per pixel for C=32)."""
     xyz = _c(xyz, 'xyz')
@@ -105,6 +110,17 @@ def project_gather_bwd(xyz, cam_ws, V, H, W, d_rgb_feat, feat_shape):
     N = xyz.shape[0]
     d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
     sv, sc, sh, sw = d_feat.stride()
+    if GATHER_BWD == 'deterministic':
+        L = _lib.lib()
+        n_taps = N * V * 4
+        keys = torch.empty(n_taps, dtype=torch.int32, device=xyz.device)
+        wts = torch.empty(n_taps, dtype=torch.float32, device=xyz.device)
+        _lib.check(L.nf_project_gather_keys(_ptr(xyz), N, _ptr(cam_ws), V, Hf, Wf, _ptr(keys), _ptr(wts), _stream(xyz)), 'nf_project_gather_keys')
+        skeys, perm = torch.sort(keys, stable=True)
+        with prof.launch('nf_project_gather_bwd_sorted', xyz, n_pts=N, V=V, C=C):
+            _lib.check(L.nf_project_gather_bwd_sorted(_ptr(skeys), _ptr(perm), _ptr(wts), n_taps, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc, sh, sw,
+                                                      _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd_sorted')
+        return d_feat
     with prof.launch('nf_project_gather_bwd', xyz, n_pts=N, V=V, C=C):
         _lib.check(_lib.lib().nf_project_gather_bwd(_ptr(xyz), N, _ptr(cam_ws), V, H, W, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc,
                                                     sh, sw, _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd')

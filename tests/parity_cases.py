@@ -406,7 +406,7 @@ def check_pseudo_gt(dev):
     assert_close(a2.last_loss, gx.np('pseudo/loss'), 1e-3, 1e-6, 'use_unseen_views loss')
 
 
-def check_universal_trajectory(dev):
+def check_universal_trajectory(dev, steps=None):
     """The reference's universal loop over two target views sharing the perturbed sources (eval_adv.py:634-740; adv_iters = 3
     -> 4 steps), teacher-forced: from the reference's delta_t reproduce loss_t and grad_t, from its grad_t reproduce
     delta_{t+1} (Adam-ascent, StepLR(2, 0.5), both clamps); then the free-running loop draws the recorded pixel picks."""
@@ -422,7 +422,7 @@ def check_universal_trajectory(dev):
     deltas = [g.t('in/delta0', dev)] + [gx.t('universal/delta_%d' % (t + 1), dev) for t in range(n_steps)]
     attack = EA.PGDAttack(args, model, Projector(dev), src, delta=deltas[0].clone().requires_grad_(True))
     cfg = dict(N_samples=args.N_samples, N_importance=args.N_importance, inv_uniform=True, white_bkgd=False)
-    for t in range(n_steps):
+    for t in range(n_steps if steps is None else steps):
         attack.delta.data.copy_(deltas[t])
         view = views[t % 2]
         run = lambda: attack.gradient(view, select_inds=picks[t], lookahead=False)
@@ -437,6 +437,8 @@ def check_universal_trajectory(dev):
         assert_close(attack.last_loss, gx.np('universal/losses')[t], 1e-3, 1e-6, 'universal loss, step %d' % t)
         attack.apply(gx.t('universal/grad_%d' % t, dev))
         assert_close(attack.delta.data, deltas[t + 1], 0, 2e-7, 'delta after universal step %d' % (t + 1))
+    if steps is not None:           # shortened run (CPU stand-in): teacher-forced steps only
+        return
     # free-running: step count and the pixel stream (each step consumes one pick of RandomState(234))
     product_sample_ray.rng.seed(234)
     seen = []
@@ -1134,3 +1136,26 @@ def check_conv3x3_wino4(dev, shapes=None):
         ef = float((y.cpu().double() - ref).abs().max() / ref.abs().max())
         eb = float((dx.cpu().double() - gref).abs().max() / gref.abs().max())
         assert ef <= 3e-5 and eb <= 3e-5, ('wino4', N, cin, cout, H, W, ef, eb)
+
+
+def check_gather_bwd_deterministic(dev):
+    """NERFOOL_GATHER_BWD=deterministic (keys -> stable sort -> segmented sum): equals the atomic scatter to rounding and is
+    bitwise identical from run to run."""
+    g = Golden('ibrnet_tiny_invu')
+    cfg = g.stage_cfg()
+    rb = g.ray_batch(dev)
+    cam = ops.camera_setup(rb['camera'], rb['src_cameras'])
+    pts = g.t('coarse/pts', dev).reshape(-1, 3)
+    fm = g.t('in/featmap_coarse', dev)
+    dg = torch.randn(pts.shape[0], cfg['V'], 35, generator=torch.Generator().manual_seed(6)).to(dev)
+    saved = ops.GATHER_BWD
+    try:
+        ops.GATHER_BWD = 'atomic'
+        ref = ops.project_gather_bwd(pts, cam, cfg['V'], cfg['H'], cfg['W'], dg, fm.shape)
+        ops.GATHER_BWD = 'deterministic'
+        a = ops.project_gather_bwd(pts, cam, cfg['V'], cfg['H'], cfg['W'], dg, fm.shape)
+        b = ops.project_gather_bwd(pts, cam, cfg['V'], cfg['H'], cfg['W'], dg, fm.shape)
+    finally:
+        ops.GATHER_BWD = saved
+    assert torch.equal(a, b), 'the sorted form must be bitwise reproducible'
+    assert_close(a, ref, 1e-5, 1e-5 * float(ref.abs().max()), 'sorted vs atomic scatter')

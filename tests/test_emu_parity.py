@@ -73,6 +73,10 @@ def test_conv3x3_wino4():
     pc.check_conv3x3_wino4('cpu', shapes=((1, 8, 32, 18, 34), (1, 20, 40, 9, 13)))
 
 
+def test_gather_bwd_deterministic():
+    pc.check_gather_bwd_deterministic('cpu')
+
+
 def test_fused_cnn_glue():
     pc.check_fused_cnn_glue('cpu')
 
@@ -90,7 +94,7 @@ def test_pseudo_gt():
 
 
 def test_universal_trajectory():
-    pc.check_universal_trajectory('cpu')
+    pc.check_universal_trajectory('cpu', steps=2)      # both target views once; the full loop runs on the GPU
 
 
 def test_hybrid_and_sample_pdf():

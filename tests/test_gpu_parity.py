@@ -65,6 +65,10 @@ def test_conv3x3_wino4():
     pc.check_conv3x3_wino4('cuda')
 
 
+def test_gather_bwd_deterministic():
+    pc.check_gather_bwd_deterministic('cuda')
+
+
 def test_fused_cnn_glue():
     pc.check_fused_cnn_glue('cuda')
 
