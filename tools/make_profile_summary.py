@@ -93,6 +93,13 @@ def main():
     md.append('`%.2f ms/step` (`%.0f rays/s`), dtype %s.  %s.  `%s_bench_c5_fp32.json`: the same workload with fp32 rows.\n'
               % (c5['ms_per_step'], c5['value'], c5['dtype'],
                  ', '.join('%s %.3f ms (%.3f of its peak)' % (kk, v['mean_ms'], v['frac']) for kk, v in ck.items() if 'ibrnet' in kk), rnd))
+    try:
+        lr = load(rnd + '_bench_1000iters_ibrnet.json')
+        md.append('## 1000-iteration attack, end to end\n')
+        md.append('`python3 bench.py --steps 1000 --warmup 3 --extras 0`: %.2f s (`%s_bench_1000iters_ibrnet.json`, %.0f rays/s); the CPU oracle\n'
+                  'extrapolates to %.0f s on the %d host cores.\n' % (lr['ms_per_step'], rnd, lr['value'], 1000 * c['attack_s_per_iter'], c['cores']))
+    except OSError:
+        pass
     md.append('## Other artefacts\n')
     md.append('`%(r)s_grad_budget_before.json` (per-stage gradient error budget against float64 before the ReLU-pattern analysis,\n'
               '`tools/diag_grad_budget.py`), `%(r)s_bench_2rank_gloo_one_gpu_functional.json` (all four multi-GPU forms through gloo on one\n'
