@@ -770,6 +770,16 @@ def check_gnt(case, dev):
     assert_close(out, ref_rgb, 1e-3, 1e-3 * float(np.abs(ref_rgb).max()), 'GNT rgb (saving path)')
     mine, = torch.autograd.grad(out, x, d_rgb.to(dev))
     assert_close(mine, ref_grad, 5e-3, 1e-3 * float(ref_grad.abs().max()), 'GNT d rgb / d rgb_feat', frac_ok=1e-3)
+    # norm-wise against the GNT oracle in float64 (north_star: 1e-3)
+    d64 = lambda t: t.detach().cpu().double()
+    p64 = {k: d64(v) for k, v in p.items()}
+    x64 = d64(g.t('net_in/rgb_feat')).requires_grad_(True)
+    o64 = gr.gnt_forward(p64, x64, d64(g.t('net_in/ray_diff')), d64(g.t('net_in/mask')), d64(g.t('net_in/pts')), d64(g.t('in/ray_d')), depth)
+    g64, = torch.autograd.grad(o64, x64, d_rgb.double())
+    err = float((d64(mine) - g64).norm() / g64.norm())
+    floor = float((ref_grad.double() - g64).norm() / g64.norm())
+    print('[grad parity] %s GNT d rgb / d rgb_feat: rel-L2 vs float64 %.3e (oracle fp32: %.3e)' % (case, err, floor))
+    assert err <= 1e-3, 'GNT d rgb / d rgb_feat rel-L2 %.3e vs float64' % err
     # renderer + loss + gradient to the feature map
     fm = g.t('in/featmap', dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     rb = {'ray_o': g.t('in/ray_o', dev), 'ray_d': g.t('in/ray_d', dev), 'rgb': g.t('in/gt_rgb', dev),
@@ -791,6 +801,15 @@ def check_gnt(case, dev):
     grad, = torch.autograd.grad(loss, fm)
     gref = g.np('grad/featmap')
     assert_close(grad, gref, 1e-2, 2e-3 * float(np.abs(gref).max()), 'GNT d loss / d featmap', frac_ok=2e-3)
+    # ... and norm-wise against the float64 GNT oracle through the whole renderer
+    fm64 = d64(g.t('in/featmap')).requires_grad_(True)
+    rb64 = {k: d64(v) for k, v in rb.items()}
+    ret64 = gr.render_rays(rb64, p64, (fm64, fm64), S, depth, inv_uniform=True, det=True)
+    gfm64, = torch.autograd.grad(gr.criterion(ret64['outputs_coarse'], rb64), fm64)
+    err = float((d64(grad) - gfm64).norm() / gfm64.norm())
+    print('[grad parity] %s GNT d loss / d featmap: rel-L2 vs float64 %.3e (reference fp32: %.3e)'
+          % (case, err, float((torch.from_numpy(gref).double() - gfm64).norm() / gfm64.norm())))
+    assert err <= 1e-3, 'GNT d loss / d featmap rel-L2 %.3e vs float64' % err
 
 
 def check_gnt_alpha(dev, kernel_path=None):
