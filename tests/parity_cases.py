@@ -1178,3 +1178,41 @@ def check_gather_bwd_deterministic(dev):
         ops.GATHER_BWD = saved
     assert torch.equal(a, b), 'the sorted form must be bitwise reproducible'
     assert_close(a, ref, 1e-5, 1e-5 * float(ref.abs().max()), 'sorted vs atomic scatter')
+
+
+def check_full_size_feature_net(dev, H=756, W=1008):
+    """The feature CNN at BASELINE config 2's full size (one 756x1008 image) against the float64 oracle: forward <= 1e-4 relative
+    L2, backward (VJP of a random upstream gradient, oracle on the ReLU pattern of this evaluation) <= 1e-3 -- every hand-written
+    convolution / glue kernel at the shapes the benchmark runs."""
+    from nerfool_amd.ibrnet import feature_network
+    torch.manual_seed(0)
+    net = ResUNet(coarse_out_ch=32, fine_out_ch=32)
+    net.load_state_dict(fnet.random_resunet_state(123), strict=True)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    net = net.to(dev).eval()
+    gen = torch.Generator().manual_seed(5)
+    img = torch.rand(1, H, W, 3, generator=gen)
+    x = img.to(dev).permute(0, 3, 1, 2).requires_grad_(True)          # channels-last storage, as the attack hands it over
+    feature_network.TRACE_RELU = trace = []
+    try:
+        fc, ff = net(x)
+    finally:
+        feature_network.TRACE_RELU = None
+    up = torch.randn(1, 64, fc.shape[2], fc.shape[3], generator=gen)
+    gx, = torch.autograd.grad([fc, ff], x, [up[:, :32].to(dev), up[:, 32:].to(dev)])
+    masks = [(t > 0).cpu() for t in trace]
+    sd64 = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    x64 = img.permute(0, 3, 1, 2).double().requires_grad_(True)
+    tr = fnet.ReluTrace(masks)
+    c64, f64 = fnet.resunet_forward(sd64, x64, trace=tr)
+    g64, = torch.autograd.grad([c64, f64], x64, [up[:, :32].double(), up[:, 32:].double()])
+    n_flip = sum(int(((pre > 0) != m).sum()) for pre, m in zip(tr.pre, masks))
+    n_units = sum(m.numel() for m in masks)
+    rel = lambda a, b: float((a.detach().cpu().double() - b.detach()).norm() / b.detach().norm())
+    ef = rel(torch.cat([fc, ff], 1), torch.cat([c64, f64], 1))
+    eb = rel(gx, g64)
+    print('[full size] ResUNet %dx%d: forward rel-L2 vs float64 %.2e, backward %.2e (ReLU units decided differently than float64: %d of %d)'
+          % (H, W, ef, eb, n_flip, n_units))
+    assert ef <= 1e-4 and eb <= 1e-3
+    assert n_flip <= 2 + 1e-5 * n_units

@@ -104,6 +104,10 @@ def test_winograd_full_size_layers_repeated():
             assert torch.equal(alone, first[0][3:4]), 'an image must not depend on its batch neighbours'
 
 
+def test_full_size_feature_net_vs_float64():
+    pc.check_full_size_feature_net('cuda')
+
+
 def test_fused_resunet_matches_module_graph():
     pc.check_fused_resunet('cuda')
 
