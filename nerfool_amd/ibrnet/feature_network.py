@@ -417,16 +417,17 @@ def _upsample_pad(tape, a, pad):
     return up
 
 
-def _join_pad(tape, enc, dec, pad):
-    """reflect_pad(cat([dec, zero-pad(enc)], dim=1), pad) written slice by slice into one buffer (no torch.cat), and the
-    backward folded slice by slice out of the convolution's input gradient (dec: _Act with pad 0, enc: _Act)."""
-    e, d = enc.interior(), dec.interior()
-    dy, dx = d.shape[2] - e.shape[2], d.shape[3] - e.shape[3]
-    top, left = dy // 2, dx // 2
-    N, cd, H, W = d.shape
+def _join_pad(tape, enc, t, norm, pad):
+    """reflect_pad(cat([ELU(IN(t)), zero-pad(enc)], dim=1), pad) written slice by slice into one buffer (no torch.cat, no copy
+    of the decoder half: its norm + activation kernel writes straight into its channel slice), and the backward read slice by
+    slice out of the convolution's input gradient (the decoder half's fold happens inside its norm backward).
+    t: _Slot of the decoder convolution's output, enc: _Act."""
+    e = enc.interior()
+    N, cd, H, W = t.v.shape
     ce, eh, ew = e.shape[1], e.shape[2], e.shape[3]
-    buf = torch.empty(N, cd + ce, H + 2 * pad, W + 2 * pad, dtype=d.dtype, device=d.device)
-    ops.in_act_pad_fwd(d, None, None, None, ops.ACT_NONE, pad, out=buf, c_off=0)
+    top, left = (H - eh) // 2, (W - ew) // 2
+    buf = torch.empty(N, cd + ce, H + 2 * pad, W + 2 * pad, dtype=t.v.dtype, device=t.v.device)
+    _, mean, rstd = ops.in_act_pad_fwd(t.v, norm.weight, norm.bias, None, ops.ACT_ELU, pad, eps=norm.eps, out=buf, c_off=0)
     # the encoder tensor is read where it lies (interior view of its padded activation) and lands zero-extended to H x W at
     # (top, left), reflect-padded, in its channel slice of the buffer: no F.pad copy, no separate padding pass
     ops.pad_gather_fwd(e, H, W, pad, top, left, out=buf[:, cd:])
@@ -434,8 +435,9 @@ def _join_pad(tape, enc, dec, pad):
 
     def bwd():
         g = out.gp
-        dd, _ = ops.in_act_pad_bwd(g[:, :cd], None, None, None, None, None, None, ops.ACT_NONE, pad, False, shape=(N, cd, H, W))
-        dec.add_i(dd)
+        dx, _ = ops.in_act_pad_bwd(g[:, :cd], None, None, t.v, norm.weight, mean, rstd, ops.ACT_ELU, pad, False, beta=norm.bias,
+                                   shape=(N, cd, H, W))
+        t.add(dx)
         enc.add_i(ops.pad_gather_bwd(g[:, cd:], H, W, pad, eh, ew, top, left))
         out.gp = None
     tape.append(bwd)
@@ -475,8 +477,7 @@ def fused_forward(net, x, need_grad=True):
     def decoder_stage(src, up, iconv, enc):
         up_p = _upsample_pad(tape, src, 1)
         t = _conv(tape, up_p.yp, up.conv.conv.weight, 1, up_p.add_p)
-        dec = _fuse(tape, t, up.conv.bn, None, ops.ACT_ELU, 0)
-        jp = _join_pad(tape, enc, dec, 1)
+        jp = _join_pad(tape, enc, t, up.conv.bn, 1)
         t = _conv(tape, jp.yp, iconv.conv.weight, 1, jp.add_p)
         return _fuse(tape, t, iconv.bn, None, ops.ACT_ELU, 0)
 

@@ -662,12 +662,13 @@ def check_fused_cnn_glue(dev):
         wgt = torch.randn(co, ci, 3, 3, generator=gen) * 0.2
         xin = torch.randn(N, ci, H + 2, W + 2, generator=gen)
         ref = F.conv2d(xin, wgt)
-        got = ops.conv3x3_wino(ops.wino_pack(wgt, False, dev), xin.to(dev), co, 0)
-        assert_close(got, ref, 1e-4, 1e-4 * float(ref.abs().max()), 'Winograd 3x3 forward')
         gy = torch.randn(ref.shape, generator=gen)
         gref = F.conv_transpose2d(gy, wgt)
-        ggot = ops.conv3x3_wino(ops.wino_pack(wgt, True, dev), gy.to(dev), ci, 2)
-        assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'Winograd 3x3 backward-data')
+        for kpg in (64, 32):        # both workgroup widths; the CPU stand-in build walks several items per workgroup (WN_GRID_DIV)
+            got = ops.conv3x3_wino(ops.wino_pack(wgt, False, dev, kpg), xin.to(dev), co, 0, k_per_group=kpg)
+            assert_close(got, ref, 1e-4, 1e-4 * float(ref.abs().max()), 'Winograd 3x3 forward (%d per group)' % kpg)
+            ggot = ops.conv3x3_wino(ops.wino_pack(wgt, True, dev, kpg), gy.to(dev), ci, 2, k_per_group=kpg)
+            assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'Winograd 3x3 backward-data (%d per group)' % kpg)
     # 1x1 convolutions as MFMA GEMMs over the pixels: subsampled / strided input, bias, channels-last output, backward-data
     for (N, ci, co, H, W, sub, cl) in ((2, 64, 64, 5, 7, False, True), (1, 64, 128, 6, 9, True, False), (1, 32, 40, 4, 5, False, False)):
         wgt = torch.randn(co, ci, 1, 1, generator=gen) * 0.2
