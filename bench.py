@@ -418,7 +418,9 @@ def main():
         from nerfool_amd.ibrnet.render_image import render_single_image
         rays = sampler.get_all()
         t_img = []
-        for _ in range(2):
+        ret = None
+        for _ in range(3):
+            ret = None          # the page-locked host tensors of the previous image go back to torch's host allocator
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             ret = render_single_image(ray_sampler=sampler, ray_batch=rays, model=model, projector=projector, chunk_size=4096,
@@ -428,7 +430,7 @@ def main():
             t_img.append(time.perf_counter() - t0)
         n_rays = a.height * a.width
         extra_legs['render_single_image'] = {'image': '%dx%d' % (a.height, a.width), 'chunks': -(-n_rays // 4096), 'samples': '%d+%d' % (a.samples, a.importance),
-                                             'seconds': round(min(t_img), 4), 'rays_per_s': n_rays / min(t_img), 'includes': 'chunk loop, D2H of all six output fields per level, reshape',
+                                             'seconds': round(min(t_img), 4), 'rays_per_s': n_rays / min(t_img), 'includes': 'chunk loop, D2H of all six output fields per level (second stream, page-locked host tensors), reshape',
                                              'rgb_shape': list(ret['outputs_fine']['rgb'].shape)}
         del ret
         # north-star render case: 800x800 scene, 64 samples per ray -- coarse only and 64+64

@@ -1,10 +1,11 @@
 """Full-image rendering for the GNT flavour (gnt/render_image.py:6-130 call surface): chunk loop over the GNT render_rays,
-outputs that the renderer leaves at None (weights / depth without ret_alpha) stay None, chunk results stay in HBM until the
-single device-to-host copy at the end."""
+outputs that the renderer leaves at None (weights / depth without ret_alpha) stay None, chunk results leave for page-locked host
+tensors on a second stream while the next chunk renders (ibrnet/render_image.HostCollector)."""
 from collections import OrderedDict
 
 import torch
 
+from ..ibrnet.render_image import HostCollector
 from .render_ray import render_rays, render_rays_hybrid
 
 _WHOLE = ('camera', 'depth_range', 'src_rgbs', 'src_cameras')
@@ -16,8 +17,8 @@ def render_single_image(ray_sampler, ray_batch, model, projector, chunk_size, N_
     hybrid = args is not None and (getattr(args, 'use_clean_color', False) or getattr(args, 'use_clean_density', False))
     if hybrid:
         assert featmaps_clean is not None
-    parts = {'outputs_coarse': OrderedDict(), 'outputs_fine': OrderedDict()}
     n_rays = ray_batch['ray_o'].shape[0]
+    out = HostCollector(n_rays, ray_batch['ray_o'].device)
     with torch.no_grad():
         for i in range(0, n_rays, chunk_size):
             chunk = OrderedDict((k, v if (k in _WHOLE or v is None) else v[i:i + chunk_size]) for k, v in ray_batch.items())
@@ -27,21 +28,6 @@ def render_single_image(ray_sampler, ray_batch, model, projector, chunk_size, N_
                 ret = render_rays_hybrid(chunk, model, featmaps, featmaps_clean=featmaps_clean, **kw)
             else:
                 ret = render_rays(chunk, model, featmaps, **kw)
-            for level in ('outputs_coarse', 'outputs_fine'):
-                if ret[level] is None:
-                    parts[level] = None
-                    continue
-                for k, v in ret[level].items():
-                    parts[level].setdefault(k, [])
-                    if v is not None:
-                        parts[level][k].append(v)
-    hs = len(range(0, ray_sampler.H, render_stride))
-    ws = len(range(0, ray_sampler.W, render_stride))
-    all_ret = OrderedDict([('outputs_coarse', OrderedDict()), ('outputs_fine', OrderedDict())])
-    for level in ('outputs_coarse', 'outputs_fine'):
-        if parts[level] is None:
-            all_ret[level] = None
-            continue
-        for k, lst in parts[level].items():
-            all_ret[level][k] = torch.cat(lst, dim=0).reshape(hs, ws, -1).squeeze().cpu() if lst else None
+            out.add(i, ret)
+    all_ret = out.finish(len(range(0, ray_sampler.H, render_stride)), len(range(0, ray_sampler.W, render_stride)))
     return all_ret

@@ -560,6 +560,42 @@ def check_evaluate_view(dev):
     assert abs(clean['fine_psnr'] - zero['fine_psnr']) < 1e-3, (clean['fine_psnr'], zero['fine_psnr'])
 
 
+def check_ragged_ray_batches(dev):
+    """Edge sizes of a ray batch: none, one, three rays (a chunk's ragged tail, render_image.py:52-102; an N_rand that leaves a
+    rank without rays).  Shapes for the empty batch; the small batches equal the first rows of a larger batch's
+    result (each ray is rendered independently) and their gradients w.r.t. the feature maps are finite and non-zero."""
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    H, W, V, R, S, N_imp, _, _ = dims
+    src = sampler.get_all()
+    with torch.no_grad():
+        fm = model.feature_net(src['src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
+    rb = sampler.get_all()
+
+    def render(n, featmaps):
+        b = {k: (v[:n] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in rb.items()}
+        return render_rays(ray_batch=b, model=model, projector=Projector(dev), featmaps=featmaps, N_samples=S, inv_uniform=True,
+                           N_importance=N_imp, det=True, white_bkgd=False, args=None, src_ray_batch=src)
+
+    with torch.no_grad():
+        full = render(40, fm)
+        for n in (0, 1, 3):
+            ret = render(n, fm)
+            for level, n_s in (('outputs_coarse', S), ('outputs_fine', S + N_imp)):
+                out = ret[level]
+                assert out['rgb'].shape == (n, 3) and out['depth'].shape == (n,) and out['weights'].shape == (n, n_s), (n, level)
+                if n:
+                    assert_close(out['rgb'], full[level]['rgb'][:n], 1e-5, 1e-6, '%d-ray batch vs a 40-ray batch (%s)' % (n, level))
+                    assert_close(out['weights'], full[level]['weights'][:n], 1e-5, 1e-6, '%d-ray batch weights (%s)' % (n, level))
+    for n in (0, 1):
+        fmg = tuple(f.detach().clone().requires_grad_(True) for f in fm)
+        ret = render(n, fmg)
+        loss = ret['outputs_coarse']['rgb'].sum() + ret['outputs_fine']['rgb'].sum()
+        loss.backward()
+        for f in fmg:
+            assert f.grad is not None and bool(torch.isfinite(f.grad).all())
+            assert bool((f.grad != 0).any()) == (n > 0)
+
+
 def check_hybrid_and_sample_pdf(dev):
     """render_rays_hybrid (clean colour / clean density) and the stand-alone sample_pdf against the reference."""
     from nerfool_amd.synthetic import smooth_featmaps

@@ -97,6 +97,10 @@ def test_universal_trajectory():
     pc.check_universal_trajectory('cpu', steps=2)      # both target views once; the full loop runs on the GPU
 
 
+def test_ragged_ray_batches():
+    pc.check_ragged_ray_batches('cpu')
+
+
 def test_hybrid_and_sample_pdf():
     pc.check_hybrid_and_sample_pdf('cpu')
 
