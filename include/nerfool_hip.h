@@ -258,6 +258,16 @@ int nf_wino_pack(const float* weight_host, int c_out, int c_in, int backward, in
 int nf_conv3x3_wino(const float* records, int k_per_group, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi,
                     int pad, float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out,
                     int tile_blocks, nf_stream_t stream);
+/* The one-pixel border ring of a backward-data pass, g = d(padded input) [N, c_dx, H + 2, W + 2] from dy [N, c_dy, H, W]: the ring
+ * sees one row / column of dy, i.e. four 1-D convolutions -- computed apart so that the Winograd kernel covers an H x W region
+ * with the forward pass's block count (48 x 63: 24 blocks instead of 35) at pad 1 on the output shifted by (1, 1).
+ *   kinds: bit 0 top row, 1 bottom row, 2 left column, 3 right column (columns: rows 1 .. H, and H + 1 too when the bottom row is not
+ *   asked for -- the caller's Winograd region then ends at row H + 1 and the corners are the columns');  records = nf_wino_ring_pack(weight
+ *   [c_dy = c_out][c_dx = c_in][3][3]) (HOST pointers).  ref: the same lines as nf_conv3x3_wino (backward of :28-36, 38-78). */
+int64_t nf_wino_ring_pack_floats(int c_out, int c_in);
+int nf_wino_ring_pack(const float* weight_host, int c_out, int c_in, float* records_host);
+int nf_conv3x3_bwd_ring(const float* ring_records, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int H, int W, float* g,
+                        int64_t gs_n, int64_t gs_c, int64_t gs_h, int n_img, int c_dy, int c_dx, int kinds, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a11/a13  perturbation update             ref: eval/ibrnet/eval_adv.py:28-29, :248-254, :805-839

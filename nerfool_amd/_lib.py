@@ -89,6 +89,10 @@ _PROTOTYPES = {
     'nf_wino_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
     'nf_conv3x3_wino': (c_int, [_P, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int,
                                 c_int, c_int, c_int, c_int, c_int, _P]),
+    'nf_wino_ring_pack_floats': (c_int64, [c_int, c_int]),
+    'nf_wino_ring_pack': (c_int, [_P, c_int, c_int, _P]),
+    'nf_conv3x3_bwd_ring': (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                                    c_int, _P]),
     'nf_in_act_pad_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_int64, c_int64, c_int64, c_int64,
                                   c_int, c_int, _P, c_int64, _P, _P, _P, _P]),
     'nf_in_act_pad_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64,

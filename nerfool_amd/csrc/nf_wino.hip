@@ -414,3 +414,159 @@ extern "C" int nf_conv3x3_wino(const float* records, int k_per_group, const floa
     NF_LAUNCH_CHECK("nf_conv3x3_wino");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The border ring of a backward-data convolution.  d(padded input) = full correlation of d y (H x W) with the rotated weights:
+// (H + 2) x (W + 2) values -- for a 48 x 63 plane that is 7 x 5 output blocks of 8 x 16 where the forward pass of the same layer
+// has 6 x 4: 46 % more matrix work for a ring one pixel wide (measured: 108 us against 69 us, 11 launches per step).  The ring
+// only sees ONE row (column) of d y -- rows Y + a - 2 with Y = 0 leave a = 2 -- so it is four 1-D convolutions of 3 taps:
+//   top    g[k][0][X]     = sum_c sum_b dy[c][0][X + b - 2]     W'[k][c][2][b]      W'[k][c][a][b] = weight[c][k][2 - a][2 - b]
+//   bottom g[k][H + 1][X] = sum_c sum_b dy[c][H - 1][X + b - 2] W'[k][c][0][b]
+//   left   g[k][Y][0]     = sum_c sum_a dy[c][Y + a - 2][0]     W'[k][c][a][2]
+//   right  g[k][Y][W + 1] = sum_c sum_a dy[c][Y + a - 2][W - 1] W'[k][c][a][0]
+// 0.14 GFLOP for layer3: plain vector FMAs (k_wino_ring below).  The host computes the rest -- rows / columns 1 .. -- with nf_conv3x3_wino at pad 1 on the shifted output
+// (nerfool_amd/ops.conv3x3_wino_bwd_split), which also takes the bottom row / right column along when its blocks have room.
+// ---------------------------------------------------------------------------------------------------------------------
+#define WR_KB 64            // output channels per wave (lane = output channel); the packed weights are padded to a multiple of it
+#define WR_WAVES 8          // input-channel split of a workgroup
+
+extern "C" int64_t nf_wino_ring_pack_floats(int c_out, int c_in) { return (int64_t)4 * c_out * 3 * ((c_in + WR_KB - 1) / WR_KB * WR_KB); }
+
+/* HOST: weight [c_out][c_in][3][3] -> ring weights [kind 4][c = c_out][tap 3][k = c_in rounded up to 64] of the backward-data pass */
+extern "C" int nf_wino_ring_pack(const float* weight, int c_out, int c_in, float* out) {
+    const int Kp = (c_in + WR_KB - 1) / WR_KB * WR_KB;
+    for (int kind = 0; kind < 4; ++kind)
+        for (int c = 0; c < c_out; ++c)
+            for (int t = 0; t < 3; ++t)
+                for (int k = 0; k < Kp; ++k) {
+                    // W'[k][c][a][b] = weight[c][k][2 - a][2 - b];  top: a = 2, b = t;  bottom: a = 0, b = t;  left: a = t, b = 2;  right: a = t, b = 0
+                    const int a = kind == 0 ? 2 : (kind == 1 ? 0 : t), b = kind == 2 ? 2 : (kind == 3 ? 0 : t);
+                    out[(((size_t)kind * c_out + c) * 3 + t) * Kp + k] = k < c_in ? weight[(((size_t)c * c_in + k) * 3 + (2 - a)) * 3 + (2 - b)] : 0.f;
+                }
+    return 0;
+}
+
+#define WR_POS 8            // ring positions per workgroup
+#define WR_NI 1             // images per workgroup (more would share the weight loads; one keeps every CU busy at 4 images: measured 16 us against 19 at two, 30 at four)
+#define WR_XS 12            // floats per (image, channel) line piece in LDS: WR_POS + 2 taps, padded to three 16-byte reads
+// lane = output channel (weights [kind][c][tap][k]: one coalesced 256-byte load per channel and tap, eight channels ahead in
+// registers); the d y values of the workgroup's WR_POS positions -- the same for every lane -- are fetched ONCE by the whole
+// workgroup (one load per value, whatever the stride of the line: the column lines have one cache line per element) into LDS and
+// read back as broadcasts; the eight waves split the input channels and add up through LDS in a fixed order.
+__global__ void __launch_bounds__(64 * WR_WAVES) k_wino_ring(const float* __restrict__ wr, const float* __restrict__ dy, WnTensor di, int H, int W,
+                                                             float* __restrict__ g, WnTensor go, int C, int K, int kinds, int col_rows,
+                                                             int n_img) {
+    HIP_DYNAMIC_SHARED(float, xs)           // [WR_NI][C][WR_XS], later the partial sums [wave][WR_NI * WR_POS][64]
+    const int lane = threadIdx.x & 63, wave = wn_uniform(threadIdx.x >> 6);
+    const int Kp = (K + WR_KB - 1) / WR_KB * WR_KB, k = blockIdx.y * 64 + lane, n0 = blockIdx.z * WR_NI;
+    // blockIdx.x -> (segment kind, WR_POS positions of it): the kinds asked for, rows first (length W + 2), then columns (rows 1 ..
+    // col_rows: H, or H + 1 when the bottom row is not a ring segment of its own and the corners belong to the columns)
+    int chunk = blockIdx.x, kind = -1;
+    const int row_chunks = (W + 2 + WR_POS - 1) / WR_POS, col_chunks = (col_rows + WR_POS - 1) / WR_POS;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int nq = q < 2 ? row_chunks : col_chunks;
+        if (kind < 0 && (kinds >> q & 1)) {
+            if (chunk < nq) kind = q;
+            else chunk -= nq;
+        }
+    }
+    const bool row_kind = kind < 2;
+    const int p0 = chunk * WR_POS, len = row_kind ? W + 2 : col_rows;
+    // the taps of position p lie at p - 2 .. p of the source line (rows: p = X) or p - 1 .. p + 1 (columns: p = Y - 1)
+    const int64_t line = row_kind ? (int64_t)(kind == 0 ? 0 : H - 1) * di.rs : (kind == 2 ? 0 : W - 1);
+    const int64_t step = row_kind ? 1 : di.rs;
+    const int q_first = p0 + (row_kind ? -2 : -1), n_src = row_kind ? W : H;
+    // (unconditional loads from clamped addresses, eight in flight per thread: a load behind a branch is waited for on the spot)
+    for (int i0 = threadIdx.x; i0 < WR_NI * C * WR_XS; i0 += 8 * blockDim.x) {
+        float v[8];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x, ii = i < WR_NI * C * WR_XS ? i : 0;
+            const int e = ii % WR_XS, ic = ii / WR_XS, c = ic % C, im = ic / C, q = q_first + e;
+            ok[u] = e < WR_POS + 2 && q >= 0 && q < n_src && n0 + im < n_img;
+            const int qc = q < 0 ? 0 : (q >= n_src ? n_src - 1 : q), nc = n0 + im < n_img ? n0 + im : n_img - 1;
+            v[u] = dy[nc * di.ns + c * di.cs + line + qc * step];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < WR_NI * C * WR_XS) xs[i] = ok[u] ? v[u] : 0.f;
+        }
+    }
+    __syncthreads();
+    float acc[WR_NI][WR_POS];
+#pragma unroll
+    for (int im = 0; im < WR_NI; ++im)
+#pragma unroll
+        for (int j = 0; j < WR_POS; ++j) acc[im][j] = 0.f;
+    const float* wk = wr + (size_t)kind * C * 3 * Kp + (k < Kp ? k : 0);
+    constexpr int AHEAD = 8;         // (all 32 channels of a wave at once measured slower: 23 us against 16)
+    for (int c0 = wave; c0 < C; c0 += AHEAD * WR_WAVES) {
+        float wv[AHEAD][3];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const int c = c0 + u * WR_WAVES;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) wv[u][t] = wk[((size_t)(c < C ? c : 0) * 3 + t) * Kp];
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+            const int c = c0 + u * WR_WAVES;
+            if (c < C) {
+#pragma unroll
+                for (int im = 0; im < WR_NI; ++im) {
+                    const float* xp = xs + (im * C + c) * WR_XS;
+                    const w4f x0 = *reinterpret_cast<const w4f*>(xp), x1 = *reinterpret_cast<const w4f*>(xp + 4), x2 = *reinterpret_cast<const w4f*>(xp + 8);
+                    const float x[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
+#pragma unroll
+                    for (int j = 0; j < WR_POS; ++j)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) acc[im][j] = fmaf(wv[u][t], x[j + t], acc[im][j]);
+                }
+            }
+        }
+    }
+    __syncthreads();        // everybody is done with the line pieces: the same memory takes the partial sums
+    float* red = xs;
+#pragma unroll
+    for (int im = 0; im < WR_NI; ++im)
+#pragma unroll
+        for (int j = 0; j < WR_POS; ++j) red[(wave * (WR_NI * WR_POS) + im * WR_POS + j) * 64 + lane] = acc[im][j];
+    __syncthreads();
+    // wave w adds up four of the 32 (image, position) values of every lane (fixed order: the result does not depend on scheduling)
+#pragma unroll
+    for (int aa = 0; aa < WR_NI * WR_POS / WR_WAVES; ++aa) {
+        const int a = wave * (WR_NI * WR_POS / WR_WAVES) + aa, im = a / WR_POS, j = a - im * WR_POS, p = p0 + j;
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < WR_WAVES; ++q) sum += red[(q * (WR_NI * WR_POS) + a) * 64 + lane];
+        if (p < len && k < K && n0 + im < n_img) {
+            const int Y = row_kind ? (kind == 0 ? 0 : H + 1) : p + 1, X = row_kind ? p : (kind == 2 ? 0 : W + 1);
+            g[(n0 + im) * go.ns + k * go.cs + Y * go.rs + X] = sum;
+        }
+    }
+}
+
+/* ring of g = d(padded input) [N, K, H + 2, W + 2] of a 3x3 stride-1 convolution from dy [N, C, H, W]; `kinds`: bit 0 top row,
+ * 1 bottom row, 2 left column, 3 right column; the columns cover rows 1 .. H, and row H + 1 as well when the bottom row is not
+ * asked for (the corners must belong to somebody).  records: nf_wino_ring_pack(weight [C][K][3][3]). */
+extern "C" int nf_conv3x3_bwd_ring(const float* ring_records, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int H, int W, float* g,
+                                   int64_t gs_n, int64_t gs_c, int64_t gs_h, int n_img, int c_dy, int c_dx, int kinds, nf_stream_t stream) {
+    NF_REQUIRE(n_img >= 1 && c_dy >= 1 && c_dx >= 1 && H >= 1 && W >= 1 && kinds > 0 && kinds < 16, "nf_conv3x3_bwd_ring: bad arguments (kinds %d)", kinds);
+    const int col_rows = (kinds & 2) ? H : H + 1;
+    const int row_chunks = (W + 2 + WR_POS - 1) / WR_POS, col_chunks = (col_rows + WR_POS - 1) / WR_POS;
+    int chunks = 0;
+    for (int q = 0; q < 4; ++q)
+        if (kinds >> q & 1) chunks += q < 2 ? row_chunks : col_chunks;
+    const WnTensor di = {ds_n, ds_c, ds_h}, go = {gs_n, gs_c, gs_h};
+    // line pieces of WR_NI images, or the eight waves' partial sums, whichever is larger
+    size_t smem = sizeof(float) * (size_t)WR_NI * c_dy * WR_XS;
+    if (smem < sizeof(float) * WR_WAVES * WR_NI * WR_POS * 64) smem = sizeof(float) * WR_WAVES * WR_NI * WR_POS * 64;
+    NF_REQUIRE(smem <= 64 * 1024, "nf_conv3x3_bwd_ring: at most 341 gradient channels (got %d)", c_dy);
+    hipLaunchKernelGGL(k_wino_ring, dim3((unsigned)chunks, (unsigned)((c_dx + 63) / 64), (unsigned)((n_img + WR_NI - 1) / WR_NI)), dim3(64 * WR_WAVES),
+                       smem, (hipStream_t)stream, ring_records, dy, di, H, W, g, go, c_dy, c_dx, kinds, col_rows, n_img);
+    NF_LAUNCH_CHECK("nf_conv3x3_bwd_ring");
+    return 0;
+}

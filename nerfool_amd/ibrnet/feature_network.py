@@ -249,6 +249,16 @@ def _wino_records(conv_w, k_per_group):
     return cache[1], cache[2]
 
 
+def _wino_ring_records(conv_w):
+    """1-D border weights of the backward-data pass (nf_conv3x3_bwd_ring), kept on the weight tensor"""
+    key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
+    cache = getattr(conv_w, '_nf_wino_ring', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.wino_ring_pack(conv_w, conv_w.device))
+        conv_w._nf_wino_ring = cache
+    return cache[1]
+
+
 def _wino4_records(conv_w):
     """F(4x4,3x3) records (csrc/nf_wino4.hip; NERFOOL_CONV3X3=wino4 only), kept on the weight tensor"""
     key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
@@ -274,9 +284,19 @@ def _conv3x3(tape, inp, w, sink):
 
     def bwd():
         g_out = out.g
-        cand = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_in))[1], g_out, c_in, 2, k_per_group=ops.wino_group(c_in))}
+        # planes whose (H + 2) x (W + 2) gradient needs many more 8 x 16 output blocks than the H x W plane itself (48 x 63: 35
+        # against 24): the Winograd kernel on the interior-aligned region + the 1-D border ring kernel (a rule on the shape, not a
+        # timing: the two forms round differently)
+        plan = ops.wino_bwd_split_plan(g_out.shape[2], g_out.shape[3])
+
+        def bwd_data(kpg):
+            rec = _wino_records(w, kpg)[1]
+            if plan is None:
+                return ops.conv3x3_wino(rec, g_out, c_in, 2, k_per_group=kpg)
+            return ops.conv3x3_wino_bwd_split(rec, _wino_ring_records(w), g_out, c_in, plan, k_per_group=kpg)
+        cand = {'wino': lambda: bwd_data(ops.wino_group(c_in))}
         if c_in > 64:
-            cand['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[1], g_out, c_in, 2, k_per_group=32)
+            cand['wino32'] = lambda: bwd_data(32)
         if CONV3X3 == 'miopen':
             cand['miopen'] = lambda: _aten.convolution_backward(g_out, inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                                 [True, False, False])[0]

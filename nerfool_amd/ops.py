@@ -641,6 +641,53 @@ def conv3x3_wino(records, x, c_out, pad, tile_blocks=0, k_per_group=None):
     return y
 
 
+def wino_ring_pack(weight, device):
+    """weight [c_out, c_in, 3, 3] -> the 1-D border weights of its backward-data pass (nf_conv3x3_bwd_ring)"""
+    L = _lib.lib()
+    w = weight.detach().to('cpu', torch.float32).contiguous()
+    out = torch.empty(L.nf_wino_ring_pack_floats(w.shape[0], w.shape[1]), dtype=torch.float32)
+    _lib.check(L.nf_wino_ring_pack(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr()), 'nf_wino_ring_pack')
+    return out.to(device)
+
+
+def _wino_blocks(h, w):
+    return -(-h // 8) * -(-w // 16)
+
+
+def wino_bwd_split_plan(H, W):
+    """(rows, columns, ring kinds) of the split backward-data pass of an H x W gradient, or None when the split does not save
+    a tenth of the 8 x 16 output blocks: the Winograd kernel covers rows 1 .. rows, columns 1 .. columns of the (H + 2) x (W + 2)
+    result -- the bottom row / right column ride along when the last block row / column has room -- the ring kernel the rest.
+    A function of the shape alone, so the choice (and with it every rounding) is the same in every run."""
+    rows = min(H + 1, -(-H // 8) * 8)
+    cols = min(W + 1, -(-W // 16) * 16)
+    if 10 * _wino_blocks(rows, cols) > 9 * _wino_blocks(H + 2, W + 2):
+        return None
+    return rows, cols, 1 | (0 if rows == H + 1 else 2) | 4 | (0 if cols == W + 1 else 8)
+
+
+def conv3x3_wino_bwd_split(records, ring_records, dy, c_dx, plan, k_per_group=None):
+    """backward-data of a 3x3 stride-1 convolution, dy [N, c_dy, H, W] -> d(padded input) [N, c_dx, H + 2, W + 2], as the Winograd
+    kernel on the interior-aligned region + the 1-D ring kernel (plan = wino_bwd_split_plan(H, W)); every element of the result
+    is written exactly once."""
+    _f32(dy, 'dy')
+    if dy.stride(3) != 1:
+        dy = dy.contiguous()
+    N, c_dy, H, W = dy.shape
+    rows, cols, kinds = plan
+    g = torch.empty(N, c_dx, H + 2, W + 2, dtype=torch.float32, device=dy.device)
+    xs, gs = dy.stride(), g.stride()
+    L = _lib.lib()
+    with prof.launch('nf_conv3x3_wino', dy, n_img=N, c_in=c_dy, c_out=c_dx, Hi=H, Wi=W, Ho=rows, Wo=cols):
+        _lib.check(L.nf_conv3x3_wino(_ptr(records), wino_group(c_dx) if k_per_group is None else int(k_per_group), _ptr(dy), xs[0], xs[1], xs[2],
+                                     H, W, 1, g.data_ptr() + 4 * (gs[2] + 1), gs[0], gs[1], gs[2], rows, cols, N, c_dy, c_dx, 0, _stream(dy)),
+                   'nf_conv3x3_wino')
+    with prof.launch('nf_conv3x3_bwd_ring', dy, n=N * c_dx * (2 * (W + 2) + 2 * H)):
+        _lib.check(L.nf_conv3x3_bwd_ring(_ptr(ring_records), _ptr(dy), xs[0], xs[1], xs[2], H, W, _ptr(g), gs[0], gs[1], gs[2], N, c_dy, c_dx,
+                                         int(kinds), _stream(dy)), 'nf_conv3x3_bwd_ring')
+    return g
+
+
 def upsample2x_pad_fwd(x, pad):
     """reflect_pad(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=True), pad); x [N,C,h,w] may be the
     interior view of a padded tensor (unit column stride, planes laid out like a contiguous [N,C] grid)."""

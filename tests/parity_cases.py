@@ -705,6 +705,21 @@ def check_fused_cnn_glue(dev):
             assert_close(got, ref, 1e-4, 1e-4 * float(ref.abs().max()), 'Winograd 3x3 forward (%d per group)' % kpg)
             ggot = ops.conv3x3_wino(ops.wino_pack(wgt, True, dev, kpg), gy.to(dev), ci, 2, k_per_group=kpg)
             assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'Winograd 3x3 backward-data (%d per group)' % kpg)
+    # backward-data split into the Winograd kernel on the interior-aligned region + the 1-D border ring kernel: every combination
+    # of ring segments (forced plans) and the plan the executor would take, ragged channel counts included
+    for (N, ci, co, H, W) in ((2, 32, 64, 8, 15), (1, 40, 24, 16, 32), (1, 64, 64, 7, 18), (2, 16, 48, 3, 70)):
+        wgt = torch.randn(co, ci, 3, 3, generator=gen) * 0.2
+        gy = torch.randn(N, co, H, W, generator=gen)
+        gref = F.conv_transpose2d(gy, wgt)
+        rb, ring = ops.wino_pack(wgt, True, dev), ops.wino_ring_pack(wgt, dev)
+        plans = {(H, W, 1 | 2 | 4 | 8), (H + 1, W, 1 | 4 | 8), (H, W + 1, 1 | 2 | 4), (H + 1, W + 1, 1 | 4)}
+        if ops.wino_bwd_split_plan(H, W) is not None:
+            plans.add(ops.wino_bwd_split_plan(H, W))
+        for plan in sorted(plans):
+            ggot = ops.conv3x3_wino_bwd_split(rb, ring, gy.to(dev), ci, plan)
+            assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'split backward-data %s of %dx%d' % (plan, H, W))
+    assert ops.wino_bwd_split_plan(48, 63) == (48, 64, 1 | 2 | 4) and ops.wino_bwd_split_plan(189, 252) is None
+    assert ops.wino_bwd_split_plan(32, 32) == (32, 32, 15)
     # 1x1 convolutions as MFMA GEMMs over the pixels: subsampled / strided input, bias, channels-last output, backward-data
     for (N, ci, co, H, W, sub, cl) in ((2, 64, 64, 5, 7, False, True), (1, 64, 128, 6, 9, True, False), (1, 32, 40, 4, 5, False, False)):
         wgt = torch.randn(co, ci, 1, 1, generator=gen) * 0.2
