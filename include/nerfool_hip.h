@@ -125,6 +125,15 @@ int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, const float* p
                        const float* ray_diff, const float* mask, const float* smp, const float* d_raw, int64_t n_rays,
                        int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat, float* d_workspace,
                        nf_stream_t stream);
+/* The same backward with the adjoint of Projector.compute's feature gather (autograd of F.grid_sample, ibrnet/projection.py:116-125)
+ * fused into its output stage: d rgb_feat is not written, its 32 feature channels are scattered straight into the feature-map
+ * gradient.  xyz [n_rays * n_samples][3] and cam_ws exactly as given to nf_project_gather_fwd; d_featmap [V][32][Hf][Wf]
+ * through element strides, ZEROED by the caller (the kernel adds, float atomics like nf_project_gather_bwd). */
+int nf_ibrnet_bwd_mfma_scatter(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
+                               const float* ray_diff, const float* mask, const float* smp, const float* d_raw, int64_t n_rays,
+                               int n_samples, int n_views, int anti_alias_pooling, float* d_workspace, const float* xyz,
+                               const float* cam_ws, float* d_featmap, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
+                               int Hf, int Wf, nf_stream_t stream);
 /* bf16-operand variant of the matrix-core path (BASELINE config 5, "bf16 MFMA path"): the per-(sample, view) row network of
  * IBRNet.forward (ibrnet/mlp_network.py:231-257, 268-273: ray_dir_fc, base_fc, vis_fc, vis_fc2, rgb_fc) runs on
  * v_mfma_f32_32x32x16_bf16 -- weights and activations rounded to bf16 at the matrix-core inputs, fp32 accumulation; pooling,

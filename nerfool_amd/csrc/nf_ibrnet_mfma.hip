@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "nf_ibrnet.h"
+#include "nf_geometry.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -825,11 +826,34 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
     }
 }
 
-template <int V, bool BF>
+// The scatter of d rgb_feat into the feature-map gradient (autograd of F.grid_sample, ibrnet/projection.py:120-121), fused into
+// the row kernel's output stage: d rgb_feat never goes to memory (north-star design: no rgb_feat round trip on the way back) and
+// the float atomics -- fire and forget -- drain while the matrix work of the next tile runs, where the stand-alone scatter kernel
+// is bound by the chip-wide atomic rate with nothing else to do.
+// wave-level ordering point for data handed from lane to lane through LDS (on the CPU stand-in of tests/host_harness, where lanes
+// are threads, the collective is a real rendezvous)
+__device__ __forceinline__ void rs_wave_sync() {
+    asm volatile("" ::: "memory");
+    (void)__shfl(0, 0, NF_WAVE);
+    asm volatile("" ::: "memory");
+}
+
+struct RowScatter {
+    const float* xyz;         // [n_samples][3] sample points
+    const float* cam_ws;      // nf_camera_setup workspace: V source cameras + the query entry
+    float* d_featmap;         // [V][C = 32][Hf][Wf] through the element strides below; nullptr: write d rgb_feat instead
+    int64_t fs_v, fs_c, fs_h, fs_w;
+    int Hf, Wf;
+};
+#define RS_ROW 33             // floats per row of the wave's staging tile (32 channels, padded: conflict-free column reads)
+#define RS_TAP 8              // per row: 4 tap weights, x0, y0 (as int bits), view, pad
+#define RS_FLOATS (32 * RS_ROW + 32 * RS_TAP)
+
+template <int V, bool BF, bool SCAT>
 __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_OCC) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                          const float* __restrict__ d_smp, int64_t n_samples, int aa,
-                                                         float* __restrict__ d_rgb_feat) {
+                                                         float* __restrict__ d_rgb_feat, RowScatter sc) {
     HIP_DYNAMIC_SHARED(float, lds)
     for (int i = threadIdx.x; i < (BF ? (int)NF_BF_BLOB_FLOATS : (int)NF_ROWS_BLOB_FLOATS); i += blockDim.x) lds[i] = wblob[i];
     __syncthreads();
@@ -858,7 +882,45 @@ __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_O
         f32x16 d_feat;
         float d_col[3];
         rows_backward<V, BF>(lds, lane, h, in, a, d_mean2, d_var2, g[64], d_rgb, d_feat, d_col);
-        if (live) {
+        if (SCAT) {
+            // the wave's 32 rows x 32 channels pass through a private LDS tile so that lane = channel afterwards: one atomic
+            // instruction then adds 2 rows x 128 contiguous bytes (as the stand-alone kernel does), not 64 scattered floats
+            float* gt = lds + (BF ? (int)NF_BF_BLOB_FLOATS : (int)NF_ROWS_BLOB_FLOATS) + wave * RS_FLOATS;
+            float* tp = gt + 32 * RS_ROW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gt[m * RS_ROW + nf_nidx(r, h)] = d_feat[r];
+            if (h == 0) {
+                const int v = (int)(row - sample * V);
+                const float* cam = sc.cam_ws + (int64_t)v * NF_CAM_STRIDE;
+                const float* qc = sc.cam_ws + (int64_t)V * NF_CAM_STRIDE;
+                float px, py;
+                bool front;
+                nf_project_point(cam, sc.xyz[sample * 3 + 0], sc.xyz[sample * 3 + 1], sc.xyz[sample * 3 + 2], px, py, front);
+                const NfTaps tf = nf_bilinear_taps(px, py, qc[0], qc[1], sc.Hf, sc.Wf);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) tp[m * RS_TAP + t] = (live && tf.in[t]) ? tf.w[t] : 0.f;       // 0 = nothing to add
+                tp[m * RS_TAP + 4] = __builtin_bit_cast(float, (int)(tf.x0));
+                tp[m * RS_TAP + 5] = __builtin_bit_cast(float, (int)(tf.y0));
+                tp[m * RS_TAP + 6] = __builtin_bit_cast(float, (int)(v));
+            }
+            // the tile is private to the wave, whose lanes run in lockstep and whose LDS operations execute in order: rs_wave_sync
+            // only keeps the compiler from moving the reads below above the writes of other lanes
+            rs_wave_sync();
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int j = 2 * i + h;                    // row of the tile; lane & 31 = channel
+                const float gv = gt[j * RS_ROW + m];
+                const float* tj = tp + j * RS_TAP;
+                const int x0 = __builtin_bit_cast(int, (float)(tj[4])), y0 = __builtin_bit_cast(int, (float)(tj[5])), v = __builtin_bit_cast(int, (float)(tj[6]));
+                float* fb = sc.d_featmap + (int64_t)v * sc.fs_v + (int64_t)m * sc.fs_c;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float wt = tj[t];
+                    if (wt != 0.f) atomicAdd(fb + (int64_t)(y0 + (t >> 1)) * sc.fs_h + (int64_t)(x0 + (t & 1)) * sc.fs_w, gv * wt);
+                }
+            }
+            rs_wave_sync();         // ... and the next tile's writes below these reads
+        } else if (live) {
             float* o = d_rgb_feat + row * 35;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[3 + nf_nidx(r, h)] = d_feat[r];
@@ -1686,14 +1748,15 @@ extern "C" int nf_ibrnet_fwd_mfma_bf16(const float* bf16_blob, const float* mfma
                            n_views, anti_alias_pooling, raw, workspace, stream);
 }
 
-template <int V, bool BF>
+template <int V, bool BF, bool SCAT>
 static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
-                           const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, hipStream_t st) {
+                           const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, hipStream_t st) {
     static bool configured_on[NF_MAX_DEVICES] = {};      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel and device
     bool& configured = configured_on[nf_current_device()];
-    const size_t smem = (BF ? (size_t)NF_BF_BLOB_FLOATS : (size_t)NF_ROWS_BLOB_FLOATS) * sizeof(float);
+    // the weight image (+ one staging tile per wave for the fused scatter)
+    const size_t smem = ((BF ? (size_t)NF_BF_BLOB_FLOATS : (size_t)NF_ROWS_BLOB_FLOATS) + (SCAT ? NF_ROWS_BWD_WAVES * RS_FLOATS : 0)) * sizeof(float);
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V, BF, SCAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
             hipSuccess) {
             nf_set_error("nf_ibrnet_bwd_mfma: cannot reserve %zu bytes of LDS", smem);
             return 1;
@@ -1705,16 +1768,18 @@ static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const floa
     // fp32: one workgroup per CU holds the 113 KB weight image (fwd + transposed); bf16: 64 KB, two per CU
     const int64_t cap = BF ? 1024 : 512;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask,
-                       d_smp, n_samples, aa, d_rgb_feat);
+    hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF, SCAT>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask,
+                       d_smp, n_samples, aa, d_rgb_feat, sc);
     return 0;
 }
 
 template <int V>
 static int launch_rows_bwd_any(const float* wblob, const float* bf_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
-                               const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, hipStream_t st) {
-    return bf_blob ? launch_rows_bwd<V, true>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, st)
-                   : launch_rows_bwd<V, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, st);
+                               const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, hipStream_t st) {
+    if (sc.d_featmap)       // fused scatter: exact-fp32 rows only (the bf16 image leaves no LDS for the staging tiles at two workgroups per CU)
+        return launch_rows_bwd<V, false, true>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, st);
+    return bf_blob ? launch_rows_bwd<V, true, false>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, st)
+                   : launch_rows_bwd<V, false, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, st);
 }
 
 template <int WPR>
@@ -1740,8 +1805,9 @@ static int launch_ray_bwd(const float* mfma_blob, const float* pos_enc, const fl
 static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
                            const float* rgb_feat, const float* ray_diff, const float* mask, const float* smp, const float* d_raw,
                            int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat,
-                           float* d_workspace, nf_stream_t stream) {
+                           float* d_workspace, nf_stream_t stream, const RowScatter& sc = RowScatter{}) {
     NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: V must be a power of two <= 32 (got %d)", who, n_views);
+    NF_REQUIRE(!(sc.d_featmap && bf_blob), "%s: the fused scatter runs with the fp32 row kernels", who);
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int threads = ((n_samples + 63) / 64) * 64;
@@ -1769,12 +1835,12 @@ static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* m
     int64_t ns = n_rays * n_samples;
     int rc;
     switch (n_views) {
-        case 1: rc = launch_rows_bwd_any<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        case 2: rc = launch_rows_bwd_any<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        case 4: rc = launch_rows_bwd_any<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        case 8: rc = launch_rows_bwd_any<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        case 16: rc = launch_rows_bwd_any<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
-        default: rc = launch_rows_bwd_any<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, st); break;
+        case 1: rc = launch_rows_bwd_any<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
+        case 2: rc = launch_rows_bwd_any<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
+        case 4: rc = launch_rows_bwd_any<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
+        case 8: rc = launch_rows_bwd_any<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
+        case 16: rc = launch_rows_bwd_any<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
+        default: rc = launch_rows_bwd_any<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
     }
     if (rc) return rc;
     NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (rows)");
@@ -1788,6 +1854,21 @@ extern "C" int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, con
                                   float* d_workspace, nf_stream_t stream) {
     return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma", nullptr, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, n_rays, n_samples,
                            n_views, anti_alias_pooling, d_rgb_feat, d_workspace, stream);
+}
+
+/* nf_ibrnet_bwd_mfma with the scatter of d rgb_feat into the feature-map gradient fused into the row kernel (d rgb_feat is not
+ * written): xyz [n_rays * n_samples][3] and cam_ws as given to nf_project_gather_fwd, d_featmap [V][32][Hf][Wf] through element
+ * strides, ZEROED by the caller (the kernel adds). */
+extern "C" int nf_ibrnet_bwd_mfma_scatter(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
+                                          const float* ray_diff, const float* mask, const float* smp, const float* d_raw, int64_t n_rays,
+                                          int n_samples, int n_views, int anti_alias_pooling, float* d_workspace, const float* xyz,
+                                          const float* cam_ws, float* d_featmap, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
+                                          int Hf, int Wf, nf_stream_t stream) {
+    if (n_rays == 0) return 0;       // nothing to add
+    NF_REQUIRE(xyz && cam_ws && d_featmap && Hf >= 1 && Wf >= 1, "nf_ibrnet_bwd_mfma_scatter: bad arguments");
+    const RowScatter sc = {xyz, cam_ws, d_featmap, fs_v, fs_c, fs_h, fs_w, Hf, Wf};
+    return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma_scatter", nullptr, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, n_rays,
+                           n_samples, n_views, anti_alias_pooling, nullptr, d_workspace, stream, sc);
 }
 
 extern "C" int nf_ibrnet_bwd_mfma_bf16(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc,

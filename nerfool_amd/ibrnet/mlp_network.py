@@ -79,6 +79,32 @@ class _IBRNetFunction(torch.autograd.Function):
         return d_rgb_feat, None, None, None, None, None, None, None
 
 
+class _IBRNetGatherFunction(torch.autograd.Function):
+    """_IBRNetFunction differentiated straight through to the feature maps: the backward scatters d rgb_feat into d featmaps
+    inside the row kernel (ops.ibrnet_bwd_mfma_scatter).  rgb_feat comes in detached -- Projector.compute produced it from
+    `featmaps` with the sample points / cameras handed over next to it."""
+
+    @staticmethod
+    def forward(ctx, featmaps, rgb_feat, ray_diff, mask, blob, mfma_blob, pos_enc, anti_alias, pts, cam_ws):
+        raw, smp = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
+        ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp, pts, cam_ws)
+        ctx.anti_alias, ctx.feat_shape = anti_alias, tuple(featmaps.shape)
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp, pts, cam_ws = ctx.saved_tensors
+        d_feat = ops.ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, ctx.anti_alias, pts, cam_ws,
+                                             ctx.feat_shape)
+        return (d_feat,) + (None,) * 9
+
+
+# 'fused' (default): where Projector.compute handed over its gather context, the adjoint of the gather runs inside the IBRNet
+# backward; 'separate': nf_ibrnet_bwd_mfma writes d rgb_feat and nf_project_gather_bwd scatters it (always so with the generic
+# kernels, the bf16 rows and NERFOOL_GATHER_BWD=deterministic)
+GATHER_BWD_FUSION = os.environ.get('NERFOOL_GATHER_FUSION', 'fused')
+
+
 class IBRNet(nn.Module):
     def __init__(self, args, in_feat_ch=32, n_samples=64, **kwargs):
         super().__init__()
@@ -130,5 +156,12 @@ class IBRNet(nn.Module):
         :return: [n_rays, n_samples, 4]  (rgb, sigma)
         """
         blob, mfma_blob = self._packed(rgb_feat.device)
+        gather = getattr(rgb_feat, '_nf_gather', None)
+        if (gather is not None and GATHER_BWD_FUSION == 'fused' and self.precision == 'fp32' and KERNEL_PATH != 'generic'
+                and ops.GATHER_BWD != 'deterministic' and torch.is_grad_enabled() and gather[2].requires_grad
+                and gather[2].shape[1] == 32 and ops.ibrnet_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])):
+            pts, cam_ws, featmaps = gather
+            return _IBRNetGatherFunction.apply(featmaps, rgb_feat.detach(), ray_diff, mask[..., 0], blob, mfma_blob, self.pos_encoding,
+                                               bool(self.anti_alias_pooling), pts, cam_ws)
         return _IBRNetFunction.apply(rgb_feat, ray_diff, mask[..., 0], blob, mfma_blob, self.pos_encoding,
                                      bool(self.anti_alias_pooling), self._bf16_blob if self.precision == 'bf16' else None)

@@ -46,9 +46,15 @@ class Projector:
         R, S, _ = xyz.shape
         V = train_cameras.shape[1]
         cam_ws = ops.camera_setup(query_camera.detach(), train_cameras.detach())
-        rgb_feat, ray_diff, mask = _ProjectGather.apply(xyz.detach().reshape(-1, 3), cam_ws, train_imgs[0].detach(), featmaps)
+        pts = xyz.detach().reshape(-1, 3)
+        rgb_feat, ray_diff, mask = _ProjectGather.apply(pts, cam_ws, train_imgs[0].detach(), featmaps)
         C = featmaps.shape[1]
-        return rgb_feat.view(R, S, V, 3 + C), ray_diff.view(R, S, V, 4), mask.view(R, S, V, 1)
+        rgb_feat = rgb_feat.view(R, S, V, 3 + C)
+        if featmaps.requires_grad:
+            # what the adjoint of this gather needs, for a consumer that fuses it into its own backward (IBRNet.forward: the scatter
+            # then runs inside the row kernel and d rgb_feat is never written); anybody else differentiates rgb_feat as usual
+            rgb_feat._nf_gather = (pts, cam_ws, featmaps)
+        return rgb_feat, ray_diff.view(R, S, V, 4), mask.view(R, S, V, 1)
 
     def compute_projections(self, xyz, train_cameras):
         """pixel_locations [n_views, n_rays, n_samples, 2] (ibrnet/projection.py:42-62); the in-front flag is folded

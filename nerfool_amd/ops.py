@@ -232,6 +232,27 @@ def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_r
     return d_rgb_feat
 
 
+def ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias, xyz, cam_ws, feat_shape):
+    """ibrnet_bwd_mfma + project_gather_bwd in one: d_raw [R,S,4] -> d_featmaps [V,C,Hf,Wf] (channels-last storage); the
+    gradient of rgb_feat never exists in memory."""
+    rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
+    d_raw, xyz = _c(d_raw, 'd_raw'), _c(xyz, 'xyz')
+    R, S, V, _ = rgb_feat.shape
+    Vf, C, Hf, Wf = feat_shape
+    if Vf != V or C != 32 or xyz.shape[0] != R * S:
+        raise ValueError('feature maps %s / sample points %s do not match rgb_feat %s' % (tuple(feat_shape), tuple(xyz.shape), tuple(rgb_feat.shape)))
+    pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
+    d_ws = torch.empty_like(smp)
+    d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
+    sv, sc, sh, sw = d_feat.stride()
+    with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
+        _lib.check(_lib.lib().nf_ibrnet_bwd_mfma_scatter(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
+                                                         _ptr(smp), _ptr(d_raw), R, S, V, int(bool(anti_alias)), _ptr(d_ws), _ptr(xyz),
+                                                         _ptr(cam_ws), _ptr(d_feat), sv, sc, sh, sw, Hf, Wf, _stream(d_raw)),
+                   'nf_ibrnet_bwd_mfma_scatter')
+    return d_feat
+
+
 def debug_mfma32(a, b, c):
     d = torch.empty_like(c)
     _lib.check(_lib.lib().nf_debug_mfma32(_ptr(_c(a, 'a')), _ptr(_c(b, 'b')), _ptr(_c(c, 'c')), _ptr(d), _stream(d)),
