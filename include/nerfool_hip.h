@@ -134,6 +134,14 @@ int nf_ibrnet_bwd_mfma_scatter(const float* mfma_blob, const float* blob, const 
                                int n_samples, int n_views, int anti_alias_pooling, float* d_workspace, const float* xyz,
                                const float* cam_ws, float* d_featmap, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
                                int Hf, int Wf, nf_stream_t stream);
+/* The forward with Projector.compute (ibrnet/projection.py:42-132: projection, bilinear taps of the feature maps and of the source
+ * images, ray_diff, mask) folded into the row kernel -- the per-ray source features go from the maps to the lanes that consume
+ * them, rgb_feat / ray_diff are never written (no-grad rendering).  bf16_blob: nullptr = exact fp32 rows.  featmap channels-last
+ * (fs_c == 1, 16-byte aligned pixel records); mask_out [n_rays * n_samples * V] receives the validity mask. */
+int nf_ibrnet_fwd_mfma_gather(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc, const float* xyz,
+                              const float* cam_ws, const float* src_rgbs, int H, int W, const float* featmap, int Hf, int Wf,
+                              int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w, int64_t n_rays, int n_samples, int n_views,
+                              int anti_alias_pooling, float* raw, float* workspace, float* mask_out, nf_stream_t stream);
 /* bf16-operand variant of the matrix-core path (BASELINE config 5, "bf16 MFMA path"): the per-(sample, view) row network of
  * IBRNet.forward (ibrnet/mlp_network.py:231-257, 268-273: ray_dir_fc, base_fc, vis_fc, vis_fc2, rgb_fc) runs on
  * v_mfma_f32_32x32x16_bf16 -- weights and activations rounded to bf16 at the matrix-core inputs, fp32 accumulation; pooling,

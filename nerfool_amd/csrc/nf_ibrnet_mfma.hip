@@ -494,6 +494,67 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rgb_feat, con
     in.mk = mask[row];
 }
 
+// Projector.compute (ibrnet/projection.py:42-132) done by the row itself: the kernel reads the feature maps and the source
+// images, rgb_feat / ray_diff never exist in memory (north-star design: the per-ray source features go from the maps to the
+// registers of the lanes that consume them).  Same arithmetic, tap by tap, as k_project_gather_fwd, so the values are the ones the
+// stand-alone gather would have written.  Feature maps channels-last (unit channel stride, 16-byte aligned pixel records).
+struct RowGather {
+    const float* xyz;         // [n_samples][3]
+    const float* cam_ws;      // nf_camera_setup workspace
+    const float* src_rgbs;    // [V][H][W][3]
+    const float* featmap;     // [V][32][Hf][Wf] through fs_v / fs_h / fs_w (channel stride 1)
+    float* mask_out;          // [n_samples * V]: the validity mask (the caller's pixel mask needs it)
+    int64_t fs_v, fs_h, fs_w;
+    int H, W, Hf, Wf;
+};
+
+template <int V>
+__device__ __forceinline__ void load_row_gather(const RowGather& g, int64_t row, int64_t sample, int v, int h, bool live, RowIn& in) {
+    const float* cam = g.cam_ws + (int64_t)v * NF_CAM_STRIDE;
+    const float* qc = g.cam_ws + (int64_t)V * NF_CAM_STRIDE;
+    const float x = g.xyz[sample * 3 + 0], y = g.xyz[sample * 3 + 1], z = g.xyz[sample * 3 + 2];
+    float px, py;
+    bool front;
+    nf_project_point(cam, x, y, z, px, py, front);
+    const NfTaps tf = nf_bilinear_taps(px, py, qc[0], qc[1], g.Hf, g.Wf);
+    const float* fbase = g.featmap + (int64_t)v * g.fs_v + 4 * h;        // this lane half's channels: 8 q + 4 h + (0 .. 3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (tf.in[t]) {
+                const int xx = tf.x0 + (t & 1), yy = tf.y0 + (t >> 1);
+                const float4 val = *reinterpret_cast<const float4*>(fbase + (int64_t)yy * g.fs_h + (int64_t)xx * g.fs_w + 8 * q);
+                acc.x = acc.x + val.x * tf.w[t];
+                acc.y = acc.y + val.y * tf.w[t];
+                acc.z = acc.z + val.z * tf.w[t];
+                acc.w = acc.w + val.w * tf.w[t];
+            }
+        }
+        in.feat[4 * q + 0] = acc.x;
+        in.feat[4 * q + 1] = acc.y;
+        in.feat[4 * q + 2] = acc.z;
+        in.feat[4 * q + 3] = acc.w;
+    }
+    const NfTaps ti = nf_bilinear_taps(px, py, qc[0], qc[1], g.H, g.W);
+    const float* ibase = g.src_rgbs + (int64_t)v * g.H * g.W * 3;
+    float r = 0.f, gg = 0.f, b = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (ti.in[t]) {
+            const float* p = ibase + ((int64_t)(ti.y0 + (t >> 1)) * g.W + (ti.x0 + (t & 1))) * 3;
+            r = r + p[0] * ti.w[t];
+            gg = gg + p[1] * ti.w[t];
+            b = b + p[2] * ti.w[t];
+        }
+    }
+    in.c[0] = r; in.c[1] = gg; in.c[2] = b;
+    nf_ray_diff(qc + 12, cam + 12, x, y, z, in.rd);
+    in.mk = (nf_inbound(px, py, qc[0], qc[1]) && front) ? 1.f : 0.f;
+    if (live && h == 0) g.mask_out[row] = in.mk;
+}
+
 // base_fc.0 (105 -> 64), output tile NT: the [mean | var | f] feature blocks of 32 inputs and their 3 colour inputs each
 template <bool BF, int NT>
 __device__ __forceinline__ f32x16 base0_tile(const float* lds, int lane, int h, const RowActs& a) {
@@ -627,10 +688,10 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
     for (int c = 0; c < 3; ++c) a.rgb[c] = grp_sum<V>(a.beta * in.c[c]);
 }
 
-template <int V, bool BF>
+template <int V, bool BF, bool GATH>
 __global__ void __launch_bounds__(64 * NF_ROWS_FWD_WAVES, NF_ROWS_FWD_OCC) k_ibr_rows_fwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
-                                                         int64_t n_samples, int aa, float* __restrict__ smp) {
+                                                         int64_t n_samples, int aa, float* __restrict__ smp, RowGather gather) {
     HIP_DYNAMIC_SHARED(float, lds)
     static_assert(NF_BF_FWD_FLOATS == NF_MFMA_FWD_FLOATS, "both forward images are MS_END floats");
     for (int i = threadIdx.x; i < NF_MFMA_FWD_FLOATS; i += blockDim.x) lds[i] = wblob[i];      // BF: wblob is the bf16 image
@@ -648,7 +709,8 @@ __global__ void __launch_bounds__(64 * NF_ROWS_FWD_WAVES, NF_ROWS_FWD_OCC) k_ibr
         const int64_t sample = row / V;
         const int v = (int)(row - sample * V);
         RowIn in;
-        load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
+        if (GATH) load_row_gather<V>(gather, row, sample, v, h, live, in);
+        else load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
         RowActs a;
         rows_forward<V, BF>(lds, lane, h, aa, in, a);
         // per-sample record; the lane holding view 0 writes (both lane halves, 16 features each)
@@ -1665,32 +1727,37 @@ extern "C" int64_t nf_ibrnet_mfma_workspace_floats(int64_t n_rays, int n_samples
 
 template <int V>
 static void launch_rows_fwd(const float* wblob, const float* bf_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
-                            int64_t n_samples, int aa, float* smp, hipStream_t st) {
+                            int64_t n_samples, int aa, float* smp, const RowGather& g, hipStream_t st) {
     int64_t tiles = (n_samples * V + 31) / 32;
     int64_t blocks = (tiles + NF_ROWS_FWD_WAVES - 1) / NF_ROWS_FWD_WAVES;
     if (blocks > 1024) blocks = 1024;     // persistent-ish: 2 workgroups per CU hold the 58 KB weight image each
-    if (bf_blob)
-        hipLaunchKernelGGL((k_ibr_rows_fwd<V, true>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_FWD_WAVES), NF_BF_FWD_FLOATS * sizeof(float), st,
-                           bf_blob, rgb_feat, ray_diff, mask, n_samples, aa, smp);
-    else
-        hipLaunchKernelGGL((k_ibr_rows_fwd<V, false>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_FWD_WAVES), NF_MFMA_FWD_FLOATS * sizeof(float), st,
-                           wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp);
+#define NF_ROWS_FWD_GO(BFV, GV, blobp, floats)                                                                                          \
+    hipLaunchKernelGGL((k_ibr_rows_fwd<V, BFV, GV>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_FWD_WAVES), (floats) * sizeof(float), st, \
+                       blobp, rgb_feat, ray_diff, mask, n_samples, aa, smp, g)
+    if (g.featmap) {
+        if (bf_blob) NF_ROWS_FWD_GO(true, true, bf_blob, NF_BF_FWD_FLOATS);
+        else NF_ROWS_FWD_GO(false, true, wblob, NF_MFMA_FWD_FLOATS);
+    } else {
+        if (bf_blob) NF_ROWS_FWD_GO(true, false, bf_blob, NF_BF_FWD_FLOATS);
+        else NF_ROWS_FWD_GO(false, false, wblob, NF_MFMA_FWD_FLOATS);
+    }
+#undef NF_ROWS_FWD_GO
 }
 
 static int ibrnet_fwd_impl(const char* who, const float* bf_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
                            const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_rays, int n_samples, int n_views,
-                           int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream) {
+                           int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream, const RowGather& gather = RowGather{}) {
     NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: V must be a power of two <= 32 (got %d)", who, n_views);
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int64_t ns = n_rays * n_samples;
     switch (n_views) {
-        case 1: launch_rows_fwd<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        case 2: launch_rows_fwd<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        case 4: launch_rows_fwd<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        case 8: launch_rows_fwd<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        case 16: launch_rows_fwd<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
-        default: launch_rows_fwd<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, st); break;
+        case 1: launch_rows_fwd<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
+        case 2: launch_rows_fwd<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
+        case 4: launch_rows_fwd<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
+        case 8: launch_rows_fwd<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
+        case 16: launch_rows_fwd<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
+        default: launch_rows_fwd<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
     }
     NF_LAUNCH_CHECK("nf_ibrnet_fwd_mfma (rows)");
     if (n_samples == 32 || n_samples == 64 || n_samples == 128 || n_samples == 256) {       // per-ray part on the matrix cores as well
@@ -1736,6 +1803,24 @@ extern "C" int nf_ibrnet_fwd_mfma(const float* mfma_blob, const float* blob, con
                                   int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream) {
     return ibrnet_fwd_impl("nf_ibrnet_fwd_mfma", nullptr, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, n_rays, n_samples, n_views,
                            anti_alias_pooling, raw, workspace, stream);
+}
+
+/* nf_ibrnet_fwd_mfma (bf16_blob == nullptr) / nf_ibrnet_fwd_mfma_bf16 with Projector.compute folded into the row kernel: the inputs
+ * are the sample points, the camera workspace, the source images [V][H][W][3] and the channels-last feature maps [V][32][Hf][Wf]
+ * (fs_c == 1, pixel records 16-byte aligned); rgb_feat / ray_diff are never written, the validity mask [n_rays * n_samples * V] is. */
+extern "C" int nf_ibrnet_fwd_mfma_gather(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
+                                         const float* xyz, const float* cam_ws, const float* src_rgbs, int H, int W, const float* featmap,
+                                         int Hf, int Wf, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w, int64_t n_rays,
+                                         int n_samples, int n_views, int anti_alias_pooling, float* raw, float* workspace, float* mask_out,
+                                         nf_stream_t stream) {
+    if (n_rays == 0) return 0;
+    NF_REQUIRE(xyz && cam_ws && src_rgbs && featmap && mask_out && H >= 1 && W >= 1 && Hf >= 1 && Wf >= 1,
+               "nf_ibrnet_fwd_mfma_gather: bad arguments");
+    NF_REQUIRE(fs_c == 1 && fs_v % 4 == 0 && fs_h % 4 == 0 && fs_w % 4 == 0 && ((uintptr_t)featmap) % 16 == 0,
+               "nf_ibrnet_fwd_mfma_gather: the feature maps must be channels-last with 16-byte aligned pixel records");
+    const RowGather g = {xyz, cam_ws, src_rgbs, featmap, mask_out, fs_v, fs_h, fs_w, H, W, Hf, Wf};
+    return ibrnet_fwd_impl("nf_ibrnet_fwd_mfma_gather", bf16_blob, mfma_blob, blob, pos_enc, nullptr, nullptr, nullptr, n_rays, n_samples,
+                           n_views, anti_alias_pooling, raw, workspace, stream, g);
 }
 
 /* bf16_blob: device copy of nf_ibrnet_pack_mfma_bf16's output; the per-(sample, view) row network runs on bf16 operands with

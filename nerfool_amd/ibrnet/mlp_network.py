@@ -148,6 +148,19 @@ class IBRNet(nn.Module):
             self._blob_key = key
         return self._blob, self._mfma_blob
 
+    def can_gather(self, featmaps, n_samples, n_views):
+        """may forward_gathered take this level?  (matrix-core kernels, channels-last 32-channel maps, nothing to differentiate)"""
+        return (GATHER_BWD_FUSION == 'fused' and KERNEL_PATH != 'generic' and ops.ibrnet_mfma_supported(n_samples, n_views)
+                and not (torch.is_grad_enabled() and featmaps.requires_grad) and ops.ibrnet_gather_layout_ok(featmaps))
+
+    def forward_gathered(self, xyz, cam_ws, src_rgbs, featmaps):
+        """Projector.compute + forward for no-grad rendering: the row kernel projects the samples and takes its bilinear taps from
+        the feature maps / source images itself (ops.ibrnet_fwd_mfma_gather).  xyz [n_rays, n_samples, 3], cam_ws from
+        ops.camera_setup, src_rgbs [n_views, h, w, 3] -> raw [n_rays, n_samples, 4], mask [n_rays, n_samples, n_views]."""
+        blob, mfma_blob = self._packed(xyz.device)
+        return ops.ibrnet_fwd_mfma_gather(mfma_blob, blob, self.pos_encoding, xyz.detach(), cam_ws, src_rgbs.detach(), featmaps.detach(),
+                                          bool(self.anti_alias_pooling), bf16_blob=self._bf16_blob if self.precision == 'bf16' else None)
+
     def forward(self, rgb_feat, ray_diff, mask):
         """
         :param rgb_feat: [n_rays, n_samples, n_views, 35]

@@ -6,6 +6,7 @@ from collections import OrderedDict
 import torch
 
 from .. import ops
+from .projection import Projector
 
 
 def sample_along_camera_ray(ray_o, ray_d, depth_range, N_samples, inv_uniform=False, det=False):
@@ -62,10 +63,17 @@ def sample_fine_depths(z_vals, weights, N_importance, inv_uniform=False, det=Fal
 
 
 def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo_noise):
-    rgb_feat, ray_diff, mask = projector.compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'],
-                                                 featmaps=featmap)
-    pixel_mask = ops.pixel_mask(mask[..., 0])            # at least 2 observations (:210)
-    raw = net(rgb_feat, ray_diff, mask)
+    can = getattr(net, 'can_gather', None)
+    if can is not None and isinstance(projector, Projector) and can(featmap, pts.shape[1], src['src_cameras'].shape[1]):
+        # nothing to differentiate (rendering): projection + bilinear gather run inside the network's row kernel
+        cam_ws = ops.camera_setup(ray_batch['camera'].detach(), src['src_cameras'].detach())
+        raw, mask = net.forward_gathered(pts, cam_ws, src['src_rgbs'][0], featmap)
+        pixel_mask = ops.pixel_mask(mask)                    # at least 2 observations (:210)
+    else:
+        rgb_feat, ray_diff, mask = projector.compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'],
+                                                     featmaps=featmap)
+        pixel_mask = ops.pixel_mask(mask[..., 0])            # at least 2 observations (:210)
+        raw = net(rgb_feat, ray_diff, mask)
     return raw2outputs(raw, z_vals, pixel_mask, white_bkgd=white_bkgd, geo_noise=geo_noise)
 
 

@@ -211,6 +211,39 @@ def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_ali
     return raw, ws
 
 
+def ibrnet_gather_layout_ok(featmaps):
+    """the layout the gather-fused forward reads: 32 channels, channels-last, 16-byte aligned pixel records"""
+    sv, sc, sh, sw = featmaps.stride()
+    return (featmaps.dim() == 4 and featmaps.shape[1] == 32 and featmaps.dtype == torch.float32 and sc == 1 and sv % 4 == 0 and sh % 4 == 0
+            and sw % 4 == 0 and featmaps.data_ptr() % 16 == 0)
+
+
+def ibrnet_fwd_mfma_gather(mfma_blob, blob, pos_enc, xyz, cam_ws, src_rgbs, featmaps, anti_alias, bf16_blob=None):
+    """Projector.compute + IBRNet.forward in one pair of kernels (no-grad rendering): xyz [R,S,3], src_rgbs [V,H,W,3], featmaps
+    [V,32,Hf,Wf] channels-last -> raw [R,S,4], mask [R,S,V]; rgb_feat and ray_diff are never written."""
+    xyz, src_rgbs = _c(xyz, 'xyz'), _c(src_rgbs, 'src_rgbs')
+    _f32(featmaps, 'featmaps')
+    if not ibrnet_gather_layout_ok(featmaps):
+        raise ValueError('ibrnet_fwd_mfma_gather: feature maps must be [V,32,Hf,Wf] float32, channels-last, 16-byte aligned')
+    R, S, _ = xyz.shape
+    V, H, W, _ = src_rgbs.shape
+    _, _, Hf, Wf = featmaps.shape
+    pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
+    if pe.shape[0] != S:
+        raise ValueError('pos_encoding is built for %d samples, input has %d' % (pe.shape[0], S))
+    L = _lib.lib()
+    dev = xyz.device
+    ws = torch.empty(L.nf_ibrnet_mfma_workspace_floats(R, S), dtype=torch.float32, device=dev)
+    raw = torch.empty(R, S, 4, dtype=torch.float32, device=dev)
+    mask = torch.empty(R, S, V, dtype=torch.float32, device=dev)
+    sv, sc, sh, sw = featmaps.stride()
+    with prof.launch('nf_ibrnet_fwd_mfma_bf16' if bf16_blob is not None else 'nf_ibrnet_fwd_mfma', raw, R=R, S=S, V=V):
+        _lib.check(L.nf_ibrnet_fwd_mfma_gather(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(xyz), _ptr(cam_ws), _ptr(src_rgbs),
+                                               H, W, _ptr(featmaps), Hf, Wf, sv, sc, sh, sw, R, S, V, int(bool(anti_alias)), _ptr(raw), _ptr(ws),
+                                               _ptr(mask), _stream(raw)), 'nf_ibrnet_fwd_mfma_gather')
+    return raw, mask
+
+
 def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias, bf16_blob=None):
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     d_raw = _c(d_raw, 'd_raw')

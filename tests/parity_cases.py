@@ -560,6 +560,35 @@ def check_evaluate_view(dev):
     assert abs(clean['fine_psnr'] - zero['fine_psnr']) < 1e-3, (clean['fine_psnr'], zero['fine_psnr'])
 
 
+def check_gather_fused_forward(dev, shapes=((12, 64, 4), (5, 32, 8), (3, 128, 2))):
+    """The row kernel with Projector.compute folded in (no-grad rendering, ops.ibrnet_fwd_mfma_gather) against the stand-alone
+    gather + the row kernel on its output: same arithmetic tap by tap, so raw and mask must agree to the last bit (1e-6 allowed
+    for a differently contracted address computation); cameras that put samples behind a view and outside the maps included."""
+    from nerfool_amd.synthetic import make_scene
+    gen = torch.Generator().manual_seed(11)
+    for (R, S, V) in shapes:
+        H, W = 40, 56
+        data = make_scene(H, W, V, seed=3, tilt=0.3, push_forward=3.0)
+        net = IBRNet(SimpleNamespace(anti_alias_pooling=1), in_feat_ch=32, n_samples=S).to(dev)
+        fm = torch.randn(V, 12, 16, 32, generator=gen).to(dev).permute(0, 3, 1, 2)          # channels-last storage
+        src_rgbs = data['src_rgbs'].to(dev)
+        cams = data['src_cameras'].to(dev)
+        sampler = RaySamplerSingleImage(data, dev)
+        rb = sampler.get_all()
+        idx = torch.randint(0, H * W, (R,), generator=gen).to(dev)
+        ray_o, ray_d = rb['ray_o'][idx], rb['ray_d'][idx]
+        pts, _ = sample_along_camera_ray(ray_o, ray_d, rb['depth_range'], S, inv_uniform=False, det=True)
+        with torch.no_grad():
+            assert net.can_gather(fm, S, V)
+            cam_ws = ops.camera_setup(rb['camera'], cams)
+            raw_f, mask_f = net.forward_gathered(pts, cam_ws, src_rgbs[0], fm)
+            rgb_feat, ray_diff, mask = Projector(dev).compute(pts, rb['camera'], src_rgbs, cams, featmaps=fm)
+            raw = net(rgb_feat, ray_diff, mask)
+        assert torch.equal(mask_f, mask[..., 0]), 'validity mask of the fused gather'
+        assert 0.02 < float(mask_f.mean()) < 0.98, float(mask_f.mean())      # views that see the sample and views that do not
+        assert_close(raw_f, raw, 1e-6, 1e-6 * float(raw.abs().max()), 'raw through the gather-fused rows kernel (R %d S %d V %d)' % (R, S, V))
+
+
 def check_ragged_ray_batches(dev):
     """Edge sizes of a ray batch: none, one, three rays (a chunk's ragged tail, render_image.py:52-102; an N_rand that leaves a
     rank without rays).  Shapes for the empty batch; the small batches equal the first rows of a larger batch's

@@ -97,6 +97,15 @@ def test_universal_trajectory():
     pc.check_universal_trajectory('cpu', steps=2)      # both target views once; the full loop runs on the GPU
 
 
+def test_gather_fused_forward():
+    from nerfool_amd.ibrnet import mlp_network
+    mlp_network.KERNEL_PATH = 'auto'          # the gather-fused forward belongs to the matrix-core kernels
+    try:
+        pc.check_gather_fused_forward('cpu', shapes=((3, 32, 4),))
+    finally:
+        mlp_network.KERNEL_PATH = 'generic'
+
+
 def test_ragged_ray_batches():
     pc.check_ragged_ray_batches('cpu')
 

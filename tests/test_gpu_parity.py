@@ -137,6 +137,10 @@ def test_eval_views_gnt_and_frames():
     pc.check_eval_views_gnt_and_frames('cuda')
 
 
+def test_gather_fused_forward():
+    pc.check_gather_fused_forward('cuda')
+
+
 def test_ragged_ray_batches():
     pc.check_ragged_ray_batches('cuda')
 
