@@ -1560,12 +1560,15 @@ __device__ __forceinline__ f32x16 ray_gemm8_T(const float* rs, int rec, int lane
 // LDS per ray in the backward: K, V, Q, dO [S][16]; M, Linv, D [S][4]
 #define RAY_BWD_LDS_PER_SAMPLE (4 * 16 + 3 * 4)
 
-template <int WPR>
-__global__ void __launch_bounds__(WPR > 4 ? 64 * WPR : 256, WPR > 4 ? 2 : 1) k_ibr_ray_bwd_mfma(const float* __restrict__ wblob, const float* __restrict__ pos_enc,
+// NWV: waves per workgroup (4 or 8; at least WPR).  The weight image takes 65 KB of LDS, so one workgroup per CU: with 8 waves
+// (two per SIMD, 247 registers each) the VALU attention of one wave runs under the LDS / matrix work of the other -- chosen by the
+// host whenever the rays still fill the chip at 8 / WPR rays per workgroup.
+template <int WPR, int NWV>
+__global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd_mfma(const float* __restrict__ wblob, const float* __restrict__ pos_enc,
                                                              const float* __restrict__ smp, const float* __restrict__ d_raw,
                                                              int64_t n_rays, float* __restrict__ d_smp) {
     HIP_DYNAMIC_SHARED(float, lds)
-    constexpr int S = 32 * WPR, NW = WPR > 4 ? WPR : 4, RPI = NW / WPR;
+    constexpr int S = 32 * WPR, NW = WPR > NWV ? WPR : NWV, RPI = NW / WPR;
     float* rs = lds;
     float* ray_lds = lds + RY_FLOATS;
     for (int i = threadIdx.x; i < RY_FLOATS; i += blockDim.x) rs[i] = wblob[RY_BASE + i];
@@ -1867,24 +1870,32 @@ static int launch_rows_bwd_any(const float* wblob, const float* bf_blob, const f
                    : launch_rows_bwd<V, false, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, st);
 }
 
-template <int WPR>
-static int launch_ray_bwd(const float* mfma_blob, const float* pos_enc, const float* smp, const float* d_raw, int64_t n_rays,
-                          float* d_workspace, hipStream_t st) {
-    constexpr int nw = WPR > 4 ? WPR : 4, rpi = nw / WPR;
+template <int WPR, int NWV>
+static int launch_ray_bwd_nw(const float* mfma_blob, const float* pos_enc, const float* smp, const float* d_raw, int64_t n_rays,
+                             float* d_workspace, hipStream_t st) {
+    constexpr int nw = WPR > NWV ? WPR : NWV, rpi = nw / WPR;
     int64_t iters = (n_rays + rpi - 1) / rpi;
     unsigned blocks = (unsigned)(iters < 256 ? iters : 256);
     size_t smem_ray = (size_t)(RY_FLOATS + nw * 32 * RAY_BWD_LDS_PER_SAMPLE) * sizeof(float);
     static bool configured_on[NF_MAX_DEVICES] = {};
     bool& configured = configured_on[nf_current_device()];
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)k_ibr_ray_bwd_mfma<WPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ray) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_ibr_ray_bwd_mfma<WPR, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_ray) != hipSuccess) {
             nf_set_error("nf_ibrnet_bwd_mfma: cannot reserve %zu bytes of LDS", smem_ray);
             return 1;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(k_ibr_ray_bwd_mfma<WPR>, dim3(blocks), dim3(64 * nw), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
+    hipLaunchKernelGGL((k_ibr_ray_bwd_mfma<WPR, NWV>), dim3(blocks), dim3(64 * nw), smem_ray, st, mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace);
     return 0;
+}
+
+template <int WPR>
+static int launch_ray_bwd(const float* mfma_blob, const float* pos_enc, const float* smp, const float* d_raw, int64_t n_rays,
+                          float* d_workspace, hipStream_t st) {
+    // eight waves per workgroup once every CU still gets a workgroup that way
+    if (WPR < 8 && n_rays * WPR >= 8 * 256) return launch_ray_bwd_nw<WPR, 8>(mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace, st);
+    return launch_ray_bwd_nw<WPR, 4>(mfma_blob, pos_enc, smp, d_raw, n_rays, d_workspace, st);
 }
 
 static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
