@@ -1766,7 +1766,7 @@ static int ibrnet_fwd_impl(const char* who, const float* bf_blob, const float* m
     if (n_samples == 32 || n_samples == 64 || n_samples == 128 || n_samples == 256) {       // per-ray part on the matrix cores as well
         const int wpr = n_samples / 32, nw = wpr > 4 ? wpr : 4, rpi = nw / wpr;
         int64_t iters = (n_rays + rpi - 1) / rpi;
-        unsigned blocks = (unsigned)(iters < 512 ? iters : 512);
+        unsigned blocks = (unsigned)(iters < 768 ? iters : 768);
         size_t smem_ray = (size_t)(RYF_FLOATS + nw * 32 * 32) * sizeof(float);
         if (wpr == 1)
             hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<1>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);
