@@ -495,6 +495,9 @@ def main():
                            'total_ms': round(k['total_ms'], 3)}
     if 'nf_conv3x3_wino' in table:
         table['nf_conv3x3_wino']['direct_form_equivalent_tflops'] = round(float(np.mean(wino_direct)), 2)
+    if 'nf_ibrnet_bwd_mfma' in table and 'nf_project_gather_bwd' not in table:
+        table['nf_ibrnet_bwd_mfma']['includes'] = ('the scatter of d rgb_feat into the feature-map gradient (float atomics, formerly '
+                                                   'nf_project_gather_bwd: 0.11 ms per launch) -- not counted in the FLOPs')
     dominant = max(table, key=lambda n: table[n]['total_ms']) if table else None
     roofline = None
     if dominant:

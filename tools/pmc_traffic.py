@@ -38,10 +38,13 @@ def main():
                          'hbm_bytes_per_launch': int(2 * 1024 * sum(f) / len(f) + 1024 * sum(w) / len(w))}
     R, V = 512, 4
     alg = {}
+    # the scatter of d rgb_feat runs inside the backward row kernel when no stand-alone k_project_gather_bwd was launched:
+    # no d rgb_feat write (35 floats per row), 4 taps x 32 channels added to the feature-map gradient instead
+    fused_scatter = not any(name.startswith('k_project_gather_bwd') for name in kernels)
     for S in (64, 128):
         n = R * S
         alg[S] = {'nf_ibrnet_fwd_mfma': n * (V * 40 * 4 + (72 + 72 + 4) * 4),
-                  'nf_ibrnet_bwd_mfma': n * (V * (40 + 35) * 4 + (76 + 72 + 72) * 4),
+                  'nf_ibrnet_bwd_mfma': n * (V * ((40 + (0 if fused_scatter else 35)) * 4 + (4 * 32 * 4 if fused_scatter else 0)) + (76 + 72 + 72) * 4),
                   'nf_project_gather_fwd': n * V * (4 * 35 * 4 + 44 * 4), 'nf_project_gather_bwd': n * V * (35 * 4 + 4 * 32 * 4)}
     abi = {}
     for entry, prefixes in ABI.items():
@@ -52,6 +55,8 @@ def main():
         calls = 1 if entry == 'nf_pgd_adam_step' else 2          # coarse + fine level per step
         if entry in ('nf_conv3x3_wino', 'nf_conv_s2_fwd', 'nf_conv_s2_bwd'):     # one kernel launch per call
             calls = sum(k['launches_per_step'] for name, k in kernels.items() if name.startswith(prefixes)) or 1
+        if tot == 0.0:          # not launched in this configuration (fused into another entry point)
+            continue
         abi[entry] = {'hbm_bytes_per_launch': int(tot / calls), 'calls_per_step': calls}
         if entry in alg[64]:
             abi[entry]['algorithmic_bytes_per_launch'] = int((alg[64][entry] + alg[128][entry]) / 2)
