@@ -142,6 +142,14 @@ int nf_ibrnet_fwd_mfma_gather(const float* bf16_blob, const float* mfma_blob, co
                               const float* cam_ws, const float* src_rgbs, int H, int W, const float* featmap, int Hf, int Wf,
                               int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w, int64_t n_rays, int n_samples, int n_views,
                               int anti_alias_pooling, float* raw, float* workspace, float* mask_out, nf_stream_t stream);
+/* backward of nf_ibrnet_fwd_mfma_gather (fp32 rows): the recompute gathers from the feature maps again, the output stage scatters
+ * into d_featmap [V][32][Hf][Wf] (element strides ds_*, ZEROED by the caller) -- the attack step then holds neither rgb_feat nor
+ * its gradient in memory.  smp = the forward's workspace. */
+int nf_ibrnet_bwd_mfma_gather_scatter(const float* mfma_blob, const float* blob, const float* pos_enc, const float* smp, const float* d_raw,
+                                      int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_workspace,
+                                      const float* xyz, const float* cam_ws, const float* src_rgbs, int H, int W, const float* featmap,
+                                      int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w, float* d_featmap, int64_t ds_v, int64_t ds_c,
+                                      int64_t ds_h, int64_t ds_w, int Hf, int Wf, nf_stream_t stream);
 /* bf16-operand variant of the matrix-core path (BASELINE config 5, "bf16 MFMA path"): the per-(sample, view) row network of
  * IBRNet.forward (ibrnet/mlp_network.py:231-257, 268-273: ray_dir_fc, base_fc, vis_fc, vis_fc2, rgb_fc) runs on
  * v_mfma_f32_32x32x16_bf16 -- weights and activations rounded to bf16 at the matrix-core inputs, fp32 accumulation; pooling,

@@ -46,6 +46,8 @@ _PROTOTYPES = {
     'nf_ibrnet_bwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_ibrnet_fwd_mfma_gather': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                           c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
+    'nf_ibrnet_bwd_mfma_gather_scatter': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, c_int64,
+                                                  c_int64, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, _P]),
     'nf_ibrnet_bwd_mfma_scatter': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64,
                                            c_int64, c_int64, c_int, c_int, _P]),
     'nf_ibrnet_mfma_bf16_blob_floats': (c_int64, []),

@@ -552,7 +552,7 @@ __device__ __forceinline__ void load_row_gather(const RowGather& g, int64_t row,
     in.c[0] = r; in.c[1] = gg; in.c[2] = b;
     nf_ray_diff(qc + 12, cam + 12, x, y, z, in.rd);
     in.mk = (nf_inbound(px, py, qc[0], qc[1]) && front) ? 1.f : 0.f;
-    if (live && h == 0) g.mask_out[row] = in.mk;
+    if (live && h == 0 && g.mask_out) g.mask_out[row] = in.mk;
 }
 
 // base_fc.0 (105 -> 64), output tile NT: the [mean | var | f] feature blocks of 32 inputs and their 3 colour inputs each
@@ -911,11 +911,11 @@ struct RowScatter {
 #define RS_TAP 8              // per row: 4 tap weights, x0, y0 (as int bits), view, pad
 #define RS_FLOATS (32 * RS_ROW + 32 * RS_TAP)
 
-template <int V, bool BF, bool SCAT>
+template <int V, bool BF, bool SCAT, bool GATH>
 __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_OCC) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                          const float* __restrict__ d_smp, int64_t n_samples, int aa,
-                                                         float* __restrict__ d_rgb_feat, RowScatter sc) {
+                                                         float* __restrict__ d_rgb_feat, RowScatter sc, RowGather gather) {
     HIP_DYNAMIC_SHARED(float, lds)
     for (int i = threadIdx.x; i < (BF ? (int)NF_BF_BLOB_FLOATS : (int)NF_ROWS_BLOB_FLOATS); i += blockDim.x) lds[i] = wblob[i];
     __syncthreads();
@@ -930,7 +930,8 @@ __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_O
         if (!live) row = n_rows - 1;
         const int64_t sample = row / V;
         RowIn in;
-        load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
+        if (GATH) load_row_gather<V>(gather, row, sample, (int)(row - sample * V), h, live, in);      // the recompute gathers again: no rgb_feat anywhere
+        else load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
         RowActs a;
         rows_forward<V, BF>(lds, lane, h, aa, in, a);
         const float* g = d_smp + sample * NF_SMP_STRIDE;
@@ -1836,15 +1837,16 @@ extern "C" int nf_ibrnet_fwd_mfma_bf16(const float* bf16_blob, const float* mfma
                            n_views, anti_alias_pooling, raw, workspace, stream);
 }
 
-template <int V, bool BF, bool SCAT>
+template <int V, bool BF, bool SCAT, bool GATH>
 static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
-                           const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, hipStream_t st) {
+                           const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, const RowGather& ga,
+                           hipStream_t st) {
     static bool configured_on[NF_MAX_DEVICES] = {};      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel and device
     bool& configured = configured_on[nf_current_device()];
     // the weight image (+ one staging tile per wave for the fused scatter)
     const size_t smem = ((BF ? (size_t)NF_BF_BLOB_FLOATS : (size_t)NF_ROWS_BLOB_FLOATS) + (SCAT ? NF_ROWS_BWD_WAVES * RS_FLOATS : 0)) * sizeof(float);
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V, BF, SCAT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V, BF, SCAT, GATH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
             hipSuccess) {
             nf_set_error("nf_ibrnet_bwd_mfma: cannot reserve %zu bytes of LDS", smem);
             return 1;
@@ -1856,18 +1858,21 @@ static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const floa
     // fp32: one workgroup per CU holds the 113 KB weight image (fwd + transposed); bf16: 64 KB, two per CU
     const int64_t cap = BF ? 1024 : 512;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF, SCAT>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask,
-                       d_smp, n_samples, aa, d_rgb_feat, sc);
+    hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF, SCAT, GATH>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask,
+                       d_smp, n_samples, aa, d_rgb_feat, sc, ga);
     return 0;
 }
 
 template <int V>
 static int launch_rows_bwd_any(const float* wblob, const float* bf_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
-                               const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, hipStream_t st) {
-    if (sc.d_featmap)       // fused scatter: exact-fp32 rows only (the bf16 image leaves no LDS for the staging tiles at two workgroups per CU)
-        return launch_rows_bwd<V, false, true>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, st);
-    return bf_blob ? launch_rows_bwd<V, true, false>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, st)
-                   : launch_rows_bwd<V, false, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, st);
+                               const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, const RowGather& ga,
+                               hipStream_t st) {
+    if (sc.d_featmap) {     // fused scatter: exact-fp32 rows only (the bf16 image leaves no LDS for the staging tiles at two workgroups per CU)
+        if (ga.featmap) return launch_rows_bwd<V, false, true, true>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st);
+        return launch_rows_bwd<V, false, true, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st);
+    }
+    return bf_blob ? launch_rows_bwd<V, true, false, false>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st)
+                   : launch_rows_bwd<V, false, false, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st);
 }
 
 template <int WPR, int NWV>
@@ -1901,9 +1906,10 @@ static int launch_ray_bwd(const float* mfma_blob, const float* pos_enc, const fl
 static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
                            const float* rgb_feat, const float* ray_diff, const float* mask, const float* smp, const float* d_raw,
                            int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat,
-                           float* d_workspace, nf_stream_t stream, const RowScatter& sc = RowScatter{}) {
+                           float* d_workspace, nf_stream_t stream, const RowScatter& sc = RowScatter{}, const RowGather& ga = RowGather{}) {
     NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: V must be a power of two <= 32 (got %d)", who, n_views);
     NF_REQUIRE(!(sc.d_featmap && bf_blob), "%s: the fused scatter runs with the fp32 row kernels", who);
+    NF_REQUIRE(!ga.featmap || sc.d_featmap, "%s: the gathering recompute comes with the fused scatter", who);
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int threads = ((n_samples + 63) / 64) * 64;
@@ -1931,12 +1937,12 @@ static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* m
     int64_t ns = n_rays * n_samples;
     int rc;
     switch (n_views) {
-        case 1: rc = launch_rows_bwd_any<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
-        case 2: rc = launch_rows_bwd_any<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
-        case 4: rc = launch_rows_bwd_any<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
-        case 8: rc = launch_rows_bwd_any<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
-        case 16: rc = launch_rows_bwd_any<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
-        default: rc = launch_rows_bwd_any<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, st); break;
+        case 1: rc = launch_rows_bwd_any<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        case 2: rc = launch_rows_bwd_any<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        case 4: rc = launch_rows_bwd_any<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        case 8: rc = launch_rows_bwd_any<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        case 16: rc = launch_rows_bwd_any<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        default: rc = launch_rows_bwd_any<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
     }
     if (rc) return rc;
     NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (rows)");
@@ -1965,6 +1971,25 @@ extern "C" int nf_ibrnet_bwd_mfma_scatter(const float* mfma_blob, const float* b
     const RowScatter sc = {xyz, cam_ws, d_featmap, fs_v, fs_c, fs_h, fs_w, Hf, Wf};
     return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma_scatter", nullptr, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, n_rays,
                            n_samples, n_views, anti_alias_pooling, nullptr, d_workspace, stream, sc);
+}
+
+/* backward of nf_ibrnet_fwd_mfma_gather (bf16_blob == nullptr): the row kernel's recompute gathers from the feature maps again and
+ * its output stage scatters into d_featmap (zeroed by the caller) -- neither rgb_feat nor its gradient exists in memory. */
+extern "C" int nf_ibrnet_bwd_mfma_gather_scatter(const float* mfma_blob, const float* blob, const float* pos_enc, const float* smp,
+                                                 const float* d_raw, int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling,
+                                                 float* d_workspace, const float* xyz, const float* cam_ws, const float* src_rgbs, int H,
+                                                 int W, const float* featmap, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
+                                                 float* d_featmap, int64_t ds_v, int64_t ds_c, int64_t ds_h, int64_t ds_w, int Hf, int Wf,
+                                                 nf_stream_t stream) {
+    if (n_rays == 0) return 0;
+    NF_REQUIRE(xyz && cam_ws && src_rgbs && featmap && d_featmap && H >= 1 && W >= 1 && Hf >= 1 && Wf >= 1,
+               "nf_ibrnet_bwd_mfma_gather_scatter: bad arguments");
+    NF_REQUIRE(fs_c == 1 && fs_v % 4 == 0 && fs_h % 4 == 0 && fs_w % 4 == 0 && ((uintptr_t)featmap) % 16 == 0,
+               "nf_ibrnet_bwd_mfma_gather_scatter: the feature maps must be channels-last with 16-byte aligned pixel records");
+    const RowScatter sc = {xyz, cam_ws, d_featmap, ds_v, ds_c, ds_h, ds_w, Hf, Wf};
+    const RowGather ga = {xyz, cam_ws, src_rgbs, featmap, nullptr, fs_v, fs_h, fs_w, H, W, Hf, Wf};
+    return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma_gather_scatter", nullptr, mfma_blob, blob, pos_enc, nullptr, nullptr, nullptr, smp, d_raw,
+                           n_rays, n_samples, n_views, anti_alias_pooling, nullptr, d_workspace, stream, sc, ga);
 }
 
 extern "C" int nf_ibrnet_bwd_mfma_bf16(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc,

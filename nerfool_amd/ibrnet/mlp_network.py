@@ -99,9 +99,32 @@ class _IBRNetGatherFunction(torch.autograd.Function):
         return (d_feat,) + (None,) * 9
 
 
-# 'fused' (default): where Projector.compute handed over its gather context, the adjoint of the gather runs inside the IBRNet
-# backward; 'separate': nf_ibrnet_bwd_mfma writes d rgb_feat and nf_project_gather_bwd scatters it (always so with the generic
-# kernels, the bf16 rows and NERFOOL_GATHER_BWD=deterministic)
+class _IBRNetGatheredFunction(torch.autograd.Function):
+    """IBRNet.forward_gathered with a gradient: forward = ops.ibrnet_fwd_mfma_gather (projection + taps inside the row kernel),
+    backward = ops.ibrnet_bwd_mfma_gather_scatter (the recompute gathers again, the output stage scatters) -- neither rgb_feat
+    nor its gradient exists in memory.  The mask (second output) is a constant of the step."""
+
+    @staticmethod
+    def forward(ctx, featmaps, xyz, cam_ws, src_rgbs, blob, mfma_blob, pos_enc, anti_alias):
+        raw, mask, smp = ops.ibrnet_fwd_mfma_gather(mfma_blob, blob, pos_enc, xyz, cam_ws, src_rgbs, featmaps, anti_alias)
+        ctx.save_for_backward(featmaps, xyz, cam_ws, src_rgbs, blob, mfma_blob, pos_enc, smp)
+        ctx.anti_alias = anti_alias
+        ctx.mark_non_differentiable(mask)
+        return raw, mask
+
+    @staticmethod
+    def backward(ctx, d_raw, _d_mask):
+        featmaps, xyz, cam_ws, src_rgbs, blob, mfma_blob, pos_enc, smp = ctx.saved_tensors
+        d_feat = ops.ibrnet_bwd_mfma_gather_scatter(mfma_blob, blob, pos_enc, smp, d_raw, ctx.anti_alias, xyz, cam_ws, src_rgbs, featmaps)
+        return (d_feat,) + (None,) * 7
+
+
+# 'fused' (default): rendering gathers inside the row kernel (no rgb_feat at all); the attack's forward runs the stand-alone
+# gather, its backward scatters d rgb_feat from inside the row kernel.  'full': the attack gathers inside the row kernels in both
+# directions as well -- neither rgb_feat nor its gradient ever exists in memory (the literal north-star data flow; measured 3 %
+# slower per step at N_rand 4096: the backward's recompute pays for the taps a second time at one wave per SIMD).
+# 'separate': nf_project_gather_fwd / nf_ibrnet_* / nf_project_gather_bwd as three stages (always so with the generic kernels;
+# the bf16 rows and NERFOOL_GATHER_BWD=deterministic keep the stand-alone scatter)
 GATHER_BWD_FUSION = os.environ.get('NERFOOL_GATHER_FUSION', 'fused')
 
 
@@ -149,17 +172,30 @@ class IBRNet(nn.Module):
         return self._blob, self._mfma_blob
 
     def can_gather(self, featmaps, n_samples, n_views):
-        """may forward_gathered take this level?  (matrix-core kernels, channels-last 32-channel maps, nothing to differentiate)"""
-        return (GATHER_BWD_FUSION == 'fused' and KERNEL_PATH != 'generic' and ops.ibrnet_mfma_supported(n_samples, n_views)
-                and not (torch.is_grad_enabled() and featmaps.requires_grad) and ops.ibrnet_gather_layout_ok(featmaps))
+        """may forward_gathered take this level?  Matrix-core kernels and channels-last 32-channel maps; with a gradient to
+        propagate also the exact-fp32 rows and the atomic scatter (the fused backward is built for those)."""
+        if not (GATHER_BWD_FUSION in ('fused', 'full') and KERNEL_PATH != 'generic' and ops.ibrnet_mfma_supported(n_samples, n_views)
+                and ops.ibrnet_gather_layout_ok(featmaps)):
+            return False
+        if torch.is_grad_enabled() and featmaps.requires_grad:
+            # gathering again in the backward's recompute is slower than re-reading the rgb_feat the forward's stand-alone gather
+            # left behind (N_rand 4096: 15.2 against 14.7 ms per step): only on request
+            return GATHER_BWD_FUSION == 'full' and self.precision == 'fp32' and ops.GATHER_BWD != 'deterministic'
+        return True
 
     def forward_gathered(self, xyz, cam_ws, src_rgbs, featmaps):
-        """Projector.compute + forward for no-grad rendering: the row kernel projects the samples and takes its bilinear taps from
-        the feature maps / source images itself (ops.ibrnet_fwd_mfma_gather).  xyz [n_rays, n_samples, 3], cam_ws from
-        ops.camera_setup, src_rgbs [n_views, h, w, 3] -> raw [n_rays, n_samples, 4], mask [n_rays, n_samples, n_views]."""
+        """Projector.compute + forward in the network's own kernels: the row kernel projects the samples and takes its bilinear
+        taps from the feature maps / source images itself (ops.ibrnet_fwd_mfma_gather); differentiable w.r.t. the feature maps
+        (_IBRNetGatheredFunction).  xyz [n_rays, n_samples, 3], cam_ws from ops.camera_setup, src_rgbs [n_views, h, w, 3]
+        -> raw [n_rays, n_samples, 4], mask [n_rays, n_samples, n_views]."""
         blob, mfma_blob = self._packed(xyz.device)
-        return ops.ibrnet_fwd_mfma_gather(mfma_blob, blob, self.pos_encoding, xyz.detach(), cam_ws, src_rgbs.detach(), featmaps.detach(),
-                                          bool(self.anti_alias_pooling), bf16_blob=self._bf16_blob if self.precision == 'bf16' else None)
+        if torch.is_grad_enabled() and featmaps.requires_grad:
+            return _IBRNetGatheredFunction.apply(featmaps, xyz.detach(), cam_ws, src_rgbs.detach(), blob, mfma_blob, self.pos_encoding,
+                                                 bool(self.anti_alias_pooling))
+        raw, mask, _ = ops.ibrnet_fwd_mfma_gather(mfma_blob, blob, self.pos_encoding, xyz.detach(), cam_ws, src_rgbs.detach(),
+                                                  featmaps.detach(), bool(self.anti_alias_pooling),
+                                                  bf16_blob=self._bf16_blob if self.precision == 'bf16' else None)
+        return raw, mask
 
     def forward(self, rgb_feat, ray_diff, mask):
         """
@@ -170,7 +206,7 @@ class IBRNet(nn.Module):
         """
         blob, mfma_blob = self._packed(rgb_feat.device)
         gather = getattr(rgb_feat, '_nf_gather', None)
-        if (gather is not None and GATHER_BWD_FUSION == 'fused' and self.precision == 'fp32' and KERNEL_PATH != 'generic'
+        if (gather is not None and GATHER_BWD_FUSION in ('fused', 'full') and self.precision == 'fp32' and KERNEL_PATH != 'generic'
                 and ops.GATHER_BWD != 'deterministic' and torch.is_grad_enabled() and gather[2].requires_grad
                 and gather[2].shape[1] == 32 and ops.ibrnet_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])):
             pts, cam_ws, featmaps = gather

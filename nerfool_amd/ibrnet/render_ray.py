@@ -65,7 +65,7 @@ def sample_fine_depths(z_vals, weights, N_importance, inv_uniform=False, det=Fal
 def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo_noise):
     can = getattr(net, 'can_gather', None)
     if can is not None and isinstance(projector, Projector) and can(featmap, pts.shape[1], src['src_cameras'].shape[1]):
-        # nothing to differentiate (rendering): projection + bilinear gather run inside the network's row kernel
+        # projection + bilinear gather run inside the network's row kernel (and their adjoint inside its backward)
         cam_ws = ops.camera_setup(ray_batch['camera'].detach(), src['src_cameras'].detach())
         raw, mask = net.forward_gathered(pts, cam_ws, src['src_rgbs'][0], featmap)
         pixel_mask = ops.pixel_mask(mask)                    # at least 2 observations (:210)

@@ -241,7 +241,30 @@ def ibrnet_fwd_mfma_gather(mfma_blob, blob, pos_enc, xyz, cam_ws, src_rgbs, feat
         _lib.check(L.nf_ibrnet_fwd_mfma_gather(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(xyz), _ptr(cam_ws), _ptr(src_rgbs),
                                                H, W, _ptr(featmaps), Hf, Wf, sv, sc, sh, sw, R, S, V, int(bool(anti_alias)), _ptr(raw), _ptr(ws),
                                                _ptr(mask), _stream(raw)), 'nf_ibrnet_fwd_mfma_gather')
-    return raw, mask
+    return raw, mask, ws
+
+
+def ibrnet_bwd_mfma_gather_scatter(mfma_blob, blob, pos_enc, smp, d_raw, anti_alias, xyz, cam_ws, src_rgbs, featmaps):
+    """backward of ibrnet_fwd_mfma_gather (fp32 rows): d_raw [R,S,4] -> d_featmaps [V,32,Hf,Wf] (channels-last storage); the row
+    kernel gathers again for its recompute and scatters from its output stage."""
+    xyz, src_rgbs, d_raw = _c(xyz, 'xyz'), _c(src_rgbs, 'src_rgbs'), _c(d_raw, 'd_raw')
+    if not ibrnet_gather_layout_ok(featmaps):
+        raise ValueError('ibrnet_bwd_mfma_gather_scatter: feature maps must be [V,32,Hf,Wf] float32, channels-last, 16-byte aligned')
+    R, S, _ = xyz.shape
+    V, H, W, _ = src_rgbs.shape
+    _, C, Hf, Wf = featmaps.shape
+    pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
+    d_ws = torch.empty_like(smp)
+    sv, sc, sh, sw = featmaps.stride()
+    d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
+    dv, dc, dh, dw = d_feat.stride()
+    with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
+        _lib.check(_lib.lib().nf_ibrnet_bwd_mfma_gather_scatter(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(smp), _ptr(d_raw), R, S, V,
+                                                                int(bool(anti_alias)), _ptr(d_ws), _ptr(xyz), _ptr(cam_ws), _ptr(src_rgbs), H, W,
+                                                                _ptr(featmaps), sv, sc, sh, sw, _ptr(d_feat), dv, dc, dh, dw, Hf, Wf,
+                                                                _stream(d_raw)),
+                   'nf_ibrnet_bwd_mfma_gather_scatter')
+    return d_feat
 
 
 def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias, bf16_blob=None):

@@ -157,7 +157,7 @@ def test_render_rays_through_mfma_kernels():
     from nerfool_amd.ibrnet import mlp_network
     mlp_network.KERNEL_PATH = 'auto'
     try:
-        pc.check_render_rays('ibrnet_tiny_invu', 'cpu')
+        pc.check_render_rays('ibrnet_tiny_invu', 'cpu')       # default: stand-alone gather, scatter fused into the backward
     finally:
         mlp_network.KERNEL_PATH = 'generic'
 

@@ -137,6 +137,17 @@ def test_eval_views_gnt_and_frames():
     pc.check_eval_views_gnt_and_frames('cuda')
 
 
+def test_render_rays_fully_fused_gather():
+    """NERFOOL_GATHER_FUSION=full: gather inside the row kernels in both directions (no rgb_feat in memory), same parity bars."""
+    from nerfool_amd.ibrnet import mlp_network
+    mlp_network.GATHER_BWD_FUSION = 'full'
+    try:
+        pc.check_render_rays('ibrnet_tiny_invu', 'cuda')
+        pc.check_render_rays('ibrnet_medium', 'cuda')
+    finally:
+        mlp_network.GATHER_BWD_FUSION = 'fused'
+
+
 def test_gather_fused_forward():
     pc.check_gather_fused_forward('cuda')
 
