@@ -564,7 +564,7 @@ extern "C" int nf_conv3x3_bwd_ring(const float* ring_records, const float* dy, i
     // line pieces of WR_NI images, or the eight waves' partial sums, whichever is larger
     size_t smem = sizeof(float) * (size_t)WR_NI * c_dy * WR_XS;
     if (smem < sizeof(float) * WR_WAVES * WR_NI * WR_POS * 64) smem = sizeof(float) * WR_WAVES * WR_NI * WR_POS * 64;
-    NF_REQUIRE(smem <= 64 * 1024, "nf_conv3x3_bwd_ring: at most 341 gradient channels (got %d)", c_dy);
+    NF_REQUIRE(smem <= 64 * 1024, "nf_conv3x3_bwd_ring: at most %d gradient channels (got %d)", 64 * 1024 / (4 * WR_NI * WR_XS), c_dy);
     hipLaunchKernelGGL(k_wino_ring, dim3((unsigned)chunks, (unsigned)((c_dx + 63) / 64), (unsigned)((n_img + WR_NI - 1) / WR_NI)), dim3(64 * WR_WAVES),
                        smem, (hipStream_t)stream, ring_records, dy, di, H, W, g, go, c_dy, c_dx, kinds, col_rows, n_img);
     NF_LAUNCH_CHECK("nf_conv3x3_bwd_ring");

@@ -287,7 +287,7 @@ def _conv3x3(tape, inp, w, sink):
         # planes whose (H + 2) x (W + 2) gradient needs many more 8 x 16 output blocks than the H x W plane itself (48 x 63: 35
         # against 24): the Winograd kernel on the interior-aligned region + the 1-D border ring kernel (a rule on the shape, not a
         # timing: the two forms round differently)
-        plan = ops.wino_bwd_split_plan(g_out.shape[2], g_out.shape[3])
+        plan = ops.wino_bwd_split_plan(g_out.shape[2], g_out.shape[3]) if g_out.shape[1] <= ops.WINO_RING_MAX_CHANNELS else None
 
         def bwd_data(kpg):
             rec = _wino_records(w, kpg)[1]

@@ -727,6 +727,9 @@ def wino_ring_pack(weight, device):
     return out.to(device)
 
 
+WINO_RING_MAX_CHANNELS = 1365     # gradient channels whose line pieces fit the ring kernel's 64 KB of LDS (nf_conv3x3_bwd_ring)
+
+
 def _wino_blocks(h, w):
     return -(-h // 8) * -(-w // 16)
 
