@@ -1444,7 +1444,10 @@ __device__ __forceinline__ void ray_forward_a(const float* rs, int lane, int h, 
 }
 
 // attention of this lane's two heads over the S keys in LDS (Ks / Vs: [S][16]); masked query rows (n_valid <= 1) use
-// q = 0: all scores equal => uniform attention, exactly what masked_fill(-1e9) + softmax gives (mlp_network.py:36)
+// q = 0: all scores equal => uniform attention, exactly what masked_fill(-1e9) + softmax gives (mlp_network.py:36).
+// ONE pass over the keys: scores of a block of 8 keys, running maximum, the sums rescaled when the maximum moves (a block, not a
+// key, at a time: the rescale is one exponential per block and mostly exp(0)) -- every K row is read and multiplied once instead
+// of twice.  mx / l end as the row maximum and the softmax denominator relative to it, which is what the backward re-uses.
 __device__ __forceinline__ void ray_attention(const float* Ks, const float* Vs, int S, int h, RayActs& a) {
     const bool row_on = a.nval > 1.f;
 #pragma unroll
@@ -1452,18 +1455,27 @@ __device__ __forceinline__ void ray_attention(const float* Ks, const float* Vs, 
         const int head = h + 2 * j;
         float q0 = row_on ? a.q[4 * j + 0] * 0.5f : 0.f, q1 = row_on ? a.q[4 * j + 1] * 0.5f : 0.f,
               q2 = row_on ? a.q[4 * j + 2] * 0.5f : 0.f, q3 = row_on ? a.q[4 * j + 3] * 0.5f : 0.f;
-        float mx = -3.0e38f;
-        for (int k = 0; k < S; ++k) {
-            const float* kp = Ks + k * 16 + head * 4;
-            mx = fmaxf(mx, fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0]))));
-        }
-        float l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int k = 0; k < S; ++k) {
-            const float* kp = Ks + k * 16 + head * 4;
-            const float* vp = Vs + k * 16 + head * 4;
-            float p = mf_exp(fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0]))) - mx);
-            l += p;
-            a0 = fmaf(p, vp[0], a0); a1 = fmaf(p, vp[1], a1); a2 = fmaf(p, vp[2], a2); a3 = fmaf(p, vp[3], a3);
+        float mx = -3.0e38f, l = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int k0 = 0; k0 < S; k0 += 8) {          // S is a multiple of 32
+            float sc[8], bm = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float* kp = Ks + (k0 + i) * 16 + head * 4;
+                sc[i] = fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0])));
+                bm = fmaxf(bm, sc[i]);
+            }
+            if (bm > mx) {                            // the maximum moves: bring the sums to the new reference
+                const float r = mf_exp(mx - bm);      // first block: exp(-3e38) = 0 on zero sums
+                l *= r; a0 *= r; a1 *= r; a2 *= r; a3 *= r;
+                mx = bm;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float* vp = Vs + (k0 + i) * 16 + head * 4;
+                const float p = mf_exp(sc[i] - mx);
+                l += p;
+                a0 = fmaf(p, vp[0], a0); a1 = fmaf(p, vp[1], a1); a2 = fmaf(p, vp[2], a2); a3 = fmaf(p, vp[3], a3);
+            }
         }
         float rl = 1.f / l;
         a.o[4 * j + 0] = a0 * rl; a.o[4 * j + 1] = a1 * rl; a.o[4 * j + 2] = a2 * rl; a.o[4 * j + 3] = a3 * rl;
