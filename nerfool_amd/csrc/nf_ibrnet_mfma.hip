@@ -1570,8 +1570,8 @@ __device__ __forceinline__ f32x16 ray_gemm8_T(const float* rs, int rec, int lane
     return acc;
 }
 
-// LDS per ray in the backward: K, V, Q, dO [S][16]; M, Linv, D [S][4]
-#define RAY_BWD_LDS_PER_SAMPLE (4 * 16 + 3 * 4)
+// LDS per ray in the backward: K, V, Q, dO [S][16]; {M, 1 / L, D, -} [S][4 heads] (one 16-byte read per query and head)
+#define RAY_BWD_LDS_PER_SAMPLE (4 * 16 + 4 * 4)
 
 // NWV: waves per workgroup (4 or 8; at least WPR).  The weight image takes 65 KB of LDS, so one workgroup per CU: with 8 waves
 // (two per SIMD, 247 registers each) the VALU attention of one wave runs under the LDS / matrix work of the other -- chosen by the
@@ -1602,9 +1602,7 @@ __global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd
         float* Vs = Ks + S * 16;
         float* Qs = Vs + S * 16;
         float* Gs = Qs + S * 16;          // d_o
-        float* Ms = Gs + S * 16;          // row max, 1 / row sum, D per (sample, head)
-        float* Ls = Ms + S * 4;
-        float* Ds = Ls + S * 4;
+        float* MLD = Gs + S * 16;         // {row max, 1 / row sum, D, -} per (sample, head)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             Ks[s * 16 + nf_nidx(r, h)] = a.k[r];
@@ -1644,9 +1642,7 @@ __global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd
                 Gs[s * 16 + head * 4 + d] = d_o[4 * j + d];
                 D = fmaf(d_o[4 * j + d], a.o[4 * j + d], D);
             }
-            Ms[s * 4 + head] = row_on ? a.mx[j] : 0.f;
-            Ls[s * 4 + head] = 1.f / a.l[j];
-            Ds[s * 4 + head] = D;
+            *reinterpret_cast<float4*>(MLD + (s * 4 + head) * 4) = make_float4(row_on ? a.mx[j] : 0.f, 1.f / a.l[j], D, 0.f);
         }
         __syncthreads();
         // ---- attention backward: dQ (this sample as query), dK / dV (this sample as key); masked query rows have zero
@@ -1659,7 +1655,8 @@ __global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd
             if (row_on) {
                 float q0 = a.q[4 * j] * 0.5f, q1 = a.q[4 * j + 1] * 0.5f, q2 = a.q[4 * j + 2] * 0.5f, q3 = a.q[4 * j + 3] * 0.5f;
                 float g0 = d_o[4 * j], g1 = d_o[4 * j + 1], g2 = d_o[4 * j + 2], g3 = d_o[4 * j + 3];
-                float mx = a.mx[j], rl = 1.f / a.l[j], D = Ds[s * 4 + head];
+                const float4 own = *reinterpret_cast<const float4*>(MLD + (s * 4 + head) * 4);
+                float mx = a.mx[j], rl = own.y, D = own.z;
                 for (int k = 0; k < S; ++k) {
                     const float* kp = Ks + k * 16 + head * 4;
                     const float* vp = Vs + k * 16 + head * 4;
@@ -1677,10 +1674,11 @@ __global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd
                 const float* qp = Qs + qi * 16 + head * 4;
                 const float* gp = Gs + qi * 16 + head * 4;
                 float q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];          // pre-scaled; zero for masked query rows
-                float p = mf_exp(fmaf(q3, k3, fmaf(q2, k2, fmaf(q1, k1, q0 * k0))) - Ms[qi * 4 + head]) * Ls[qi * 4 + head];
+                const float4 mld = *reinterpret_cast<const float4*>(MLD + (qi * 4 + head) * 4);
+                float p = mf_exp(fmaf(q3, k3, fmaf(q2, k2, fmaf(q1, k1, q0 * k0))) - mld.x) * mld.y;
                 c0 = fmaf(p, gp[0], c0); c1 = fmaf(p, gp[1], c1); c2 = fmaf(p, gp[2], c2); c3 = fmaf(p, gp[3], c3);
                 float dA = fmaf(gp[3], v3, fmaf(gp[2], v2, fmaf(gp[1], v1, gp[0] * v0)));
-                float dS = p * (dA - Ds[qi * 4 + head]);
+                float dS = p * (dA - mld.z);
                 b0 = fmaf(dS, q0, b0); b1 = fmaf(dS, q1, b1); b2 = fmaf(dS, q2, b2); b3 = fmaf(dS, q3, b3);
             }
             dk[4 * j] = b0; dk[4 * j + 1] = b1; dk[4 * j + 2] = b2; dk[4 * j + 3] = b3;
