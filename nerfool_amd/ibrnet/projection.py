@@ -32,20 +32,22 @@ class Projector:
     def __init__(self, device=None):
         self.device = device
 
-    def compute(self, xyz, query_camera, train_imgs, train_cameras, featmaps):
+    def compute(self, xyz, query_camera, train_imgs, train_cameras, featmaps, cam_ws=None):
         """
         :param xyz: [n_rays, n_samples, 3]
         :param query_camera: [1, 34]   (H, W, K 4x4, c2w 4x4)
         :param train_imgs: [1, n_views, h, w, 3]
         :param train_cameras: [1, n_views, 34]
         :param featmaps: [n_views, d, hf, wf]   (any strides; channels-last is the fast layout)
+        :param cam_ws: optional ops.camera_setup(query_camera, train_cameras) if the caller already has it
         :return: rgb_feat [n_rays, n_samples, n_views, 3+d], ray_diff [..., 4], mask [..., 1]
         """
         if not (train_imgs.shape[0] == 1 and train_cameras.shape[0] == 1 and query_camera.shape[0] == 1):
             raise AssertionError('only support batch_size=1 for now')
         R, S, _ = xyz.shape
         V = train_cameras.shape[1]
-        cam_ws = ops.camera_setup(query_camera.detach(), train_cameras.detach())
+        if cam_ws is None:          # (render_rays hands in the workspace it built for the coarse level)
+            cam_ws = ops.camera_setup(query_camera.detach(), train_cameras.detach())
         pts = xyz.detach().reshape(-1, 3)
         rgb_feat, ray_diff, mask = _ProjectGather.apply(pts, cam_ws, train_imgs[0].detach(), featmaps)
         C = featmaps.shape[1]

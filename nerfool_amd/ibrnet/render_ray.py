@@ -62,16 +62,19 @@ def sample_fine_depths(z_vals, weights, N_importance, inv_uniform=False, det=Fal
     return ops.sample_fine(z_vals.detach(), weights.detach(), N_importance, inv_uniform, u)
 
 
-def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo_noise):
+def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo_noise, cams):
+    """cams: one-element list caching the camera workspace of this render_rays call (both levels see the same cameras)"""
     can = getattr(net, 'can_gather', None)
-    if can is not None and isinstance(projector, Projector) and can(featmap, pts.shape[1], src['src_cameras'].shape[1]):
+    ours = isinstance(projector, Projector)
+    if ours and cams[0] is None:
+        cams[0] = ops.camera_setup(ray_batch['camera'].detach(), src['src_cameras'].detach())
+    if can is not None and ours and can(featmap, pts.shape[1], src['src_cameras'].shape[1]):
         # projection + bilinear gather run inside the network's row kernel (and their adjoint inside its backward)
-        cam_ws = ops.camera_setup(ray_batch['camera'].detach(), src['src_cameras'].detach())
-        raw, mask = net.forward_gathered(pts, cam_ws, src['src_rgbs'][0], featmap)
+        raw, mask = net.forward_gathered(pts, cams[0], src['src_rgbs'][0], featmap)
         pixel_mask = ops.pixel_mask(mask)                    # at least 2 observations (:210)
     else:
         rgb_feat, ray_diff, mask = projector.compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'],
-                                                     featmaps=featmap)
+                                                     featmaps=featmap, **({'cam_ws': cams[0]} if ours else {}))
         pixel_mask = ops.pixel_mask(mask[..., 0])            # at least 2 observations (:210)
         raw = net(rgb_feat, ray_diff, mask)
     return raw2outputs(raw, z_vals, pixel_mask, white_bkgd=white_bkgd, geo_noise=geo_noise)
@@ -89,14 +92,15 @@ def render_rays(ray_batch, model, featmaps, projector, N_samples, inv_uniform=Fa
     ret = {'outputs_coarse': None, 'outputs_fine': None}
     pts, z_vals = sample_along_camera_ray(ray_batch['ray_o'], ray_batch['ray_d'], ray_batch['depth_range'], N_samples,
                                           inv_uniform=inv_uniform, det=det)
+    cams = [None]
     ret['outputs_coarse'] = _level(pts, z_vals, ray_batch, src, model.net_coarse, featmaps[0], projector, white_bkgd,
-                                   geo_noise)
+                                   geo_noise, cams)
     if N_importance > 0:
         assert model.net_fine is not None
         z_vals = sample_fine_depths(z_vals, ret['outputs_coarse']['weights'], N_importance, inv_uniform, det)
         pts = ops.points_from_depths(ray_batch['ray_o'], ray_batch['ray_d'], z_vals)
         ret['outputs_fine'] = _level(pts, z_vals, ray_batch, src, model.net_fine, featmaps[1], projector, white_bkgd,
-                                     geo_noise)
+                                     geo_noise, cams)
     return ret
 
 
