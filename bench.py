@@ -12,11 +12,13 @@ Adam/eps-ball/[0,1] update.  `value` = rays rendered-and-differentiated per seco
 
 Multi-GPU: rays are sharded over the ranks (nerfool_amd.eval_adv.RayShard).  `--scaling weak` (default): every rank
 differentiates its own N_rand rays (global batch N_rand * N); `--scaling strong`: the N_rand rays of the single-GPU step are
-split over the ranks.  `--cnn-shard view` (default): the feature CNN is sharded by source view, 4 collectives per step
-(16-byte counts/loss all-reduce, all-gather of the feature maps, reduce-scatter of their gradients, all-gather of d delta);
-`--cnn-shard replicated`: the north-star form, 2 collectives per step (16-byte all-reduce + ONE RCCL all-reduce of d delta).
-Whatever the headline flags, an N > 1 run also times the other scaling mode and the replicated form and reports them under
-`extra.multi_gpu`.  Prints ONE JSON line on rank 0.
+split over the ranks.  `--cnn-shard replicated` (default = the north-star form): the feature CNN runs on every rank, 2
+collectives per step (16-byte counts/loss all-reduce + ONE RCCL all-reduce of d delta); `--cnn-shard view`: the feature CNN is
+sharded by source view, 4 collectives per step (the 16-byte one, all-gather of the feature maps, reduce-scatter of their
+gradients, all-gather of d delta).  Whatever the headline flags, an N > 1 run also times the other three forms and reports them
+under `extra.multi_gpu`.  The render legs (`extra.render*`) run on ALL ranks: every rank renders its own contiguous block of
+4096-ray chunks (no collective in the data path) and the figure is the all-rank rays/s between barriers; `render_single_image`
+is the whole image sharded over the ranks and gathered to rank 0 by one collective.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -93,9 +95,9 @@ def parse():
                          "shape, 512x512, 8 source views, 128 + 128 samples, white background, bf16 matrix-core operands in the row network")
     ap.add_argument('--precision', choices=('fp32', 'bf16'), default=None, help='IBRNet row-network operand precision (default: fp32; c5: bf16)')
     ap.add_argument('--depth', type=int, default=8, help='GNT trans_depth')
-    ap.add_argument('--cnn-shard', choices=('view', 'replicated'), default='view',
-                    help='N > 1: feature CNN sharded by source view (exchange of feature maps) or replicated on every rank '
-                         '(north-star form: one all-reduce of d delta)')
+    ap.add_argument('--cnn-shard', choices=('view', 'replicated'), default='replicated',
+                    help='N > 1: feature CNN replicated on every rank (north-star form: one all-reduce of d delta; the default) or '
+                         'sharded by source view (exchange of feature maps)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='N > 1: --n-rand rays per rank (weak) or split over the ranks (strong)')
     ap.add_argument('--cpu-iters', type=int, default=10, help='timed CPU-oracle PGD iterations for cpu_baseline after 2 warm-ups (0 = skip)')
@@ -234,8 +236,11 @@ def time_steps(attack, data, steps, warmup, barrier, timer_ctx=None):
     return time.perf_counter() - t0
 
 
-def render_leg(model, projector, sampler, src_ray_batch, featmaps, n_chunks, samples, importance, gnt, prof):
-    """forward-only throughput on 4096-ray chunks with resident feature maps: 1 warm-up chunk + n_chunks timed"""
+def render_leg(model, projector, sampler, src_ray_batch, featmaps, n_chunks, samples, importance, gnt, prof, par=None):
+    """forward-only throughput on 4096-ray chunks with resident feature maps: 1 warm-up chunk + n_chunks timed PER RANK -- rank r
+    renders the contiguous chunk block [r (n_chunks + 1), (r + 1)(n_chunks + 1)) of the image, nothing is exchanged; the rate is
+    all ranks' rays over the slowest rank's time between barriers.  par = (rank, world, barrier, max_over_ranks)."""
+    rank, world, barrier, max_over_ranks = par if par is not None else (0, 1, torch.cuda.synchronize, lambda x: x)
     if gnt:
         from nerfool_amd.gnt.render_ray import render_rays as gnt_render_rays
 
@@ -245,20 +250,23 @@ def render_leg(model, projector, sampler, src_ray_batch, featmaps, n_chunks, sam
     else:
         from nerfool_amd.ibrnet.render_ray import render_rays
     rays = sampler.get_all()
-    chunk = lambda i: {k: (v[i * 4096:(i + 1) * 4096] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in rays.items()}
+    first = rank * (n_chunks + 1)
+    assert (world * (n_chunks + 1)) * 4096 <= rays['ray_o'].shape[0], 'the image has too few rays for %d ranks x %d chunks' % (world, n_chunks + 1)
+    chunk = lambda i: {k: (v[(first + i) * 4096:(first + i + 1) * 4096] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in rays.items()}
     with torch.no_grad():
         render_rays(chunk(0), model, featmaps, projector, samples, inv_uniform=True, N_importance=importance, det=True,
                     src_ray_batch=src_ray_batch)
-        torch.cuda.synchronize()
+        barrier()
         rtimer = prof.KernelTimer()
         r0 = time.perf_counter()
         with prof.timing(rtimer):
             for i in range(n_chunks):
                 render_rays(chunk(i + 1), model, featmaps, projector, samples, inv_uniform=True, N_importance=importance,
                             det=True, src_ray_batch=src_ray_batch)
-        torch.cuda.synchronize()
-        rdt = time.perf_counter() - r0
-    return {'rays_per_s': n_chunks * 4096 / rdt, 'chunks': n_chunks, 'chunk_rays': 4096, 'samples': '%d+%d' % (samples, importance),
+        barrier()
+        rdt = max_over_ranks(time.perf_counter() - r0)
+    return {'rays_per_s': world * n_chunks * 4096 / rdt, 'rays_per_s_per_gpu': n_chunks * 4096 / rdt, 'n_gpus': world,
+            'chunks_per_rank': n_chunks, 'chunk_rays': 4096, 'samples': '%d+%d' % (samples, importance),
             'kernels_ms': {k: round(v['mean_ms'], 4) for k, v in rtimer.summary().items()}}
 
 
@@ -396,16 +404,17 @@ def main():
             multi['exchange_ms_per_step_isolated_' + cnn_shard] = round(max_over_ranks(
                 exchange_microbench(attack.shard, a.views, C, Hf, Wf, a.height, a.width, dev, cnn_shard == 'view') * 1e-3) * 1e3, 4)
 
-    # ---- single-GPU legs outside the timed region of the headline value
+    # ---- legs outside the timed region of the headline value.  The render legs run on EVERY rank (ray-range sharding).
     render = None
     extra_legs = {}
     featmaps = None
-    if a.extras and rank == 0 and (a.render_chunks > 0 or world == 1):
-        with torch.no_grad():
+    par = (rank, world, barrier, max_over_ranks)
+    if a.extras and (a.render_chunks > 0 or a.model == 'ibrnet'):
+        with torch.no_grad():       # the same delta on every rank (replicated state of the attack)
             featmaps = model.feature_net((src_ray_batch['src_rgbs'] + attack.delta).squeeze(0).permute(0, 3, 1, 2))
-    if a.extras and rank == 0 and a.render_chunks > 0:
+    if a.extras and a.render_chunks > 0:
         render = render_leg(model, projector, sampler, src_ray_batch, featmaps, a.render_chunks, a.samples, a.importance,
-                            a.model == 'gnt', prof)
+                            a.model == 'gnt', prof, par)
     if a.extras and world == 1 and a.model == 'ibrnet' and a.config == 'c2':
         # N_rand = 4096 attack step (SURVEY 8d asks for 512 and 4096)
         big = make_attack(a.cnn_shard, a.scaling, n_rand=4096)
@@ -413,25 +422,32 @@ def main():
         ms = 1e3 * time_steps(big, data, n, 2, barrier) / n
         extra_legs['attack_n_rand_4096'] = {'ms_per_step': round(ms, 4), 'rays_per_s': 4096 / (ms * 1e-3)}
         del big
+    if a.extras and a.model == 'ibrnet' and a.config == 'c2':
         # the whole 756x1008 image through render_single_image: 187 chunks of 4096 rays, outputs moved to the host (D2H) and
-        # reshaped as the reference does (render_image.py:52-102)
+        # reshaped as the reference does (render_image.py:52-102).  N > 1: the chunks are dealt to the ranks as contiguous blocks
+        # and one gather of the packed per-ray records assembles the image on rank 0 (strong scaling of one image).
         from nerfool_amd.ibrnet.render_image import render_single_image
         rays = sampler.get_all()
+        img_shard = EA.RayShard(shard_views=False) if world > 1 else None
         t_img = []
         ret = None
         for _ in range(3):
             ret = None          # the page-locked host tensors of the previous image go back to torch's host allocator
-            torch.cuda.synchronize()
+            barrier()
             t0 = time.perf_counter()
             ret = render_single_image(ray_sampler=sampler, ray_batch=rays, model=model, projector=projector, chunk_size=4096,
                                       N_samples=a.samples, inv_uniform=True, N_importance=a.importance, det=True, white_bkgd=False,
-                                      featmaps=featmaps, src_ray_batch=src_ray_batch)
-            torch.cuda.synchronize()
-            t_img.append(time.perf_counter() - t0)
+                                      featmaps=featmaps, src_ray_batch=src_ray_batch, shard=img_shard)
+            barrier()
+            t_img.append(max_over_ranks(time.perf_counter() - t0))
         n_rays = a.height * a.width
-        extra_legs['render_single_image'] = {'image': '%dx%d' % (a.height, a.width), 'chunks': -(-n_rays // 4096), 'samples': '%d+%d' % (a.samples, a.importance),
-                                             'seconds': round(min(t_img), 4), 'rays_per_s': n_rays / min(t_img), 'includes': 'chunk loop, D2H of all six output fields per level (second stream, page-locked host tensors), reshape',
-                                             'rgb_shape': list(ret['outputs_fine']['rgb'].shape)}
+        extra_legs['render_single_image'] = {
+            'image': '%dx%d' % (a.height, a.width), 'chunks': -(-n_rays // 4096), 'samples': '%d+%d' % (a.samples, a.importance),
+            'n_gpus': world, 'seconds': round(min(t_img), 4), 'rays_per_s': n_rays / min(t_img),
+            'includes': 'chunk loop, D2H of all six output fields per level (second stream, page-locked host tensors), reshape' if world == 1 else
+                        'chunk loop on all ranks, ONE gather of the packed per-ray records to rank 0 (%.2f GB), D2H there, reshape'
+                        % (img_shard.bytes / 3 / 1e9),
+            'rgb_shape': None if ret is None else list(ret['outputs_fine']['rgb'].shape)}
         del ret
         # north-star render case: 800x800 scene, 64 samples per ray -- coarse only and 64+64
         a8 = argparse.Namespace(**vars(a))
@@ -440,9 +456,9 @@ def main():
         with torch.no_grad():
             fm8 = model8.feature_net(src8['src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
         for imp, tag in ((0, 'render_800x800_64'), (64, 'render_800x800_64+64')):
-            r = render_leg(model8, projector8, sampler8, src8, fm8, 8, 64, imp, False, prof)
+            r = render_leg(model8, projector8, sampler8, src8, fm8, 8, 64, imp, False, prof, par)
             fl = ibrnet_flops(1, 64, a.views) + (ibrnet_flops(1, 64 + imp, a.views) if imp else 0)
-            r['mfma_frac_of_peak'] = round(r['rays_per_s'] * fl / 1e12 / PEAK_F32_TFLOPS, 4)
+            r['mfma_frac_of_peak'] = round(r['rays_per_s_per_gpu'] * fl / 1e12 / PEAK_F32_TFLOPS, 4)
             extra_legs[tag] = r
         del model8, fm8, sampler8, src8, data8
 

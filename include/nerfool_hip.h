@@ -142,14 +142,6 @@ int nf_ibrnet_fwd_mfma_gather(const float* bf16_blob, const float* mfma_blob, co
                               const float* cam_ws, const float* src_rgbs, int H, int W, const float* featmap, int Hf, int Wf,
                               int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w, int64_t n_rays, int n_samples, int n_views,
                               int anti_alias_pooling, float* raw, float* workspace, float* mask_out, nf_stream_t stream);
-/* backward of nf_ibrnet_fwd_mfma_gather (fp32 rows): the recompute gathers from the feature maps again, the output stage scatters
- * into d_featmap [V][32][Hf][Wf] (element strides ds_*, ZEROED by the caller) -- the attack step then holds neither rgb_feat nor
- * its gradient in memory.  smp = the forward's workspace. */
-int nf_ibrnet_bwd_mfma_gather_scatter(const float* mfma_blob, const float* blob, const float* pos_enc, const float* smp, const float* d_raw,
-                                      int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_workspace,
-                                      const float* xyz, const float* cam_ws, const float* src_rgbs, int H, int W, const float* featmap,
-                                      int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w, float* d_featmap, int64_t ds_v, int64_t ds_c,
-                                      int64_t ds_h, int64_t ds_w, int Hf, int Wf, nf_stream_t stream);
 /* bf16-operand variant of the matrix-core path (BASELINE config 5, "bf16 MFMA path"): the per-(sample, view) row network of
  * IBRNet.forward (ibrnet/mlp_network.py:231-257, 268-273: ray_dir_fc, base_fc, vis_fc, vis_fc2, rgb_fc) runs on
  * v_mfma_f32_32x32x16_bf16 -- weights and activations rounded to bf16 at the matrix-core inputs, fp32 accumulation; pooling,
@@ -231,15 +223,6 @@ int nf_conv1x1_pack(const float* weight_host, int c_out, int c_in, int transpose
 int nf_conv1x1(const float* records, const float* bias, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w,
                float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int64_t ys_w, int n_img, int H, int W, int c_in, int c_out,
                const float* x2, int c_split, nf_stream_t stream);
-
-/* The same stride-1 3x3 convolution as nf_conv3x3_wino in Winograd F(4x4, 3x3) form (csrc/nf_wino4.hip: 36 products per 4x4 output
- * tile instead of 64; fp32 error 2-4e-6 of full scale).  records = nf_wino4_pack(weight [c_out][c_in][3][3], backward) (HOST
- * pointers, nf_wino4_pack_floats(outputs, inputs of the packed convolution) floats).  pad 0: forward on pre-padded input; pad 2:
- * backward-data on the gradient with records packed with backward != 0. */
-int64_t nf_wino4_pack_floats(int c_out, int c_in);
-int nf_wino4_pack(const float* weight_host, int c_out, int c_in, int backward, float* records_host);
-int nf_conv3x3_wino4(const float* records, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, int pad, float* y,
-                     int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out, nf_stream_t stream);
 
 /* Layout / padding glue of the ResUNet executor (csrc/nf_pad.hip; ibrnet/feature_network.py:188 reflect padding of the input,
  * :231-243 skipconnect zero padding, :143-151 upsampling in front of a reflect-padded convolution -- its backward):

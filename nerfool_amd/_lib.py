@@ -46,8 +46,6 @@ _PROTOTYPES = {
     'nf_ibrnet_bwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_ibrnet_fwd_mfma_gather': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                           c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
-    'nf_ibrnet_bwd_mfma_gather_scatter': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, c_int64,
-                                                  c_int64, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, _P]),
     'nf_ibrnet_bwd_mfma_scatter': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64,
                                            c_int64, c_int64, c_int, c_int, _P]),
     'nf_ibrnet_mfma_bf16_blob_floats': (c_int64, []),
@@ -87,10 +85,6 @@ _PROTOTYPES = {
                                c_int, c_int, _P]),
     'nf_conv_s2_bwd': (c_int, [_P, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int,
                                c_int, c_int, _P]),
-    'nf_wino4_pack_floats': (c_int64, [c_int, c_int]),
-    'nf_wino4_pack': (c_int, [_P, c_int, c_int, c_int, _P]),
-    'nf_conv3x3_wino4': (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int,
-                                 c_int, c_int, _P]),
     'nf_wino_pack_floats': (c_int64, [c_int, c_int, c_int]),
     'nf_wino_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
     'nf_conv3x3_wino': (c_int, [_P, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int,

@@ -1878,7 +1878,6 @@ static int launch_rows_bwd_any(const float* wblob, const float* bf_blob, const f
                                const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, const RowGather& ga,
                                hipStream_t st) {
     if (sc.d_featmap) {     // fused scatter: exact-fp32 rows only (the bf16 image leaves no LDS for the staging tiles at two workgroups per CU)
-        if (ga.featmap) return launch_rows_bwd<V, false, true, true>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st);
         return launch_rows_bwd<V, false, true, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st);
     }
     return bf_blob ? launch_rows_bwd<V, true, false, false>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st)
@@ -1981,25 +1980,6 @@ extern "C" int nf_ibrnet_bwd_mfma_scatter(const float* mfma_blob, const float* b
     const RowScatter sc = {xyz, cam_ws, d_featmap, fs_v, fs_c, fs_h, fs_w, Hf, Wf};
     return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma_scatter", nullptr, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, n_rays,
                            n_samples, n_views, anti_alias_pooling, nullptr, d_workspace, stream, sc);
-}
-
-/* backward of nf_ibrnet_fwd_mfma_gather (bf16_blob == nullptr): the row kernel's recompute gathers from the feature maps again and
- * its output stage scatters into d_featmap (zeroed by the caller) -- neither rgb_feat nor its gradient exists in memory. */
-extern "C" int nf_ibrnet_bwd_mfma_gather_scatter(const float* mfma_blob, const float* blob, const float* pos_enc, const float* smp,
-                                                 const float* d_raw, int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling,
-                                                 float* d_workspace, const float* xyz, const float* cam_ws, const float* src_rgbs, int H,
-                                                 int W, const float* featmap, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
-                                                 float* d_featmap, int64_t ds_v, int64_t ds_c, int64_t ds_h, int64_t ds_w, int Hf, int Wf,
-                                                 nf_stream_t stream) {
-    if (n_rays == 0) return 0;
-    NF_REQUIRE(xyz && cam_ws && src_rgbs && featmap && d_featmap && H >= 1 && W >= 1 && Hf >= 1 && Wf >= 1,
-               "nf_ibrnet_bwd_mfma_gather_scatter: bad arguments");
-    NF_REQUIRE(fs_c == 1 && fs_v % 4 == 0 && fs_h % 4 == 0 && fs_w % 4 == 0 && ((uintptr_t)featmap) % 16 == 0,
-               "nf_ibrnet_bwd_mfma_gather_scatter: the feature maps must be channels-last with 16-byte aligned pixel records");
-    const RowScatter sc = {xyz, cam_ws, d_featmap, ds_v, ds_c, ds_h, ds_w, Hf, Wf};
-    const RowGather ga = {xyz, cam_ws, src_rgbs, featmap, nullptr, fs_v, fs_h, fs_w, H, W, Hf, Wf};
-    return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma_gather_scatter", nullptr, mfma_blob, blob, pos_enc, nullptr, nullptr, nullptr, smp, d_raw,
-                           n_rays, n_samples, n_views, anti_alias_pooling, nullptr, d_workspace, stream, sc, ga);
 }
 
 extern "C" int nf_ibrnet_bwd_mfma_bf16(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc,

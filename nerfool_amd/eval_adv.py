@@ -74,8 +74,9 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
     """One loss evaluation of the attack (eval_adv.py:258-310,512-519): draw N_rand rays of the target view `data`,
     features from the PERTURBED source images, colours from the CLEAN ones, masked MSE on coarse + fine.
 
-    args.use_pseudo_gt (forced by args.use_unseen_views, eval_adv.py:652-653; the caller supplies the interpolated target
-    camera in data['camera']): the target colours are the model's own render from the clean source images
+    args.use_pseudo_gt (the universal loop sets it under args.use_unseen_views and puts the interpolated target camera into
+    data['camera'], eval_adv.py:652-691 -- `PGDAttack.run_universal`; the flag `use_unseen_views` itself is not read here,
+    as in the reference): the target colours are the model's own render from the clean source images
     (eval_adv.py:271-290 -- outputs_fine; the GNT flavour takes outputs_coarse, eval/gnt/eval_adv.py:296-315), always with
     det=True.  featmaps_clean: those clean feature maps if the caller already has them.
 
@@ -99,7 +100,7 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
     else:
         featmaps = model.feature_net((src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
     gnt = _is_gnt(model)
-    if getattr(args, 'use_pseudo_gt', False) or getattr(args, 'use_unseen_views', False):
+    if getattr(args, 'use_pseudo_gt', False):
         with torch.no_grad():
             if featmaps_clean is None:
                 featmaps_clean = clean_featmaps(model, src_ray_batch)
@@ -189,6 +190,10 @@ class RayShard:
         self.split_n_rand = bool(split_n_rand)
         self.collectives = 0            # issued so far (bench.py reports collectives per step)
         self.bytes = 0                  # payload bytes of those collectives (size of the reduced / gathered buffer)
+        self.gather_render_to = 0       # group rank that receives a sharded render_single_image (None: every rank)
+
+    def global_rank(self, r):
+        return self.dist.get_global_rank(self.group, r) if self.group is not None else r
 
     def pixels_to_draw(self, n_rand):
         return n_rand if self.split_n_rand else n_rand * self.world
@@ -236,6 +241,25 @@ class RayShard:
             return out
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
         return g[lo:hi]
+
+    def gather_rows(self, buf, dst=0):
+        """buf [rows, F] (same shape on every rank) -> [world, rows, F] on group rank `dst`, None on the others; dst None: on
+        every rank (all-gather).  ONE collective: the image assembly of a sharded render_single_image."""
+        buf = buf.contiguous()
+        if dst is not None and buf.is_cuda and self.dist.get_backend(self.group) == 'gloo':
+            # functional single-GPU debugging set-up only (bench.py NERFOOL_DIST_BACKEND=gloo): gloo gathers host tensors only
+            full = self.gather_rows(buf, None)
+            return full if self.rank == dst else None
+        if dst is None:
+            full = torch.empty((self.world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+            # output = the ranks' buffers concatenated along dim 0 (the one form both RCCL and gloo accept)
+            self.dist.all_gather_into_tensor(full.view((self.world * buf.shape[0],) + tuple(buf.shape[1:])), buf, group=self.group)
+        else:
+            full = torch.empty((self.world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device) if self.rank == dst else None
+            self.dist.gather(buf, list(full.unbind(0)) if full is not None else None, dst=self.global_rank(dst), group=self.group)
+        self.collectives += 1
+        self.bytes += self.world * buf.numel() * buf.element_size()
+        return full
 
     def view_sharded_featmaps(self, feature_net, src_rgbs, delta):
         """feature_net(src + delta) with the views split over the ranks -> the same tuple the network returns."""
@@ -301,8 +325,7 @@ class PGDAttack:
         self.delta = delta if delta is not None else init_adv_perturb(args, src_ray_batch, self.epsilon, 1, 0)
         if shard is not None and shard.world > 1:
             # delta must start replicated (every rank then applies the identical deterministic update): rank 0's draw wins
-            shard.dist.broadcast(self.delta.data, src=shard.dist.get_global_rank(shard.group, 0) if shard.group is not None else 0,
-                                 group=shard.group)
+            shard.dist.broadcast(self.delta.data, src=shard.global_rank(0), group=shard.group)
         self.use_adam = bool(getattr(args, 'use_adam', False))
         if self.use_adam:
             self.exp_avg = torch.zeros_like(self.delta.data)
@@ -318,7 +341,7 @@ class PGDAttack:
 
     def gradient(self, data, select_inds=None, lookahead=True):
         self.delta.grad = None
-        if self._featmaps_clean is None and (getattr(self.args, 'use_pseudo_gt', False) or getattr(self.args, 'use_unseen_views', False)):
+        if self._featmaps_clean is None and getattr(self.args, 'use_pseudo_gt', False):
             self._featmaps_clean = clean_featmaps(self.model, self.src)
         loss, total = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data,
                                            return_loss=True, select_inds=select_inds, shard=self.shard, lookahead=lookahead,
@@ -352,13 +375,33 @@ class PGDAttack:
             self.step(data)
         return self.delta
 
-    def run_universal(self, train_loader, n_iters=None):
+    def run_universal(self, train_loader, n_iters=None, render_poses=None):
         """eval_adv.py:646-740: cycles over the training views; the reference's `iters > adv_iters` test makes it run
-        adv_iters + 1 steps."""
+        adv_iters + 1 steps.
+
+        args.use_unseen_views (eval_adv.py:652-691): every step replaces the batch's target camera by an interpolation of three
+        of the scene's render poses drawn from numpy's global generator (`geo_interp.unseen_camera`) and renders the pseudo
+        ground truth there.  render_poses: that list of camera-to-world matrices (default: `train_loader.dataset.render_poses`,
+        where the reference's loaders keep it); without one the flag raises instead of silently attacking the seen cameras.
+        Sharded: rank 0's draw is broadcast so that all ranks step on the same camera."""
+        unseen = bool(getattr(self.args, 'use_unseen_views', False))
+        if unseen:
+            if render_poses is None:
+                render_poses = getattr(getattr(train_loader, 'dataset', None), 'render_poses', None)
+            if render_poses is None or len(render_poses) < 3:
+                raise NotImplementedError('--use_unseen_views needs at least three render poses of the scene: pass render_poses= or a '
+                                          'loader whose dataset has .render_poses (the data loaders themselves are out of scope)')
+            from .geo_interp import unseen_camera
+            self.args.use_pseudo_gt = True      # as GT rgb/depth may not be available for unseen views (eval_adv.py:653)
         total = (self.args.adv_iters if n_iters is None else n_iters) + 1
         done = 0
         while done < total:
             for data in train_loader:
+                if unseen:
+                    camera = unseen_camera(self.args, render_poses, data['camera'].to(self.delta.device))
+                    if self.shard is not None and self.shard.world > 1:
+                        self.shard.dist.broadcast(camera, src=self.shard.global_rank(0), group=self.shard.group)
+                    data = dict(data, camera=camera)
                 self.step(data)
                 done += 1
                 if done >= total:

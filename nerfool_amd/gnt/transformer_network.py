@@ -2,15 +2,14 @@
 gnt/transformer_network.py:205-268 (rgbfeat_fc, view_crosstrans.N.{attn_norm, ff_norm, ff.fc1/fc2, attn.{q_fc,k_fc,v_fc,
 pos_fc.0/2, attn_fc.0/2, out_fc}}, view_selftrans.N.{...}, q_fcs.N.0/2 on even N, norm, rgb_fc) so that the public GNT
 checkpoints load by key.  Eval-mode semantics (Dropout = identity); the parameters are constants of the attack."""
-import os
-
 import torch
 import torch.nn as nn
 
 from .. import ops
 
-# 'mfma': forward on the matrix cores where the shape allows (S in {32, 64, 96, 128}); 'generic': shape-generic kernels only
-KERNEL_PATH = os.environ.get('NERFOOL_GNT_KERNELS', 'mfma')
+# Test / diagnostic hook: 'mfma' = matrix-core kernels where the shape allows (S in {32, 64, 96, 128}); 'generic': shape-generic
+# kernels only
+KERNEL_PATH = 'mfma'
 
 
 class _FF(nn.Module):

@@ -7,17 +7,17 @@ out_conv) so that reference checkpoints load by key.
 
 The output is produced channels-last ([V, Hf, Wf, 64] in memory): each feature-map pixel is one 256-byte record whose
 halves are the coarse / fine 32-channel maps, which is what the gather kernels want (one cache line per bilinear tap)."""
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
 
-# 'fused' (default): MIOpen convolutions with padding 0 + the hand-written InstanceNorm/activation/reflect-pad kernels of
-# csrc/nf_cnn.hip in between, explicit backward-data only;  'torch': the plain nn.Module graph (ATen + MIOpen + autograd)
-CNN_PATH = os.environ.get('NERFOOL_CNN', 'fused')
+# Test / diagnostic hook (tests/ and tools/ set it; nothing reads the environment).  'fused' (default): the executor below --
+# hand-written convolutions with padding 0 + the InstanceNorm / activation / reflect-pad kernels of csrc/nf_cnn.hip in between,
+# explicit backward-data only;  'torch': the plain nn.Module graph (ATen + autograd), what the fused executor is compared with
+# and what the CPU tests of the host logic run (the stand-in emulates the fused glue slowly)
+CNN_PATH = 'fused'
 
 
 def _c3(cin, cout, stride=1):
@@ -116,12 +116,12 @@ class ResUNet(nn.Module):
         # next to a multi-millisecond network, and a partly unfrozen network must not pass silently)
         self._frozen = not any(p.requires_grad for p in self.parameters())
         if CNN_PATH != 'fused':
-            return False                # NERFOOL_CNN=torch: the plain nn.Module graph, an explicit choice (tests compare against it)
+            return False                # the plain nn.Module graph, an explicit choice (tests compare against it)
         if not (x.is_cuda or ops._lib.emulated()):
             raise RuntimeError('ResUNet: input on %s -- the feature CNN runs on the GPU only (no CPU fallback)' % x.device)
         if not self._frozen:
             raise NotImplementedError('ResUNet: the fused executor differentiates w.r.t. its input only; freeze the weights '
-                                      '(requires_grad_(False), as IBRNetModel does) or set NERFOOL_CNN=torch')
+                                      '(requires_grad_(False), as IBRNetModel does)')
         return True
 
     def _module_graph(self, x):
@@ -137,15 +137,15 @@ class ResUNet(nn.Module):
         """out_conv's whole output [N, coarse + fine channels, Hf, Wf] (channels-last), i.e. forward() before the channel
         split -- what the view-sharded attack step exchanges between the ranks (eval_adv.RayShard)."""
         if self._fused(x):
-            return _FusedResUNet.apply(x, self, (self.coarse_out_ch + self.fine_out_ch,))[0]
+            return _FusedResUNet.apply(x, self, (self.coarse_out_ch + self.fine_out_ch,), _taped(x))[0]
         return self._module_graph(x)
 
     def forward(self, x):
         if self._fused(x):
             if self.single_net or self.coarse_only:
-                out, = _FusedResUNet.apply(x, self, (self.coarse_out_ch,))
+                out, = _FusedResUNet.apply(x, self, (self.coarse_out_ch,), _taped(x))
                 return (out, out) if self.single_net else (out, None)
-            return _FusedResUNet.apply(x, self, (self.coarse_out_ch, self.fine_out_ch))
+            return _FusedResUNet.apply(x, self, (self.coarse_out_ch, self.fine_out_ch), _taped(x))
         out = self._module_graph(x)
         if self.single_net:
             return out, out
@@ -199,10 +199,8 @@ class _Act:
 # 3x3 stride-1 convolutions: 'auto' times the Winograd matrix-core kernel (csrc/nf_wino.hip) with 64 and with 32 output
 # channels per workgroup, once per (shape, direction) on first use, and keeps the faster -- both forms compute every output
 # with the same arithmetic in the same order, so the choice does not change a single bit of the result; 'wino' / 'wino32'
-# force one, 'miopen' (NERFOOL_CONV3X3) runs the vendor library instead (comparison runs only: its small-plane kernels are
-# not run-to-run reproducible, tools/diag_determinism.py), 'wino4' the F(4x4,3x3) kernel of csrc/nf_wino4.hip (correct, 2-4e-6
-# accurate, but 1.7x slower than F(2x2) in its present form: never chosen automatically)
-CONV3X3 = os.environ.get('NERFOOL_CONV3X3', 'auto')
+# force one (test / diagnostic hook)
+CONV3X3 = 'auto'
 _CONV_CHOICE = {}
 
 
@@ -259,16 +257,6 @@ def _wino_ring_records(conv_w):
     return cache[1]
 
 
-def _wino4_records(conv_w):
-    """F(4x4,3x3) records (csrc/nf_wino4.hip; NERFOOL_CONV3X3=wino4 only), kept on the weight tensor"""
-    key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
-    cache = getattr(conv_w, '_nf_wino4', None)
-    if cache is None or cache[0] != key:
-        cache = (key, ops.wino4_pack(conv_w, False, conv_w.device), ops.wino4_pack(conv_w, True, conv_w.device))
-        conv_w._nf_wino4 = cache
-    return cache[1], cache[2]
-
-
 def _conv3x3(tape, inp, w, sink):
     """3x3 stride-1 convolution on a pre-padded activation (padding 0) and its backward-data pass"""
     c_out, c_in = w.shape[0], w.shape[1]
@@ -276,10 +264,6 @@ def _conv3x3(tape, inp, w, sink):
     fwd = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out))[0], inp, c_out, 0, k_per_group=ops.wino_group(c_out))}
     if c_out > 64:                      # narrower workgroups only matter when they add workgroups to a thin grid
         fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[0], inp, c_out, 0, k_per_group=32)
-    if CONV3X3 == 'miopen':
-        fwd['miopen'] = lambda: _aten.convolution(inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
-    if CONV3X3 == 'wino4':
-        fwd['wino4'] = lambda: ops.conv3x3_wino4(_wino4_records(w)[0], inp, c_out, 0)
     out = _Slot(fwd[_pick(('f', c_in, c_out) + tuple(inp.shape), fwd, timed)]())
 
     def bwd():
@@ -297,11 +281,6 @@ def _conv3x3(tape, inp, w, sink):
         cand = {'wino': lambda: bwd_data(ops.wino_group(c_in))}
         if c_in > 64:
             cand['wino32'] = lambda: bwd_data(32)
-        if CONV3X3 == 'miopen':
-            cand['miopen'] = lambda: _aten.convolution_backward(g_out, inp, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                                [True, False, False])[0]
-        if CONV3X3 == 'wino4':
-            cand['wino4'] = lambda: ops.conv3x3_wino4(_wino4_records(w)[1], g_out, c_in, 2)
         sink(cand[_pick(('b', c_in, c_out) + tuple(inp.shape), cand, timed)]())
         out.g = None
     tape.append(bwd)
@@ -318,8 +297,7 @@ def _s2_records(conv_w):
     return cache[1], cache[2]
 
 
-# stride-2 convolutions (7x7 stem, first 3x3 of layer1-3): 'own' = csrc/nf_conv_s2.hip (default), 'miopen' = the vendor library
-CONV_S2 = os.environ.get('NERFOOL_CONV_S2', 'own')
+# stride-2 convolutions (7x7 stem, first 3x3 of layer1-3): csrc/nf_conv_s2.hip
 
 
 def _conv_s2(tape, inp, w, sink):
@@ -338,7 +316,7 @@ def _conv_s2(tape, inp, w, sink):
 def _conv(tape, inp, w, stride, sink, bias=None):
     if stride == 1 and bias is None and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 32 == 0:
         return _conv3x3(tape, inp, w, sink)
-    if stride == 2 and bias is None and CONV_S2 == 'own' and tuple(w.shape[2:]) in ((3, 3), (7, 7)) and (w.shape[2] == 3 or w.shape[1] <= 3):
+    if stride == 2 and bias is None and tuple(w.shape[2:]) in ((3, 3), (7, 7)) and (w.shape[2] == 3 or w.shape[1] <= 3):
         return _conv_s2(tape, inp, w, sink)
     out = _Slot(_aten.convolution(inp, w, bias, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1))
 
@@ -507,14 +485,20 @@ def fused_forward(net, x, need_grad=True):
     return out, tape, xin
 
 
+def _taped(x):
+    """will anybody differentiate this evaluation?  (ctx.needs_input_grad ignores the grad mode, and inside Function.forward the
+    grad mode is always off: the caller decides)"""
+    return torch.is_grad_enabled() and x.requires_grad
+
+
 class _FusedResUNet(torch.autograd.Function):
     """outputs: the feature maps as channel slices of out_conv's ONE channels-last buffer, split INSIDE the function -- the
     gradients then arrive one per map and out_conv's backward reads them in place (nf_conv1x1's second source) instead of
     autograd assembling them with zero fills, two strided copies and an add (0.19 ms per step at BASELINE config 2)."""
 
     @staticmethod
-    def forward(ctx, x, net, split):
-        out, tape, xin = fused_forward(net, x, need_grad=ctx.needs_input_grad[0])
+    def forward(ctx, x, net, split, need_grad):
+        out, tape, xin = fused_forward(net, x, need_grad=need_grad)
         ctx.tape, ctx.out, ctx.xin = tape, out, xin
         full = out.v.contiguous(memory_format=torch.channels_last)
         if len(split) == 1:
@@ -533,4 +517,4 @@ class _FusedResUNet(torch.autograd.Function):
             step()
         g = ctx.xin.g
         ctx.tape = ctx.out = ctx.xin = None
-        return g, None, None
+        return g, None, None, None

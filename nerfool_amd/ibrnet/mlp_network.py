@@ -4,8 +4,6 @@ The module tree reproduces the parameter names of ibrnet/mlp_network.py:152-208 
 checkpoints (`net_coarse` / `net_fine` state-dicts) load by key; `pos_encoding` is rebuilt from n_samples because
 checkpoints may lack it (ibrnet/model.py:148-150).  The parameters are treated as constants of the attack: the
 backward produces d/d(rgb_feat) only (the reference accumulates weight gradients and never reads them)."""
-import os
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -41,13 +39,9 @@ def sinusoid_table(n_samples, d_hid=16):
     return torch.from_numpy(np.where(j % 2 == 0, np.sin(ang), np.cos(ang))).float().unsqueeze(0)
 
 
-# 'auto' = matrix-core kernels whenever the shape allows (V a power of two), 'generic' = shape-generic kernels only
-KERNEL_PATH = os.environ.get('NERFOOL_IBRNET_KERNELS', 'auto')
-
-
-# 'fp32' (default: exact fp32 matrix-core arithmetic, the parity path) or 'bf16' (BASELINE config 5: bf16 operands with fp32
-# accumulation in the per-(sample, view) row network -- 16x the matrix rate, ~1e-2 accuracy; never chosen silently)
-PRECISION = os.environ.get('NERFOOL_IBRNET_PRECISION', 'fp32')
+# Test / diagnostic hook (tests/ and tools/ set it; nothing reads the environment): 'auto' = matrix-core kernels whenever the shape
+# allows (V a power of two), 'generic' = shape-generic kernels only (the CPU stand-in emulates those ~30x faster)
+KERNEL_PATH = 'auto'
 
 
 class _IBRNetFunction(torch.autograd.Function):
@@ -99,33 +93,12 @@ class _IBRNetGatherFunction(torch.autograd.Function):
         return (d_feat,) + (None,) * 9
 
 
-class _IBRNetGatheredFunction(torch.autograd.Function):
-    """IBRNet.forward_gathered with a gradient: forward = ops.ibrnet_fwd_mfma_gather (projection + taps inside the row kernel),
-    backward = ops.ibrnet_bwd_mfma_gather_scatter (the recompute gathers again, the output stage scatters) -- neither rgb_feat
-    nor its gradient exists in memory.  The mask (second output) is a constant of the step."""
-
-    @staticmethod
-    def forward(ctx, featmaps, xyz, cam_ws, src_rgbs, blob, mfma_blob, pos_enc, anti_alias):
-        raw, mask, smp = ops.ibrnet_fwd_mfma_gather(mfma_blob, blob, pos_enc, xyz, cam_ws, src_rgbs, featmaps, anti_alias)
-        ctx.save_for_backward(featmaps, xyz, cam_ws, src_rgbs, blob, mfma_blob, pos_enc, smp)
-        ctx.anti_alias = anti_alias
-        ctx.mark_non_differentiable(mask)
-        return raw, mask
-
-    @staticmethod
-    def backward(ctx, d_raw, _d_mask):
-        featmaps, xyz, cam_ws, src_rgbs, blob, mfma_blob, pos_enc, smp = ctx.saved_tensors
-        d_feat = ops.ibrnet_bwd_mfma_gather_scatter(mfma_blob, blob, pos_enc, smp, d_raw, ctx.anti_alias, xyz, cam_ws, src_rgbs, featmaps)
-        return (d_feat,) + (None,) * 7
-
-
-# 'fused' (default): rendering gathers inside the row kernel (no rgb_feat at all); the attack's forward runs the stand-alone
-# gather, its backward scatters d rgb_feat from inside the row kernel.  'full': the attack gathers inside the row kernels in both
-# directions as well -- neither rgb_feat nor its gradient ever exists in memory (the literal north-star data flow; measured 3 %
-# slower per step at N_rand 4096: the backward's recompute pays for the taps a second time at one wave per SIMD).
-# 'separate': nf_project_gather_fwd / nf_ibrnet_* / nf_project_gather_bwd as three stages (always so with the generic kernels;
-# the bf16 rows and NERFOOL_GATHER_BWD=deterministic keep the stand-alone scatter)
-GATHER_BWD_FUSION = os.environ.get('NERFOOL_GATHER_FUSION', 'fused')
+# Test hook: 'fused' (default) -- rendering gathers inside the row kernel (no rgb_feat at all); the attack's forward runs the
+# stand-alone gather and its backward scatters d rgb_feat from inside the row kernel (a backward that gathers AGAIN for its
+# recompute was built and measured 3 % slower per step: not shipped).  'separate': nf_project_gather_fwd /
+# nf_ibrnet_* / nf_project_gather_bwd as three stages (always so with the generic kernels, the bf16 rows and the deterministic
+# scatter)
+GATHER_BWD_FUSION = 'fused'
 
 
 class IBRNet(nn.Module):
@@ -156,8 +129,9 @@ class IBRNet(nn.Module):
         self._mfma_blob = None
         self._bf16_blob = None
         self._blob_key = None
-        # args.ibrnet_precision ('fp32' | 'bf16') overrides the NERFOOL_IBRNET_PRECISION default for this network
-        self.precision = getattr(args, 'ibrnet_precision', None) or PRECISION
+        # args.ibrnet_precision: 'fp32' (default: exact fp32 matrix-core arithmetic, the parity path) or 'bf16' (BASELINE config 5:
+        # bf16 operands with fp32 accumulation in the per-(sample, view) row network; ~1e-2 accuracy, never chosen silently)
+        self.precision = getattr(args, 'ibrnet_precision', None) or 'fp32'
         if self.precision not in ('fp32', 'bf16'):
             raise ValueError("ibrnet_precision must be 'fp32' or 'bf16' (got %r)" % (self.precision,))
 
@@ -172,26 +146,22 @@ class IBRNet(nn.Module):
         return self._blob, self._mfma_blob
 
     def can_gather(self, featmaps, n_samples, n_views):
-        """may forward_gathered take this level?  Matrix-core kernels and channels-last 32-channel maps; with a gradient to
-        propagate also the exact-fp32 rows and the atomic scatter (the fused backward is built for those)."""
-        if not (GATHER_BWD_FUSION in ('fused', 'full') and KERNEL_PATH != 'generic' and ops.ibrnet_mfma_supported(n_samples, n_views)
+        """may forward_gathered take this level?  Matrix-core kernels, channels-last 32-channel maps and nothing to differentiate
+        (the attack's forward keeps the stand-alone gather: its backward re-reads rgb_feat for the recompute, which is faster than
+        gathering again -- N_rand 4096: 14.7 against 15.2 ms per step)."""
+        if not (GATHER_BWD_FUSION == 'fused' and KERNEL_PATH != 'generic' and ops.ibrnet_mfma_supported(n_samples, n_views)
                 and ops.ibrnet_gather_layout_ok(featmaps)):
             return False
-        if torch.is_grad_enabled() and featmaps.requires_grad:
-            # gathering again in the backward's recompute is slower than re-reading the rgb_feat the forward's stand-alone gather
-            # left behind (N_rand 4096: 15.2 against 14.7 ms per step): only on request
-            return GATHER_BWD_FUSION == 'full' and self.precision == 'fp32' and ops.GATHER_BWD != 'deterministic'
-        return True
+        return not (torch.is_grad_enabled() and featmaps.requires_grad)
 
     def forward_gathered(self, xyz, cam_ws, src_rgbs, featmaps):
         """Projector.compute + forward in the network's own kernels: the row kernel projects the samples and takes its bilinear
-        taps from the feature maps / source images itself (ops.ibrnet_fwd_mfma_gather); differentiable w.r.t. the feature maps
-        (_IBRNetGatheredFunction).  xyz [n_rays, n_samples, 3], cam_ws from ops.camera_setup, src_rgbs [n_views, h, w, 3]
+        taps from the feature maps / source images itself (ops.ibrnet_fwd_mfma_gather); no gradient (rendering, pseudo-GT).
+        xyz [n_rays, n_samples, 3], cam_ws from ops.camera_setup, src_rgbs [n_views, h, w, 3]
         -> raw [n_rays, n_samples, 4], mask [n_rays, n_samples, n_views]."""
         blob, mfma_blob = self._packed(xyz.device)
         if torch.is_grad_enabled() and featmaps.requires_grad:
-            return _IBRNetGatheredFunction.apply(featmaps, xyz.detach(), cam_ws, src_rgbs.detach(), blob, mfma_blob, self.pos_encoding,
-                                                 bool(self.anti_alias_pooling))
+            raise RuntimeError('IBRNet.forward_gathered carries no gradient: differentiate through Projector.compute + forward()')
         raw, mask, _ = ops.ibrnet_fwd_mfma_gather(mfma_blob, blob, self.pos_encoding, xyz.detach(), cam_ws, src_rgbs.detach(),
                                                   featmaps.detach(), bool(self.anti_alias_pooling),
                                                   bf16_blob=self._bf16_blob if self.precision == 'bf16' else None)
@@ -206,10 +176,12 @@ class IBRNet(nn.Module):
         """
         blob, mfma_blob = self._packed(rgb_feat.device)
         gather = getattr(rgb_feat, '_nf_gather', None)
-        if (gather is not None and GATHER_BWD_FUSION in ('fused', 'full') and self.precision == 'fp32' and KERNEL_PATH != 'generic'
+        if gather is not None and gather[3] != rgb_feat._version:
+            gather = None           # edited in place since Projector.compute: it is no longer the gather of those maps
+        if (gather is not None and GATHER_BWD_FUSION == 'fused' and self.precision == 'fp32' and KERNEL_PATH != 'generic'
                 and ops.GATHER_BWD != 'deterministic' and torch.is_grad_enabled() and gather[2].requires_grad
                 and gather[2].shape[1] == 32 and ops.ibrnet_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])):
-            pts, cam_ws, featmaps = gather
+            pts, cam_ws, featmaps = gather[:3]
             return _IBRNetGatherFunction.apply(featmaps, rgb_feat.detach(), ray_diff, mask[..., 0], blob, mfma_blob, self.pos_encoding,
                                                bool(self.anti_alias_pooling), pts, cam_ws)
         return _IBRNetFunction.apply(rgb_feat, ray_diff, mask[..., 0], blob, mfma_blob, self.pos_encoding,

@@ -55,7 +55,8 @@ class Projector:
         if featmaps.requires_grad:
             # what the adjoint of this gather needs, for a consumer that fuses it into its own backward (IBRNet.forward: the scatter
             # then runs inside the row kernel and d rgb_feat is never written); anybody else differentiates rgb_feat as usual
-            rgb_feat._nf_gather = (pts, cam_ws, featmaps)
+            # (the version counter lets the consumer see an in-place edit of rgb_feat made after this point and fall back)
+            rgb_feat._nf_gather = (pts, cam_ws, featmaps, rgb_feat._version)
         return rgb_feat, ray_diff.view(R, S, V, 4), mask.view(R, S, V, 1)
 
     def compute_projections(self, xyz, train_cameras):

@@ -3,7 +3,15 @@
 Unlike the reference (a synchronising `.cpu()` per key per chunk, render_image.py:98-102), a chunk's outputs leave for the
 host on a second HIP stream while the next chunk renders: 2.3 KB per ray at 64 + 64 samples, 1.8 GB for a 756 x 1008 image --
 a third of the image time when moved at the end through pageable memory.  The host tensors are page-locked (torch's caching
-host allocator: pinned once, reused by later calls); the returned values are identical."""
+host allocator: pinned once, reused by later calls) up to `PINNED_BUDGET_BYTES` of live results, pageable beyond that; the
+returned values are identical.
+
+Multi-GPU (`shard=RayShard`, SURVEY 8e: "contiguous ray ranges per rank, gather to rank 0"; the reference's only
+ray-parallel precedent is the DistributedDataParallel wrapping of ibrnet/model.py:98-110): the image's chunks are dealt to
+the ranks as contiguous blocks, every rank renders its block into HBM, and ONE collective per image (a gather of the packed
+per-ray records to rank 0, or an all-gather with `shard.gather_render_to=None`) assembles the image.  No collective sits in
+the data path of a chunk."""
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -11,10 +19,32 @@ import torch
 from .render_ray import render_rays, render_rays_hybrid
 
 _WHOLE = ('camera', 'depth_range', 'src_rgbs', 'src_cameras')
+_LEVELS = ('outputs_coarse', 'outputs_fine')
+
+PINNED_BUDGET_BYTES = 6 << 30       # live page-locked result tensors (three 756 x 1008 images at 64 + 64 samples); beyond: pageable
+_pinned_live = [0]
+
+
+def _release(nbytes):
+    _pinned_live[0] -= nbytes
+
+
+def _host_tensor(shape, dtype, want_pinned):
+    """page-locked while the live pinned results stay under the budget (accounted until the tensor's storage dies), else
+    pageable: retained renders cannot exhaust lockable memory"""
+    nbytes = torch.empty((), dtype=dtype).element_size()
+    for s in shape:
+        nbytes *= int(s)
+    if want_pinned and _pinned_live[0] + nbytes <= PINNED_BUDGET_BYTES:
+        t = torch.empty(shape, dtype=dtype, pin_memory=True)
+        _pinned_live[0] += nbytes
+        weakref.finalize(t.untyped_storage(), _release, nbytes)
+        return t
+    return torch.empty(shape, dtype=dtype)
 
 
 class HostCollector:
-    """chunk outputs -> page-locked host tensors [n_rays, ...] per level and key, copied on a second stream as they appear"""
+    """chunk outputs -> host tensors [n_rays, ...] per level and key, copied on a second stream as they appear"""
 
     def __init__(self, n_rays, device):
         self.n_rays, self.device = n_rays, device
@@ -27,7 +57,7 @@ class HostCollector:
         """outputs of the chunk that starts at ray i (a level may be None, and so may a key of the GNT flavour)"""
         if self.on_gpu:
             self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
-        for level in ('outputs_coarse', 'outputs_fine'):
+        for level in _LEVELS:
             if ret[level] is None:
                 self.host[level] = None
                 continue
@@ -36,7 +66,7 @@ class HostCollector:
                     self.host[level].setdefault(k, None)
                     continue
                 if self.host[level].get(k) is None:
-                    self.host[level][k] = torch.empty((self.n_rays,) + tuple(v.shape[1:]), dtype=v.dtype, pin_memory=self.on_gpu)
+                    self.host[level][k] = _host_tensor((self.n_rays,) + tuple(v.shape[1:]), v.dtype, self.on_gpu)
                 dst = self.host[level][k][i:i + v.shape[0]]
                 if self.on_gpu:
                     with torch.cuda.stream(self.copy_stream):
@@ -51,7 +81,7 @@ class HostCollector:
             self.copy_stream.synchronize()
         self.in_flight = []
         all_ret = OrderedDict([('outputs_coarse', OrderedDict()), ('outputs_fine', OrderedDict())])
-        for level in ('outputs_coarse', 'outputs_fine'):
+        for level in _LEVELS:
             if self.host[level] is None:
                 all_ret[level] = None
                 continue
@@ -60,29 +90,150 @@ class HostCollector:
         return all_ret
 
 
-def render_single_image(ray_sampler, ray_batch, model, projector, chunk_size, N_samples, inv_uniform=False,
-                        N_importance=0, det=False, white_bkgd=False, render_stride=1, featmaps=None, args=None,
-                        featmaps_clean=None, src_ray_batch=None):
-    hybrid = args is not None and (getattr(args, 'use_clean_color', False) or getattr(args, 'use_clean_density', False))
-    if hybrid:
-        assert featmaps_clean is not None
+def chunk_block(n_chunks, rank, world):
+    """contiguous block [lo, hi) of the image's chunks rendered by `rank` (sizes differ by at most one; the first
+    `n_chunks % world` ranks take the longer blocks; empty for the ranks beyond n_chunks)"""
+    base, extra = divmod(n_chunks, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardCollector:
+    """This rank's chunk outputs stay in HBM as ONE packed fp32 record per ray (all fields of both levels side by side, in
+    schema order; bool / integer fields travel as 0.0 / 1.0 resp. their exact float value), padded to the longest block, so
+    that a single collective assembles the image.  The schema -- (level, key, trailing shape, dtype) of every field --
+    follows from the first chunk; a rank without any chunk learns it from rank 0."""
+
+    def __init__(self, n_rays, chunk_size, shard, device):
+        self.n_rays, self.chunk_size, self.shard, self.device = n_rays, chunk_size, shard, device
+        self.n_chunks = -(-n_rays // chunk_size)
+        self.lo, self.hi = chunk_block(self.n_chunks, shard.rank, shard.world)
+        self.rows = chunk_block(self.n_chunks, 0, shard.world)[1] * chunk_size     # rank 0 owns a longest block
+        self.schema = None
+        self.buf = None
+
+    def starts(self):
+        return range(self.lo * self.chunk_size, min(self.hi * self.chunk_size, self.n_rays), self.chunk_size)
+
+    @staticmethod
+    def _schema_of(ret):
+        schema = []
+        for level in _LEVELS:
+            if ret[level] is None:
+                schema.append((level, None, None, None))
+                continue
+            for k, v in ret[level].items():
+                schema.append((level, k, None, None) if v is None else (level, k, tuple(v.shape[1:]), str(v.dtype)))
+        return schema
+
+    @staticmethod
+    def _width(shape):
+        w = 1
+        for s in shape:
+            w *= s
+        return w
+
+    def _alloc(self):
+        width = sum(self._width(s) for _, k, s, _ in self.schema if k is not None and s is not None)
+        self.buf = torch.zeros(self.rows, width, dtype=torch.float32, device=self.device)
+
+    def add(self, i, ret):
+        if self.schema is None:
+            self.schema = self._schema_of(ret)
+            self._alloc()
+        r0 = i - self.lo * self.chunk_size
+        col = 0
+        for level, k, shape, _ in self.schema:
+            if k is None or shape is None:
+                continue
+            v = ret[level][k]
+            w = self._width(shape)
+            self.buf[r0:r0 + v.shape[0], col:col + w] = v.reshape(v.shape[0], w)
+            col += w
+
+    def finish(self, hs, ws):
+        """-> the reference's return schema on the gathering rank (host tensors), None on the others"""
+        shard = self.shard
+        dist = shard.dist
+        if self.n_chunks < shard.world:       # some rank rendered nothing and has no schema yet
+            box = [self.schema if shard.rank == 0 else None]
+            dist.broadcast_object_list(box, src=shard.global_rank(0), group=shard.group)
+            if self.schema is None:
+                self.schema = box[0]
+                self._alloc()
+        dst = shard.gather_render_to
+        full = shard.gather_rows(self.buf, dst)
+        if full is None:
+            return None
+        # the blocks are contiguous in image order: drop every rank's padding rows
+        parts = []
+        for r in range(shard.world):
+            lo, hi = chunk_block(self.n_chunks, r, shard.world)
+            n = min(hi * self.chunk_size, self.n_rays) - lo * self.chunk_size
+            if n > 0:
+                parts.append(full[r, :n])
+        rows = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        all_ret = OrderedDict([('outputs_coarse', OrderedDict()), ('outputs_fine', OrderedDict())])
+        on_gpu = self.device.type == 'cuda'
+        col = 0
+        pending = []
+        for level, k, shape, dtype in self.schema:
+            if k is None:
+                all_ret[level] = None
+                continue
+            if shape is None:
+                all_ret[level][k] = None
+                continue
+            w = self._width(shape)
+            field = rows[:, col:col + w].reshape((self.n_rays,) + shape).to(getattr(torch, dtype.split('.')[-1]))
+            col += w
+            host = _host_tensor(tuple(field.shape), field.dtype, on_gpu)
+            host.copy_(field, non_blocking=on_gpu)
+            pending.append(field)
+            all_ret[level][k] = host.reshape(hs, ws, -1).squeeze()
+        if on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()
+        return all_ret
+
+
+def run_chunks(ray_batch, chunk_size, render_chunk, hs, ws, shard=None):
+    """the chunk loop shared by both flavours: `render_chunk(chunk ray batch) -> ret`; with `shard` (world > 1) this rank
+    renders its contiguous block of chunks and the image is assembled by one collective"""
     n_rays = ray_batch['ray_o'].shape[0]
-    out = HostCollector(n_rays, ray_batch['ray_o'].device)
+    device = ray_batch['ray_o'].device
+    if shard is not None and shard.world > 1:
+        out = ShardCollector(n_rays, chunk_size, shard, device)
+        starts = out.starts()
+    else:
+        out = HostCollector(n_rays, device)
+        starts = range(0, n_rays, chunk_size)
     with torch.no_grad():
-        for i in range(0, n_rays, chunk_size):
+        for i in starts:
             chunk = OrderedDict()
             for k, v in ray_batch.items():
                 chunk[k] = v if (k in _WHOLE or v is None) else v[i:i + chunk_size]
-            if hybrid:
-                ret = render_rays_hybrid(chunk, model, featmaps, projector=projector, N_samples=N_samples,
-                                         inv_uniform=inv_uniform, N_importance=N_importance, det=det, white_bkgd=white_bkgd,
-                                         args=args, src_ray_batch=src_ray_batch, featmaps_clean=featmaps_clean)
-            else:
-                ret = render_rays(chunk, model, featmaps, projector=projector, N_samples=N_samples,
-                                  inv_uniform=inv_uniform, N_importance=N_importance, det=det, white_bkgd=white_bkgd,
-                                  args=args, src_ray_batch=src_ray_batch)
-            out.add(i, ret)
-    all_ret = out.finish(len(range(0, ray_sampler.H, render_stride)), len(range(0, ray_sampler.W, render_stride)))
+            out.add(i, render_chunk(chunk))
+    return out.finish(hs, ws)
+
+
+def render_single_image(ray_sampler, ray_batch, model, projector, chunk_size, N_samples, inv_uniform=False,
+                        N_importance=0, det=False, white_bkgd=False, render_stride=1, featmaps=None, args=None,
+                        featmaps_clean=None, src_ray_batch=None, shard=None):
+    """shard: optional `eval_adv.RayShard` -- the chunks are rendered by all ranks of its group; the result is returned on
+    rank `shard.gather_render_to` (default 0; None = on every rank) and is None elsewhere."""
+    hybrid = args is not None and (getattr(args, 'use_clean_color', False) or getattr(args, 'use_clean_density', False))
+    if hybrid:
+        assert featmaps_clean is not None
+    kw = dict(projector=projector, N_samples=N_samples, inv_uniform=inv_uniform, N_importance=N_importance, det=det,
+              white_bkgd=white_bkgd, args=args, src_ray_batch=src_ray_batch)
+    if hybrid:
+        render_chunk = lambda chunk: render_rays_hybrid(chunk, model, featmaps, featmaps_clean=featmaps_clean, **kw)
+    else:
+        render_chunk = lambda chunk: render_rays(chunk, model, featmaps, **kw)
+    all_ret = run_chunks(ray_batch, chunk_size, render_chunk, len(range(0, ray_sampler.H, render_stride)),
+                         len(range(0, ray_sampler.W, render_stride)), shard)
+    if all_ret is None:
+        return None
     coarse = all_ret['outputs_coarse']
     coarse['rgb'][coarse['mask'] == 0] = 1.       # coarse level only (render_image.py:113)
     return all_ret

@@ -12,21 +12,37 @@ _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 _current_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
 
 
+_restore_device = None       # the caller's current device while a launch on another GPU is being made
+
+
 def _stream(t):
     """hipStream_t of torch's current stream on t's device (the raw-handle query: a step makes ~250 launches).  Every
     launch passes through here right before the C call, so this is also where the tensor's device is made the current HIP
     device when it is not (a model living on a non-current GPU): kernel launches, the per-device LDS opt-ins and
-    nf_device_cu_count all refer to the current device."""
+    nf_device_cu_count all refer to the current device.  `_done` -- which receives the C call's status -- switches back, so
+    a library call never changes the caller's current device."""
+    global _restore_device
     if t.is_cuda:
         idx = t.device.index
         if idx is None:
             idx = _current_device()
         elif idx != _current_device():
+            if _restore_device is None:
+                _restore_device = _current_device()
             torch.cuda.set_device(idx)
         if _raw_stream is not None:
             return _raw_stream(idx)
         return torch.cuda.current_stream(t.device).cuda_stream
     return 0
+
+
+def _done(status, name):
+    """status of the C call that `_stream` prepared the device for: restore the caller's device, then raise on failure"""
+    global _restore_device
+    if _restore_device is not None:
+        torch.cuda.set_device(_restore_device)
+        _restore_device = None
+    _lib.check(status, name)
 
 
 def _f32(t, name):
@@ -53,7 +69,7 @@ def sample_along_ray(ray_o, ray_d, depth_range, n_samples, inv_uniform, t_rand=N
     z = torch.empty(R, n_samples, dtype=torch.float32, device=ray_o.device)
     if t_rand is not None:
         t_rand = _c(t_rand, 't_rand')
-    _lib.check(_lib.lib().nf_sample_along_ray(_ptr(ray_o), _ptr(ray_d), _ptr(dr), R, n_samples, int(bool(inv_uniform)),
+    _done(_lib.lib().nf_sample_along_ray(_ptr(ray_o), _ptr(ray_d), _ptr(dr), R, n_samples, int(bool(inv_uniform)),
                                               _ptr(t_rand), _ptr(pts), _ptr(z), _stream(ray_o)), 'nf_sample_along_ray')
     return pts, z
 
@@ -62,7 +78,7 @@ def points_from_depths(ray_o, ray_d, z_vals):
     ray_o, ray_d, z_vals = _c(ray_o, 'ray_o'), _c(ray_d, 'ray_d'), _c(z_vals, 'z_vals')
     R, S = z_vals.shape
     pts = torch.empty(R, S, 3, dtype=torch.float32, device=z_vals.device)
-    _lib.check(_lib.lib().nf_points_from_depths(_ptr(ray_o), _ptr(ray_d), _ptr(z_vals), R, S, _ptr(pts), _stream(pts)),
+    _done(_lib.lib().nf_points_from_depths(_ptr(ray_o), _ptr(ray_d), _ptr(z_vals), R, S, _ptr(pts), _stream(pts)),
                'nf_points_from_depths')
     return pts
 
@@ -72,7 +88,7 @@ def camera_setup(query_camera, src_cameras):
     s = _c(src_cameras.reshape(-1, 34), 'src_cameras')
     V = s.shape[0]
     ws = torch.empty((V + 1) * 16, dtype=torch.float32, device=s.device)
-    _lib.check(_lib.lib().nf_camera_setup(_ptr(q), _ptr(s), V, _ptr(ws), _stream(s)), 'nf_camera_setup')
+    _done(_lib.lib().nf_camera_setup(_ptr(q), _ptr(s), V, _ptr(ws), _stream(s)), 'nf_camera_setup')
     return ws
 
 
@@ -91,7 +107,7 @@ def project_gather_fwd(xyz, cam_ws, src_rgbs, featmaps, want_pix=False):
     pix = torch.empty(V, N, 2, dtype=torch.float32, device=dev) if want_pix else None
     sv, sc, sh, sw = featmaps.stride()
     with prof.launch('nf_project_gather_fwd', xyz, n_pts=N, V=V, C=C):
-        _lib.check(_lib.lib().nf_project_gather_fwd(_ptr(xyz), N, _ptr(cam_ws), V, _ptr(src_rgbs), H, W, _ptr(featmaps), C,
+        _done(_lib.lib().nf_project_gather_fwd(_ptr(xyz), N, _ptr(cam_ws), V, _ptr(src_rgbs), H, W, _ptr(featmaps), C,
                                                     Hf, Wf, sv, sc, sh, sw, _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
                                                     _ptr(pix), _stream(xyz)), 'nf_project_gather_fwd')
     return rgb_feat, ray_diff, mask, pix
@@ -99,7 +115,7 @@ def project_gather_fwd(xyz, cam_ws, src_rgbs, featmaps, want_pix=False):
 
 # 'atomic' (default): float atomics, summation order varies run to run (last-bit differences in d featmaps);
 # 'deterministic': keys -> stable sort by feature-map pixel -> segmented sum in sorted order (bitwise reproducible, ~3x the time)
-GATHER_BWD = __import__('os').environ.get('NERFOOL_GATHER_BWD', 'atomic')
+GATHER_BWD = 'atomic'
 
 
 def project_gather_bwd(xyz, cam_ws, V, H, W, d_rgb_feat, feat_shape):
@@ -115,14 +131,14 @@ def project_gather_bwd(xyz, cam_ws, V, H, W, d_rgb_feat, feat_shape):
         n_taps = N * V * 4
         keys = torch.empty(n_taps, dtype=torch.int32, device=xyz.device)
         wts = torch.empty(n_taps, dtype=torch.float32, device=xyz.device)
-        _lib.check(L.nf_project_gather_keys(_ptr(xyz), N, _ptr(cam_ws), V, Hf, Wf, _ptr(keys), _ptr(wts), _stream(xyz)), 'nf_project_gather_keys')
+        _done(L.nf_project_gather_keys(_ptr(xyz), N, _ptr(cam_ws), V, Hf, Wf, _ptr(keys), _ptr(wts), _stream(xyz)), 'nf_project_gather_keys')
         skeys, perm = torch.sort(keys, stable=True)
         with prof.launch('nf_project_gather_bwd_sorted', xyz, n_pts=N, V=V, C=C):
-            _lib.check(L.nf_project_gather_bwd_sorted(_ptr(skeys), _ptr(perm), _ptr(wts), n_taps, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc, sh, sw,
+            _done(L.nf_project_gather_bwd_sorted(_ptr(skeys), _ptr(perm), _ptr(wts), n_taps, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc, sh, sw,
                                                       _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd_sorted')
         return d_feat
     with prof.launch('nf_project_gather_bwd', xyz, n_pts=N, V=V, C=C):
-        _lib.check(_lib.lib().nf_project_gather_bwd(_ptr(xyz), N, _ptr(cam_ws), V, H, W, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc,
+        _done(_lib.lib().nf_project_gather_bwd(_ptr(xyz), N, _ptr(cam_ws), V, H, W, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc,
                                                     sh, sw, _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd')
     return d_feat
 
@@ -133,7 +149,7 @@ def pixel_mask(mask):
     V = m.shape[-1]
     n = m.numel() // V
     out = torch.empty(m.shape[:-1], dtype=torch.bool, device=m.device)
-    _lib.check(_lib.lib().nf_pixel_mask(_ptr(m), n, V, _ptr(out), _stream(m)), 'nf_pixel_mask')
+    _done(_lib.lib().nf_pixel_mask(_ptr(m), n, V, _ptr(out), _stream(m)), 'nf_pixel_mask')
     return out
 
 
@@ -170,7 +186,7 @@ def pack_ibrnet_mfma_blob(natural_blob):
     L = _lib.lib()
     nat = natural_blob.detach().to('cpu', torch.float32).contiguous()
     out = torch.empty(L.nf_ibrnet_mfma_blob_floats(), dtype=torch.float32)
-    _lib.check(L.nf_ibrnet_pack_mfma(nat.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma')
+    _done(L.nf_ibrnet_pack_mfma(nat.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma')
     return out.to(natural_blob.device)
 
 
@@ -179,7 +195,7 @@ def pack_ibrnet_bf16_blob(mfma_blob):
     L = _lib.lib()
     src = mfma_blob.detach().to('cpu', torch.float32).contiguous()
     out = torch.empty(L.nf_ibrnet_mfma_bf16_blob_floats(), dtype=torch.float32)
-    _lib.check(L.nf_ibrnet_pack_mfma_bf16(src.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma_bf16')
+    _done(L.nf_ibrnet_pack_mfma_bf16(src.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma_bf16')
     return out.to(mfma_blob.device)
 
 
@@ -201,12 +217,12 @@ def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_ali
     raw = torch.empty(R, S, 4, dtype=torch.float32, device=rgb_feat.device)
     if bf16_blob is not None:
         with prof.launch('nf_ibrnet_fwd_mfma_bf16', raw, R=R, S=S, V=V):
-            _lib.check(L.nf_ibrnet_fwd_mfma_bf16(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff),
+            _done(L.nf_ibrnet_fwd_mfma_bf16(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff),
                                                  _ptr(mask), R, S, V, int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)),
                        'nf_ibrnet_fwd_mfma_bf16')
         return raw, ws
     with prof.launch('nf_ibrnet_fwd_mfma', raw, R=R, S=S, V=V):
-        _lib.check(L.nf_ibrnet_fwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S,
+        _done(L.nf_ibrnet_fwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S,
                                         V, int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd_mfma')
     return raw, ws
 
@@ -238,33 +254,10 @@ def ibrnet_fwd_mfma_gather(mfma_blob, blob, pos_enc, xyz, cam_ws, src_rgbs, feat
     mask = torch.empty(R, S, V, dtype=torch.float32, device=dev)
     sv, sc, sh, sw = featmaps.stride()
     with prof.launch('nf_ibrnet_fwd_mfma_bf16' if bf16_blob is not None else 'nf_ibrnet_fwd_mfma', raw, R=R, S=S, V=V):
-        _lib.check(L.nf_ibrnet_fwd_mfma_gather(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(xyz), _ptr(cam_ws), _ptr(src_rgbs),
+        _done(L.nf_ibrnet_fwd_mfma_gather(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(xyz), _ptr(cam_ws), _ptr(src_rgbs),
                                                H, W, _ptr(featmaps), Hf, Wf, sv, sc, sh, sw, R, S, V, int(bool(anti_alias)), _ptr(raw), _ptr(ws),
                                                _ptr(mask), _stream(raw)), 'nf_ibrnet_fwd_mfma_gather')
     return raw, mask, ws
-
-
-def ibrnet_bwd_mfma_gather_scatter(mfma_blob, blob, pos_enc, smp, d_raw, anti_alias, xyz, cam_ws, src_rgbs, featmaps):
-    """backward of ibrnet_fwd_mfma_gather (fp32 rows): d_raw [R,S,4] -> d_featmaps [V,32,Hf,Wf] (channels-last storage); the row
-    kernel gathers again for its recompute and scatters from its output stage."""
-    xyz, src_rgbs, d_raw = _c(xyz, 'xyz'), _c(src_rgbs, 'src_rgbs'), _c(d_raw, 'd_raw')
-    if not ibrnet_gather_layout_ok(featmaps):
-        raise ValueError('ibrnet_bwd_mfma_gather_scatter: feature maps must be [V,32,Hf,Wf] float32, channels-last, 16-byte aligned')
-    R, S, _ = xyz.shape
-    V, H, W, _ = src_rgbs.shape
-    _, C, Hf, Wf = featmaps.shape
-    pe = _c(pos_enc.reshape(-1, 16), 'pos_encoding')
-    d_ws = torch.empty_like(smp)
-    sv, sc, sh, sw = featmaps.stride()
-    d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
-    dv, dc, dh, dw = d_feat.stride()
-    with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
-        _lib.check(_lib.lib().nf_ibrnet_bwd_mfma_gather_scatter(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(smp), _ptr(d_raw), R, S, V,
-                                                                int(bool(anti_alias)), _ptr(d_ws), _ptr(xyz), _ptr(cam_ws), _ptr(src_rgbs), H, W,
-                                                                _ptr(featmaps), sv, sc, sh, sw, _ptr(d_feat), dv, dc, dh, dw, Hf, Wf,
-                                                                _stream(d_raw)),
-                   'nf_ibrnet_bwd_mfma_gather_scatter')
-    return d_feat
 
 
 def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias, bf16_blob=None):
@@ -276,13 +269,13 @@ def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_r
     d_rgb_feat = torch.empty_like(rgb_feat)
     if bf16_blob is not None:
         with prof.launch('nf_ibrnet_bwd_mfma_bf16', d_raw, R=R, S=S, V=V):
-            _lib.check(_lib.lib().nf_ibrnet_bwd_mfma_bf16(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat),
+            _done(_lib.lib().nf_ibrnet_bwd_mfma_bf16(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat),
                                                           _ptr(ray_diff), _ptr(mask), _ptr(smp), _ptr(d_raw), R, S, V,
                                                           int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(d_ws), _stream(d_raw)),
                        'nf_ibrnet_bwd_mfma_bf16')
         return d_rgb_feat
     with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
-        _lib.check(_lib.lib().nf_ibrnet_bwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
+        _done(_lib.lib().nf_ibrnet_bwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
                                                  _ptr(smp), _ptr(d_raw), R, S, V, int(bool(anti_alias)), _ptr(d_rgb_feat),
                                                  _ptr(d_ws), _stream(d_raw)), 'nf_ibrnet_bwd_mfma')
     return d_rgb_feat
@@ -302,7 +295,7 @@ def ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, 
     d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
     sv, sc, sh, sw = d_feat.stride()
     with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
-        _lib.check(_lib.lib().nf_ibrnet_bwd_mfma_scatter(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
+        _done(_lib.lib().nf_ibrnet_bwd_mfma_scatter(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
                                                          _ptr(smp), _ptr(d_raw), R, S, V, int(bool(anti_alias)), _ptr(d_ws), _ptr(xyz),
                                                          _ptr(cam_ws), _ptr(d_feat), sv, sc, sh, sw, Hf, Wf, _stream(d_raw)),
                    'nf_ibrnet_bwd_mfma_scatter')
@@ -311,7 +304,7 @@ def ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, 
 
 def debug_mfma32(a, b, c):
     d = torch.empty_like(c)
-    _lib.check(_lib.lib().nf_debug_mfma32(_ptr(_c(a, 'a')), _ptr(_c(b, 'b')), _ptr(_c(c, 'c')), _ptr(d), _stream(d)),
+    _done(_lib.lib().nf_debug_mfma32(_ptr(_c(a, 'a')), _ptr(_c(b, 'b')), _ptr(_c(c, 'c')), _ptr(d), _stream(d)),
                'nf_debug_mfma32')
     return d
 
@@ -328,7 +321,7 @@ def ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias):
     ws = torch.empty(L.nf_ibrnet_workspace_floats(R, S, V, 0), dtype=torch.float32, device=rgb_feat.device)
     raw = torch.empty(R, S, 4, dtype=torch.float32, device=rgb_feat.device)
     with prof.launch('nf_ibrnet_fwd', raw, R=R, S=S, V=V):
-        _lib.check(L.nf_ibrnet_fwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S, V,
+        _done(L.nf_ibrnet_fwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S, V,
                                    int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd')
     return raw
 
@@ -342,7 +335,7 @@ def ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, anti_alias):
     ws = torch.empty(L.nf_ibrnet_workspace_floats(R, S, V, 1), dtype=torch.float32, device=rgb_feat.device)
     d_rgb_feat = torch.empty_like(rgb_feat)
     with prof.launch('nf_ibrnet_bwd', d_raw, R=R, S=S, V=V):
-        _lib.check(L.nf_ibrnet_bwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(d_raw), R, S, V,
+        _done(L.nf_ibrnet_bwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(d_raw), R, S, V,
                                    int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(ws), _stream(d_raw)), 'nf_ibrnet_bwd')
     return d_rgb_feat
 
@@ -359,7 +352,7 @@ def composite_fwd(raw, z_vals, pixel_mask_b, white_bkgd):
     weights = torch.empty(R, S, dtype=torch.float32, device=dev)
     alpha = torch.empty(R, S, dtype=torch.float32, device=dev)
     ray_mask = torch.empty(R, dtype=torch.bool, device=dev)
-    _lib.check(_lib.lib().nf_composite_fwd(_ptr(raw), _ptr(z_vals), _ptr(pm), R, S, int(bool(white_bkgd)), _ptr(rgb),
+    _done(_lib.lib().nf_composite_fwd(_ptr(raw), _ptr(z_vals), _ptr(pm), R, S, int(bool(white_bkgd)), _ptr(rgb),
                                            _ptr(depth), _ptr(weights), _ptr(alpha), _ptr(ray_mask), _stream(raw)),
                'nf_composite_fwd')
     return rgb, depth, weights, alpha, ray_mask
@@ -370,7 +363,7 @@ def composite_bwd(raw, z_vals, white_bkgd, d_rgb=None, d_depth=None, d_weights=N
     R, S, _ = raw.shape
     grads = [None if g is None else _c(g, 'upstream gradient') for g in (d_rgb, d_depth, d_weights, d_alpha)]
     d_raw = torch.empty_like(raw)
-    _lib.check(_lib.lib().nf_composite_bwd(_ptr(raw), _ptr(z_vals), R, S, int(bool(white_bkgd)), _ptr(grads[0]), _ptr(grads[1]),
+    _done(_lib.lib().nf_composite_bwd(_ptr(raw), _ptr(z_vals), R, S, int(bool(white_bkgd)), _ptr(grads[0]), _ptr(grads[1]),
                                            _ptr(grads[2]), _ptr(grads[3]), _ptr(d_raw), _stream(raw)), 'nf_composite_bwd')
     return d_raw
 
@@ -381,7 +374,7 @@ def sample_fine(z_vals, weights, n_importance, inv_uniform, u_rand=None):
     out = torch.empty(R, S + n_importance, dtype=torch.float32, device=z_vals.device)
     if u_rand is not None:
         u_rand = _c(u_rand, 'u_rand')
-    _lib.check(_lib.lib().nf_sample_fine(_ptr(z_vals), _ptr(weights), R, S, n_importance, int(bool(inv_uniform)), _ptr(u_rand),
+    _done(_lib.lib().nf_sample_fine(_ptr(z_vals), _ptr(weights), R, S, n_importance, int(bool(inv_uniform)), _ptr(u_rand),
                                          _ptr(out), _stream(out)), 'nf_sample_fine')
     return out
 
@@ -394,7 +387,7 @@ def sample_pdf(bins, weights, n_samples, u_rand=None):
     out = torch.empty(R, n_samples, dtype=torch.float32, device=bins.device)
     if u_rand is not None:
         u_rand = _c(u_rand, 'u_rand')
-    _lib.check(_lib.lib().nf_sample_pdf(_ptr(bins), _ptr(weights), R, M, n_samples, _ptr(u_rand), _ptr(out), _stream(out)),
+    _done(_lib.lib().nf_sample_pdf(_ptr(bins), _ptr(weights), R, M, n_samples, _ptr(u_rand), _ptr(out), _stream(out)),
                'nf_sample_pdf')
     return out
 
@@ -408,7 +401,7 @@ def masked_mse_fwd(rgb, gt, mask_b=None, cnt_override=None):
         if pm.dtype != torch.bool:
             pm = pm != 0
     out = torch.empty(3, dtype=torch.float32, device=rgb.device)
-    _lib.check(_lib.lib().nf_masked_mse_fwd(_ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt_override), _ptr(out), _stream(rgb)),
+    _done(_lib.lib().nf_masked_mse_fwd(_ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt_override), _ptr(out), _stream(rgb)),
                'nf_masked_mse_fwd')
     return out, pm
 
@@ -417,7 +410,7 @@ def masked_mse_bwd(rgb, gt, pm, cnt, d_loss):
     R = rgb.shape[0]
     d_rgb = torch.empty_like(rgb)
     d_loss = _c(d_loss.reshape(1), 'd_loss')
-    _lib.check(_lib.lib().nf_masked_mse_bwd(_ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt), _ptr(d_loss), _ptr(d_rgb),
+    _done(_lib.lib().nf_masked_mse_bwd(_ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt), _ptr(d_loss), _ptr(d_rgb),
                                             _stream(rgb)), 'nf_masked_mse_bwd')
     return d_rgb
 
@@ -432,7 +425,7 @@ def _flat_inplace(t, name):
 def project_perturb_(delta, src, epsilon, lower=0.0, upper=1.0):
     _flat_inplace(delta, 'delta')
     src = _c(src, 'src')
-    _lib.check(_lib.lib().nf_project_perturb(_ptr(delta), _ptr(src), delta.numel(), float(epsilon), float(lower), float(upper),
+    _done(_lib.lib().nf_project_perturb(_ptr(delta), _ptr(src), delta.numel(), float(epsilon), float(lower), float(upper),
                                              _stream(delta)), 'nf_project_perturb')
     return delta
 
@@ -446,7 +439,7 @@ def pgd_adam_step_(delta, grad, exp_avg, exp_avg_sq, src, lr, step, epsilon, bet
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
     with prof.launch('nf_pgd_adam_step', delta, n=delta.numel()):
-        _lib.check(_lib.lib().nf_pgd_adam_step(_ptr(delta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(src),
+        _done(_lib.lib().nf_pgd_adam_step(_ptr(delta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(src),
                                                delta.numel(), -(lr / bc1), 1.0 - beta1, beta2, 1.0 - beta2, bc2 ** 0.5,
                                                adam_eps, float(epsilon), float(lower), float(upper), _stream(delta)),
                    'nf_pgd_adam_step')
@@ -456,7 +449,7 @@ def pgd_adam_step_(delta, grad, exp_avg, exp_avg_sq, src, lr, step, epsilon, bet
 def pgd_sign_step_(delta, grad, src, alpha, epsilon, lower=0.0, upper=1.0):
     _flat_inplace(delta, 'delta')
     grad, src = _c(grad, 'grad'), _c(src, 'src')
-    _lib.check(_lib.lib().nf_pgd_sign_step(_ptr(delta), _ptr(grad), _ptr(src), delta.numel(), float(alpha), float(epsilon),
+    _done(_lib.lib().nf_pgd_sign_step(_ptr(delta), _ptr(grad), _ptr(src), delta.numel(), float(alpha), float(epsilon),
                                            float(lower), float(upper), _stream(delta)), 'nf_pgd_sign_step')
     return delta
 
@@ -491,7 +484,7 @@ def in_act_pad_fwd(x, gamma, beta, res, act, pad, eps=1e-5, out=None, c_off=0):
             raise ValueError('residual shape %s does not match %s' % (tuple(res.shape), (N, C, H, W)))
         rs = res.stride()
     with prof.launch('nf_in_act_pad_fwd', x, n=x.numel()):
-        _lib.check(_lib.lib().nf_in_act_pad_fwd(_ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta), float(eps), _ptr(res), rs[0], rs[1],
+        _done(_lib.lib().nf_in_act_pad_fwd(_ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta), float(eps), _ptr(res), rs[0], rs[1],
                                                 rs[2], rs[3], int(act), int(pad), y_ptr, y_ns, _ptr(mean), _ptr(rstd),
                                                 _ptr(scratch), _stream(x)),
                    'nf_in_act_pad_fwd')
@@ -527,7 +520,7 @@ def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res,
     d_res = torch.empty_like(dx) if want_d_res else None
     scratch = torch.empty(N * C * 64, dtype=torch.float64, device=ref.device) if gamma is not None else None
     with prof.launch('nf_in_act_pad_bwd', ref, n=dx.numel()):
-        _lib.check(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta),
+        _done(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta),
                                                 _ptr(mean), _ptr(rstd), int(act), int(pad), _ptr(d_res), _ptr(dx), _ptr(scratch),
                                                 dy_ns, _ptr(d_extra_sub), _stream(ref)),
                    'nf_in_act_pad_bwd')
@@ -539,7 +532,7 @@ def conv1x1_pack(weight, transposed, device):
     L = _lib.lib()
     w = weight.detach().to('cpu', torch.float32).reshape(weight.shape[0], weight.shape[1]).contiguous()
     out = torch.empty(L.nf_conv1x1_pack_floats(w.shape[0], w.shape[1]), dtype=torch.float32)
-    _lib.check(L.nf_conv1x1_pack(w.data_ptr(), w.shape[0], w.shape[1], int(bool(transposed)), out.data_ptr()), 'nf_conv1x1_pack')
+    _done(L.nf_conv1x1_pack(w.data_ptr(), w.shape[0], w.shape[1], int(bool(transposed)), out.data_ptr()), 'nf_conv1x1_pack')
     return out.to(device)
 
 
@@ -563,7 +556,7 @@ def conv1x1(records, bias, x, c_out, channels_last_out=False, x2=None):
         y = torch.empty(N, c_out, H, W, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
     with prof.launch('nf_conv1x1', x, n=y.numel()):
-        _lib.check(_lib.lib().nf_conv1x1(_ptr(records), _ptr(bias), _ptr(x), xs[0], xs[1], xs[2], xs[3], _ptr(y), ys[0], ys[1], ys[2],
+        _done(_lib.lib().nf_conv1x1(_ptr(records), _ptr(bias), _ptr(x), xs[0], xs[1], xs[2], xs[3], _ptr(y), ys[0], ys[1], ys[2],
                                          ys[3], N, H, W, c_in, c_out, _ptr(x2), c_split, _stream(x)), 'nf_conv1x1')
     return y
 
@@ -585,7 +578,7 @@ def pad_gather_fwd(src, H, W, pad, top=0, left=0, out=None):
     assert tuple(out.shape) == (N, C, Hp, Wp) and out.stride(3) == 1 and out.stride(2) == Wp
     ss = src.stride()
     with prof.launch('nf_pad_gather_fwd', src, n=out.numel()):
-        _lib.check(_lib.lib().nf_pad_gather_fwd(_ptr(src), ss[0], ss[1], ss[2], ss[3], N, C, eh, ew, int(top), int(left), int(H), int(W), int(pad),
+        _done(_lib.lib().nf_pad_gather_fwd(_ptr(src), ss[0], ss[1], ss[2], ss[3], N, C, eh, ew, int(top), int(left), int(H), int(W), int(pad),
                                                 _ptr(out), out.stride(0), out.stride(1), _stream(src)), 'nf_pad_gather_fwd')
     return out
 
@@ -602,7 +595,7 @@ def pad_gather_bwd(d_out, H, W, pad, eh, ew, top=0, left=0, like=None):
         din = torch.empty(N, C, eh, ew, dtype=torch.float32, device=d_out.device)
     ds = din.stride()
     with prof.launch('nf_pad_gather_bwd', d_out, n=d_out.numel()):
-        _lib.check(_lib.lib().nf_pad_gather_bwd(_ptr(d_out), d_out.stride(0), d_out.stride(1), N, C, int(H), int(W), int(pad), int(eh), int(ew),
+        _done(_lib.lib().nf_pad_gather_bwd(_ptr(d_out), d_out.stride(0), d_out.stride(1), N, C, int(H), int(W), int(pad), int(eh), int(ew),
                                                 int(top), int(left), _ptr(din), ds[0], ds[1], ds[2], ds[3], _stream(d_out)), 'nf_pad_gather_bwd')
     return din
 
@@ -613,7 +606,7 @@ def upsample2x_pad_bwd(d_yp, h, w, pad):
     N, C = d_yp.shape[0], d_yp.shape[1]
     dx = torch.empty(N, C, h, w, dtype=torch.float32, device=d_yp.device)
     with prof.launch('nf_upsample2x_pad_bwd', d_yp, n=d_yp.numel()):
-        _lib.check(_lib.lib().nf_upsample2x_pad_bwd(_ptr(d_yp), N * C, int(h), int(w), int(pad), _ptr(dx), h * w, w, _stream(d_yp)),
+        _done(_lib.lib().nf_upsample2x_pad_bwd(_ptr(d_yp), N * C, int(h), int(w), int(pad), _ptr(dx), h * w, w, _stream(d_yp)),
                    'nf_upsample2x_pad_bwd')
     return dx
 
@@ -628,7 +621,7 @@ def conv_s2_pack(weight, backward, device):
     if n < 0:
         raise ValueError('stride-2 convolution kernels exist for 3x3 and 7x7 (got %dx%d)' % (ks, ks))
     out = torch.empty(n, dtype=torch.float32)
-    _lib.check(L.nf_conv_s2_pack(w.data_ptr(), c_out, c_in, ks, int(bool(backward)), out.data_ptr()), 'nf_conv_s2_pack')
+    _done(L.nf_conv_s2_pack(w.data_ptr(), c_out, c_in, ks, int(bool(backward)), out.data_ptr()), 'nf_conv_s2_pack')
     return out.to(device)
 
 
@@ -642,7 +635,7 @@ def conv_s2_fwd(records, x, c_out, ks):
     y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
     with prof.launch('nf_conv_s2_fwd', x, n_img=N, c_in=c_in, c_out=c_out, ks=ks, Ho=Ho, Wo=Wo):
-        _lib.check(_lib.lib().nf_conv_s2_fwd(_ptr(records), int(ks), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, _ptr(y), ys[0], ys[1], ys[2],
+        _done(_lib.lib().nf_conv_s2_fwd(_ptr(records), int(ks), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, _ptr(y), ys[0], ys[1], ys[2],
                                              Ho, Wo, N, c_in, c_out, _stream(x)), 'nf_conv_s2_fwd')
     return y
 
@@ -656,35 +649,9 @@ def conv_s2_bwd(records, dy, c_in, ks, Hi, Wi):
     dx = torch.empty(N, c_in, Hi, Wi, dtype=torch.float32, device=dy.device)
     ds, xs = dy.stride(), dx.stride()
     with prof.launch('nf_conv_s2_bwd', dy, n_img=N, c_in=c_in, c_out=c_out, ks=ks, Ho=Ho, Wo=Wo):
-        _lib.check(_lib.lib().nf_conv_s2_bwd(_ptr(records), int(ks), _ptr(dy), ds[0], ds[1], ds[2], Ho, Wo, _ptr(dx), xs[0], xs[1], xs[2],
+        _done(_lib.lib().nf_conv_s2_bwd(_ptr(records), int(ks), _ptr(dy), ds[0], ds[1], ds[2], Ho, Wo, _ptr(dx), xs[0], xs[1], xs[2],
                                              Hi, Wi, N, c_in, c_out, _stream(dy)), 'nf_conv_s2_bwd')
     return dx
-
-
-def wino4_pack(weight, backward, device):
-    """weight [c_out, c_in, 3, 3] -> Winograd F(4x4,3x3)-domain MFMA records (backward: the backward-data convolution)"""
-    L = _lib.lib()
-    w = weight.detach().to('cpu', torch.float32).contiguous()
-    c_out, c_in = w.shape[0], w.shape[1]
-    n_out, n_in = (c_in, c_out) if backward else (c_out, c_in)
-    out = torch.empty(L.nf_wino4_pack_floats(n_out, n_in), dtype=torch.float32)
-    _lib.check(L.nf_wino4_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), out.data_ptr()), 'nf_wino4_pack')
-    return out.to(device)
-
-
-def conv3x3_wino4(records, x, c_out, pad):
-    """conv3x3_wino in F(4x4,3x3) form (same arguments, records from wino4_pack)"""
-    _f32(x, 'x')
-    if x.stride(3) != 1:
-        x = x.contiguous()
-    N, c_in, Hi, Wi = x.shape
-    Ho, Wo = Hi - 2 + 2 * pad, Wi - 2 + 2 * pad
-    y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
-    xs, ys = x.stride(), y.stride()
-    with prof.launch('nf_conv3x3_wino', x, n_img=N, c_in=c_in, c_out=c_out, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, m=4):
-        _lib.check(_lib.lib().nf_conv3x3_wino4(_ptr(records), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y), ys[0], ys[1], ys[2], Ho, Wo,
-                                               N, c_in, c_out, _stream(x)), 'nf_conv3x3_wino4')
-    return y
 
 
 def wino_pack(weight, backward, device, k_per_group=None):
@@ -696,7 +663,7 @@ def wino_pack(weight, backward, device, k_per_group=None):
     n_out = c_in if backward else c_out
     kg = wino_group(n_out) if k_per_group is None else int(k_per_group)
     out = torch.empty(L.nf_wino_pack_floats(n_out, c_out if backward else c_in, kg), dtype=torch.float32)
-    _lib.check(L.nf_wino_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), kg, out.data_ptr()), 'nf_wino_pack')
+    _done(L.nf_wino_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), kg, out.data_ptr()), 'nf_wino_pack')
     return out.to(device)
 
 
@@ -712,7 +679,7 @@ def conv3x3_wino(records, x, c_out, pad, tile_blocks=0, k_per_group=None):
     y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
     with prof.launch('nf_conv3x3_wino', x, n_img=N, c_in=c_in, c_out=c_out, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo):
-        _lib.check(_lib.lib().nf_conv3x3_wino(_ptr(records), wino_group(c_out) if k_per_group is None else int(k_per_group), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y),
+        _done(_lib.lib().nf_conv3x3_wino(_ptr(records), wino_group(c_out) if k_per_group is None else int(k_per_group), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y),
                                               ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out, int(tile_blocks), _stream(x)),
                    'nf_conv3x3_wino')
     return y
@@ -723,7 +690,7 @@ def wino_ring_pack(weight, device):
     L = _lib.lib()
     w = weight.detach().to('cpu', torch.float32).contiguous()
     out = torch.empty(L.nf_wino_ring_pack_floats(w.shape[0], w.shape[1]), dtype=torch.float32)
-    _lib.check(L.nf_wino_ring_pack(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr()), 'nf_wino_ring_pack')
+    _done(L.nf_wino_ring_pack(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr()), 'nf_wino_ring_pack')
     return out.to(device)
 
 
@@ -759,11 +726,11 @@ def conv3x3_wino_bwd_split(records, ring_records, dy, c_dx, plan, k_per_group=No
     xs, gs = dy.stride(), g.stride()
     L = _lib.lib()
     with prof.launch('nf_conv3x3_wino', dy, n_img=N, c_in=c_dy, c_out=c_dx, Hi=H, Wi=W, Ho=rows, Wo=cols):
-        _lib.check(L.nf_conv3x3_wino(_ptr(records), wino_group(c_dx) if k_per_group is None else int(k_per_group), _ptr(dy), xs[0], xs[1], xs[2],
+        _done(L.nf_conv3x3_wino(_ptr(records), wino_group(c_dx) if k_per_group is None else int(k_per_group), _ptr(dy), xs[0], xs[1], xs[2],
                                      H, W, 1, g.data_ptr() + 4 * (gs[2] + 1), gs[0], gs[1], gs[2], rows, cols, N, c_dy, c_dx, 0, _stream(dy)),
                    'nf_conv3x3_wino')
     with prof.launch('nf_conv3x3_bwd_ring', dy, n=N * c_dx * (2 * (W + 2) + 2 * H)):
-        _lib.check(L.nf_conv3x3_bwd_ring(_ptr(ring_records), _ptr(dy), xs[0], xs[1], xs[2], H, W, _ptr(g), gs[0], gs[1], gs[2], N, c_dy, c_dx,
+        _done(L.nf_conv3x3_bwd_ring(_ptr(ring_records), _ptr(dy), xs[0], xs[1], xs[2], H, W, _ptr(g), gs[0], gs[1], gs[2], N, c_dy, c_dx,
                                          int(kinds), _stream(dy)), 'nf_conv3x3_bwd_ring')
     return g
 
@@ -779,7 +746,7 @@ def upsample2x_pad_fwd(x, pad):
         sn, sc, sh, sw = x.stride()
     yp = torch.empty(N, C, 2 * h + 2 * pad, 2 * w + 2 * pad, dtype=torch.float32, device=x.device)
     with prof.launch('nf_upsample2x_pad_fwd', x, n=yp.numel()):
-        _lib.check(_lib.lib().nf_upsample2x_pad_fwd(_ptr(x), N * C, sc, sh, h, w, int(pad), _ptr(yp), _stream(x)),
+        _done(_lib.lib().nf_upsample2x_pad_fwd(_ptr(x), N * C, sc, sh, h, w, int(pad), _ptr(yp), _stream(x)),
                    'nf_upsample2x_pad_fwd')
     return yp
 
@@ -816,7 +783,7 @@ def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=
     rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
     alpha = torch.empty(R, S, dtype=torch.float32, device=rgb_feat.device) if want_alpha else None
     with prof.launch('nf_gnt_fwd', rgb, R=R, S=S, V=V, depth=depth):
-        _lib.check(L.nf_gnt_fwd(_ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V, depth,
+        _done(L.nf_gnt_fwd(_ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V, depth,
                                 int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd')
     if want_alpha:
         return rgb, (ws if save else None), alpha
@@ -828,7 +795,7 @@ def pack_gnt_mfma_blob(blob, depth):
     L = _lib.lib()
     nat = blob.detach().to('cpu', torch.float32).contiguous()
     out = torch.empty(L.nf_gnt_mfma_blob_floats(depth), dtype=torch.float32)
-    _lib.check(L.nf_gnt_pack_mfma(depth, nat.data_ptr(), out.data_ptr()), 'nf_gnt_pack_mfma')
+    _done(L.nf_gnt_pack_mfma(depth, nat.data_ptr(), out.data_ptr()), 'nf_gnt_pack_mfma')
     return out.to(blob.device)
 
 
@@ -847,7 +814,7 @@ def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, w
     rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
     alpha = torch.empty(R, S, dtype=torch.float32, device=rgb_feat.device) if want_alpha else None
     with prof.launch('nf_gnt_fwd_mfma', rgb, R=R, S=S, V=V, depth=depth):
-        _lib.check(L.nf_gnt_fwd_mfma(_ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
+        _done(L.nf_gnt_fwd_mfma(_ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
                                      depth, int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd_mfma')
     if want_alpha:
         return rgb, (ws if save else None), alpha
@@ -859,7 +826,7 @@ def gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, shape, depth):
     mask, d_rgb = _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
     d_rgb_feat = torch.empty(R, S, V, 35, dtype=torch.float32, device=d_rgb.device)
     with prof.launch('nf_gnt_bwd_mfma', d_rgb, R=R, S=S, V=V, depth=depth):
-        _lib.check(_lib.lib().nf_gnt_bwd_mfma(_ptr(mfma_blob), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat), _ptr(ws),
+        _done(_lib.lib().nf_gnt_bwd_mfma(_ptr(mfma_blob), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat), _ptr(ws),
                                               _stream(d_rgb)), 'nf_gnt_bwd_mfma')
     return d_rgb_feat
 
@@ -869,6 +836,6 @@ def gnt_bwd(blob, ray_diff, mask, d_rgb, ws, shape, depth):
     ray_diff, mask, d_rgb = _c(ray_diff, 'ray_diff'), _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
     d_rgb_feat = torch.empty(R, S, V, 35, dtype=torch.float32, device=d_rgb.device)
     with prof.launch('nf_gnt_bwd', d_rgb, R=R, S=S, V=V, depth=depth):
-        _lib.check(_lib.lib().nf_gnt_bwd(_ptr(blob), _ptr(ray_diff), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat),
+        _done(_lib.lib().nf_gnt_bwd(_ptr(blob), _ptr(ray_diff), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat),
                                          _ptr(ws), _stream(d_rgb)), 'nf_gnt_bwd')
     return d_rgb_feat

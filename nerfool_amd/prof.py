@@ -49,8 +49,9 @@ def launch(name, tensor, **meta):
         return
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
-    a.record()
+    stream = torch.cuda.current_stream(tensor.device)      # the tensor's device, which need not be the current one
+    a.record(stream)
     yield
-    b.record()
+    b.record(stream)
     _active.pairs[name].append((a, b))
     _active.meta[name].append(meta)

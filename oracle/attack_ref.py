@@ -157,3 +157,47 @@ def relu_pattern_flips(trace64, masks):
             worst = max(worst, float((pre.abs() / rms)[diff].max()))
             n_flip += k
     return n_flip, n_all, worst
+
+
+def unseen_camera_stream(args, render_poses, camera, n_steps, seed):
+    """The target cameras the reference's universal loop visits under --use_unseen_views (eval/ibrnet/eval_adv.py:652-691):
+    per step, from numpy's global generator in this order -- three distinct render-pose indices (softmax of the poses' forward
+    z over args.temp as probabilities with args.sample_based_on_depth :655-661), then the interpolation parameters (decoupled:
+    two uniforms for rotation, two for translation :668-672; depth-based: two Beta(beta, beta) draws scaled by
+    interp_upbound_rot :676; else two uniforms in [0, interp_upbound] :678) -- then interp3 (eval/ibrnet/geo_interp.py:44-45;
+    pinned by tests/golden/metrics_r03.npz) replaces elements 18..33 of the [1,34] camera.  -> list of [1,34] tensors."""
+    import numpy as np
+    from scipy.spatial.transform import Rotation
+
+    def slerp(p0, p1, t):
+        omega = np.arccos(np.dot(p0 / np.linalg.norm(p0), p1 / np.linalg.norm(p1)))
+        return np.sin((1.0 - t) * omega) / np.sin(omega) * p0 + np.sin(t * omega) / np.sin(omega) * p1
+
+    def interp(a, b, s):
+        s_rot, s_trans = (s[0], s[1]) if type(s) == list else (s, s)
+        m = np.eye(4)
+        m[:3, 3] = (1 - s_trans) * a[:-1, -1] + s_trans * b[:-1, -1]
+        m[:3, :3] = Rotation.from_quat(slerp(Rotation.from_matrix(a[:3, :3]).as_quat(), Rotation.from_matrix(b[:3, :3]).as_quat(),
+                                             s_rot)).as_matrix()
+        return m
+
+    rs = np.random.RandomState(seed)
+    poses = [np.asarray(p, dtype=np.float64) for p in render_poses]
+    out = []
+    for _ in range(n_steps):
+        if getattr(args, 'sample_based_on_depth', False):
+            z = np.array([p[2, 2] for p in poses])
+            ids = rs.choice(len(poses), size=3, p=np.exp(z / args.temp) / np.sum(np.exp(z / args.temp)), replace=False)
+        else:
+            ids = rs.choice(len(poses), size=3, replace=False)
+        if getattr(args, 'decouple_interp_range', False):
+            s12_rot, s3_rot = rs.uniform(0, args.interp_upbound_rot, size=2)
+            s12_trans, s3_trans = rs.uniform(0, args.interp_upbound_trans, size=2)
+            s12, s3 = [s12_rot, s12_trans], [s3_rot, s3_trans]
+        elif getattr(args, 'sample_based_on_depth', False):
+            s12, s3 = rs.beta(args.beta, args.beta, size=2) * args.interp_upbound_rot
+        else:
+            s12, s3 = rs.uniform(0, args.interp_upbound, size=2)
+        pose = torch.from_numpy(interp(interp(poses[ids[0]], poses[ids[1]], s12), poses[ids[2]], s3))
+        out.append(torch.cat([camera[:, :18], pose.flatten().unsqueeze(0).to(camera)], dim=1))
+    return out

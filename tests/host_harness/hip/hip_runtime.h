@@ -6,9 +6,11 @@
 // through the same C ABI.  It is never loaded by the product (nerfool_amd/_lib.py refuses to run without the real
 // gfx950 library) and implements only what those sources use.
 //
-// Execution model: blocks run one after another; the threads of a block are real OS threads; __syncthreads() and the
-// wave-collective operations (__shfl*, MFMA) are barriers over the block / over the 64 consecutive threads of a wave.
-// Every lane of a wave must therefore reach every collective (true on the GPU for the kernels in this repo as well).
+// Execution model (hip_emu.cpp): the blocks of a launch are dealt to a few OS worker threads; the threads of a block are
+// cooperative fibers on their worker; __syncthreads() and the wave-collective operations (__shfl*, MFMA) are barriers over the
+// live fibers of the block / of the 64 consecutive threads of a wave.  Every live lane of a wave must therefore reach every
+// collective (true on the GPU for the kernels in this repo as well).  __shared__ variables are per worker thread, i.e. per
+// block in flight.
 #pragma once
 
 #include <math.h>
@@ -27,7 +29,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 #define HIP_DYNAMIC_SHARED(type, name) type* name = (type*)hip_emu::dynamic_smem();
 
 struct dim3 {
@@ -50,19 +52,14 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
 
 namespace hip_emu {
-struct Block {
-    pthread_barrier_t all;
-    std::vector<pthread_barrier_t> wave;
-    std::vector<std::vector<uint64_t>> slot;   // per wave, 64 exchange slots
-    std::vector<char> smem;
-};
 extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
-extern thread_local Block* t_block;
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
-inline void* dynamic_smem() { return t_block->smem.data(); }
+void* dynamic_smem();
+uint64_t* wave_slots();          // the 64 exchange slots of the calling fiber's wave
+void wave_barrier();
+void block_barrier();
 inline int lane() { return (int)(t_threadIdx.x & 63); }
 inline int wave() { return (int)(t_threadIdx.x >> 6); }
-inline void wave_barrier() { pthread_barrier_wait(&t_block->wave[wave()]); }
 
 // every lane publishes `v`, then reads the value of lane `src` (own value when src is out of range)
 template <typename T>
@@ -70,7 +67,7 @@ inline T exchange(T v, int src) {
     static_assert(sizeof(T) <= 8, "exchange");
     uint64_t raw = 0;
     memcpy(&raw, &v, sizeof(T));
-    auto& sl = t_block->slot[wave()];
+    uint64_t* sl = wave_slots();
     sl[lane()] = raw;
     wave_barrier();
     uint64_t got = (src >= 0 && src < 64) ? sl[src] : raw;
@@ -86,7 +83,7 @@ inline T exchange(T v, int src) {
 #define blockDim hip_emu::t_blockDim
 #define gridDim hip_emu::t_gridDim
 
-static inline void __syncthreads() { pthread_barrier_wait(&hip_emu::t_block->all); }
+static inline void __syncthreads() { hip_emu::block_barrier(); }
 
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hip_emu::exchange(v, hip_emu::lane() ^ mask); }
@@ -141,7 +138,7 @@ typedef float nf_emu_f32x4 __attribute__((ext_vector_type(4)));
 // c[r] of lane l = C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].  k-ordered fmaf chain.
 // all lanes publish (a, b) once; two wave barriers per MFMA
 static inline void nf_emu_publish_ab(float a, float b, float* A, float* B) {
-    auto& sl = hip_emu::t_block->slot[hip_emu::wave()];
+    uint64_t* sl = hip_emu::wave_slots();
     uint64_t raw = 0;
     float ab[2] = {a, b};
     memcpy(&raw, ab, 8);

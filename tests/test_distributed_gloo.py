@@ -21,6 +21,9 @@ import numpy as np, torch
 import torch.distributed as dist
 from nerfool_amd import _lib
 _lib.use_library_for_tests(os.path.join(%(harness)r, 'libnerfool_emu.so'))
+from nerfool_amd.ibrnet import mlp_network, feature_network
+mlp_network.KERNEL_PATH = 'generic'          # the shape-generic kernels emulate ~30x faster than the MFMA ones; the sharding
+feature_network.CNN_PATH = 'torch'           # logic under test is the same
 import parity_cases as pc
 from nerfool_amd import eval_adv as EA
 from nerfool_amd.ibrnet.projection import Projector
@@ -71,9 +74,7 @@ def _run_world(script, env, world, shard_views, draw=False):
 @pytest.mark.timeout(2400)
 def test_sharded_step_equals_single_process(tmp_path):
     script = _build_and_script(tmp_path)
-    # the shape-generic kernels emulate ~30x faster than the MFMA ones; the sharding logic under test is the same
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', OMP_NUM_THREADS='2',
-               NERFOOL_IBRNET_KERNELS='generic', NERFOOL_CNN='torch')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29531', OMP_NUM_THREADS='2')
     _run_world(script, env, 1, False)
     ref = np.load(tmp_path / 'rank0_of_1_0.npz')
     scale = np.abs(ref['grad']).max()
@@ -111,7 +112,9 @@ sys.path.insert(0, %(root)r)
 import numpy as np, torch
 import torch.distributed as dist
 from nerfool_amd import eval_adv as EA
+from nerfool_amd.ibrnet import feature_network
 from nerfool_amd.ibrnet.feature_network import ResUNet
+feature_network.CNN_PATH = 'torch'
 
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -152,6 +155,130 @@ def test_view_sharded_feature_maps_with_idle_rank(tmp_path):
     """world 3 over V = 2 source views: rank 2 owns no view but takes part in both exchanges (torch CNN path, no kernels)."""
     script = tmp_path / 'view_worker.py'
     script.write_text(VIEW_WORKER % dict(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', OMP_NUM_THREADS='2', NERFOOL_CNN='torch')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', OMP_NUM_THREADS='2')
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), WORLD_SIZE='3')) for r in range(3)]
     assert all(p.wait() == 0 for p in procs)
+
+
+RENDER_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+from types import SimpleNamespace
+import numpy as np, torch
+import torch.distributed as dist
+from nerfool_amd import _lib
+_lib.use_library_for_tests(os.path.join(%(harness)r, 'libnerfool_emu.so'))
+from nerfool_amd.ibrnet import mlp_network, feature_network
+mlp_network.KERNEL_PATH = 'generic'          # the matrix-core kernels emulate ~30x slower; the sharding under test is the same
+feature_network.CNN_PATH = 'torch'
+import parity_cases as pc
+from nerfool_amd import eval_adv as EA
+from nerfool_amd.ibrnet.projection import Projector
+from nerfool_amd.ibrnet.render_image import render_single_image, chunk_block
+from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
+
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+if world > 1:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+torch.set_num_threads(2)
+shard = EA.RayShard(shard_views=False) if world > 1 else None
+out = {}
+
+# ---- IBRNet flavour: the first 6 rows of the attack fixture's image (384 rays), coarse + fine
+g, args, model, data, sampler, dims = pc._attack_setup('cpu')
+H, W, S, N_imp = dims[0], dims[1], dims[4], dims[5]
+src = sampler.get_all()
+with torch.no_grad():
+    featmaps = model.feature_net((src['src_rgbs'] + g.t('in/delta0')).squeeze(0).permute(0, 3, 1, 2))
+rows = 6
+rb = {k: (v[:rows * W] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in src.items()}
+# chunk sizes: 50 -> 8 chunks, the last one ragged (34 rays); 200 -> 2 chunks, fewer than 3 ranks (rank 2 renders nothing and
+# learns the record layout from rank 0)
+for chunk in (50, 200):
+    for to in ((0, None) if chunk == 50 else (0,)):
+        if shard is not None:
+            shard.gather_render_to = to
+            before = shard.collectives
+        ret = render_single_image(ray_sampler=SimpleNamespace(H=rows, W=W), ray_batch=rb, model=model, projector=Projector('cpu'),
+                                  chunk_size=chunk, det=True, N_samples=S, inv_uniform=True, N_importance=N_imp, white_bkgd=False,
+                                  featmaps=featmaps, args=None, src_ray_batch=src, shard=shard)
+        if shard is not None:
+            n_chunks = -(-rows * W // chunk)
+            # ONE collective per image (+ the record-layout broadcast when a rank had no chunk)
+            assert shard.collectives - before == 1, shard.collectives - before
+            if to == 0 and rank != 0:
+                assert ret is None
+                continue
+        for level in ('outputs_coarse', 'outputs_fine'):
+            for k, v in ret[level].items():
+                out['ibr/%%d/%%s/%%s/%%s' %% (chunk, 'all' if to is None else 'r0', level, k)] = v.numpy()
+
+# ---- GNT flavour (no compositing stage; weights / depth stay None without ret_alpha)
+from nerfool_amd.gnt.model import GNTModel
+from nerfool_amd.gnt.render_image import render_single_image as gnt_render_single_image
+from nerfool_amd.synthetic import make_scene
+torch.manual_seed(0)
+for ret_alpha in (False, True):
+    gargs = SimpleNamespace(netwidth=64, trans_depth=2, single_net=True, ret_alpha=ret_alpha, coarse_feat_dim=32, fine_feat_dim=32,
+                            N_rand=16, N_samples=8, N_importance=0, inv_uniform=True, det=True, white_bkgd=False, chunk_size=512,
+                            ckpt_path=None)
+    torch.manual_seed(3)
+    gmodel = GNTModel(gargs, device='cpu')
+    gmodel.switch_to_eval()
+    gdata = make_scene(24, 32, 3, seed=21, tilt=0.3)
+    gs = RaySamplerSingleImage(gdata, 'cpu')
+    grb = gs.get_all()
+    with torch.no_grad():
+        fm = gmodel.feature_net(grb['src_rgbs'].squeeze(0).permute(0, 3, 1, 2))
+    grb = {k: (v[:8 * 32] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in grb.items()}       # the first 8 image rows
+    gs = SimpleNamespace(H=8, W=32)
+    if shard is not None:
+        shard.gather_render_to = 0
+    ret = gnt_render_single_image(ray_sampler=gs, ray_batch=grb, model=gmodel, projector=Projector('cpu'), chunk_size=60, N_samples=8,
+                                  inv_uniform=True, det=True, N_importance=0, white_bkgd=False, featmaps=fm, ret_alpha=ret_alpha,
+                                  single_net=True, shard=shard)
+    if rank == 0:
+        assert ret['outputs_fine'] is None
+        for k, v in ret['outputs_coarse'].items():
+            assert (v is None) == (k != 'rgb' and not ret_alpha)
+            if v is not None:
+                out['gnt/%%d/%%s' %% (ret_alpha, k)] = v.numpy()
+    else:
+        assert ret is None
+assert chunk_block(8, 0, 3) == (0, 3) and chunk_block(8, 1, 3) == (3, 6) and chunk_block(8, 2, 3) == (6, 8)
+assert chunk_block(2, 2, 3) == (2, 2)
+np.savez(os.path.join(%(out)r, 'render_rank%%d_of_%%d.npz' %% (rank, world)), **out)
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(2400)
+def test_sharded_render_equals_single_process_bit_for_bit(tmp_path):
+    """render_single_image(shard=RayShard) -- SURVEY 8e "contiguous ray ranges per rank, gather to rank 0": world 2 and world 3
+    (ragged chunk count, a ragged last chunk, a rank without any chunk), gather to rank 0 and all-gather, both flavours: every
+    field of both levels equals the single-process image bit for bit, one collective per image."""
+    _build_and_script(tmp_path)
+    script = tmp_path / 'render_worker.py'
+    script.write_text(RENDER_WORKER % dict(root=ROOT, harness=HARNESS, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    port = 29561
+    for world in (1, 2, 3):
+        port += 1
+        procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world)))
+                 for r in range(world)]
+        assert all(p.wait() == 0 for p in procs)
+    ref = np.load(tmp_path / 'render_rank0_of_1.npz')
+    assert any(k.startswith('gnt/1/weights') for k in ref.files) and any(k.startswith('ibr/50/all/') for k in ref.files)
+    for world in (2, 3):
+        got = np.load(tmp_path / ('render_rank0_of_%d.npz' % world))
+        assert set(got.files) == set(ref.files)
+        for k in ref.files:
+            assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape, k
+            assert np.array_equal(got[k], ref[k]), 'world %d: %s differs from the single-process render' % (world, k)
+        # the all-gather form delivers the same image to the other ranks too
+        other = np.load(tmp_path / ('render_rank%d_of_%d.npz' % (world - 1, world)))
+        keys = [k for k in ref.files if k.startswith('ibr/50/all/')]
+        assert keys and set(other.files) == set(keys)
+        for k in keys:
+            assert np.array_equal(other[k], ref[k]), k

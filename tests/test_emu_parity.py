@@ -1,6 +1,7 @@
 """CPU: the kernel SOURCES of nerfool_amd/csrc compiled through the HIP stand-in (tests/host_harness) and driven through
 the same C ABI and the same host layer as on the GPU.  Catches indexing / layout / math errors without a GPU; the
 authoritative parity run is tests/test_gpu_parity.py on the MI355X."""
+import contextlib
 import os
 import subprocess
 
@@ -23,14 +24,23 @@ def emulated_library():
     from nerfool_amd.ibrnet import mlp_network
     saved = (_lib._lib, _lib._emulated, mlp_network.KERNEL_PATH)
     _lib.use_library_for_tests(os.path.join(HARNESS, 'libnerfool_emu.so'))
-    # emulating the matrix-core kernels costs ~30x the generic ones: the end-to-end cases below run on the generic
-    # kernels, the MFMA kernels have their own (small) cases at the end of this file
-    mlp_network.KERNEL_PATH = 'generic'
-    from nerfool_amd.ibrnet import feature_network
-    saved_cnn, feature_network.CNN_PATH = feature_network.CNN_PATH, 'torch'    # ditto for the fused CNN glue
+    # the product's default dispatch: matrix-core kernels (emulated MFMA) and the fused CNN executor, exactly what runs on the GPU
     yield
     _lib._lib, _lib._emulated, mlp_network.KERNEL_PATH = saved
-    feature_network.CNN_PATH = saved_cnn
+
+
+@contextlib.contextmanager
+def fast_paths():
+    """shape-generic IBRNet kernels and the nn.Module CNN graph for the multi-step loops: emulating the matrix-core kernels and
+    the fused executor (and evaluating the float64 oracle their check needs) costs minutes there; one full step on the product's
+    own dispatch is test_attack_step_on_the_product_dispatch, everything else in this file runs on it anyway"""
+    from nerfool_amd.ibrnet import feature_network, mlp_network
+    saved = (mlp_network.KERNEL_PATH, feature_network.CNN_PATH)
+    mlp_network.KERNEL_PATH, feature_network.CNN_PATH = 'generic', 'torch'
+    try:
+        yield
+    finally:
+        mlp_network.KERNEL_PATH, feature_network.CNN_PATH = saved
 
 
 @pytest.mark.parametrize('case', TINY)
@@ -69,10 +79,6 @@ def test_pad_glue():
     pc.check_pad_glue('cpu')
 
 
-def test_conv3x3_wino4():
-    pc.check_conv3x3_wino4('cpu', shapes=((1, 8, 32, 18, 34), (1, 20, 40, 9, 13)))
-
-
 def test_gather_bwd_deterministic():
     pc.check_gather_bwd_deterministic('cpu')
 
@@ -86,24 +92,33 @@ def test_init_perturb():
 
 
 def test_attack_steps():
-    pc.check_attack_steps('cpu', free_steps=2)
+    with fast_paths():
+        pc.check_attack_steps('cpu', free_steps=2)
+
+
+def test_attack_step_on_the_product_dispatch():
+    """one teacher-forced PGD step through exactly what runs on the GPU -- fused CNN executor, matrix-core IBRNet kernels with
+    the scatter fused into the backward -- with the float64 check on the ReLU pattern of this evaluation"""
+    pc.check_attack_steps('cpu', free_steps=0, forced_steps=1)
 
 
 def test_pseudo_gt():
-    pc.check_pseudo_gt('cpu')
+    with fast_paths():
+        pc.check_pseudo_gt('cpu')
+
+
+def test_unseen_views():
+    with fast_paths():
+        pc.check_unseen_views('cpu')
 
 
 def test_universal_trajectory():
-    pc.check_universal_trajectory('cpu', steps=2)      # both target views once; the full loop runs on the GPU
+    with fast_paths():
+        pc.check_universal_trajectory('cpu', steps=2)      # both target views once; the full loop runs on the GPU
 
 
 def test_gather_fused_forward():
-    from nerfool_amd.ibrnet import mlp_network
-    mlp_network.KERNEL_PATH = 'auto'          # the gather-fused forward belongs to the matrix-core kernels
-    try:
-        pc.check_gather_fused_forward('cpu', shapes=((3, 32, 4),))
-    finally:
-        mlp_network.KERNEL_PATH = 'generic'
+    pc.check_gather_fused_forward('cpu', shapes=((3, 32, 4),))
 
 
 def test_ragged_ray_batches():
@@ -152,14 +167,11 @@ def test_mfma_kernels_match_generic_kernels():
         assert float((ga - gb).abs().max()) <= 1e-4 * max(1.0, float(ga.abs().max()))
 
 
-def test_render_rays_through_mfma_kernels():
-    """end-to-end render_rays + loss + gradients with the matrix-core kernels selected (V = 4 case)."""
-    from nerfool_amd.ibrnet import mlp_network
-    mlp_network.KERNEL_PATH = 'auto'
-    try:
-        pc.check_render_rays('ibrnet_tiny_invu', 'cpu')       # default: stand-alone gather, scatter fused into the backward
-    finally:
-        mlp_network.KERNEL_PATH = 'generic'
+def test_render_rays_through_generic_kernels():
+    """end-to-end render_rays + loss + gradients with the shape-generic kernels forced (the default dispatch above took the
+    matrix-core ones for this V = 4 case)."""
+    with fast_paths():
+        pc.check_render_rays('ibrnet_tiny_invu', 'cpu')
 
 
 def test_gnt_matrix_core_forward_matches_generic():

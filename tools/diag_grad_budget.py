@@ -83,7 +83,6 @@ def main():
     table = {}
     variants = [('product path', {})]
     variants += [('nn.Module graph (ATen + MIOpen)', {'cnn': 'torch'}),
-                 ('fused CNN, MIOpen 3x3', {'conv3x3': 'miopen'}),
                  ('fused CNN, Winograd 3x3 forced', {'conv3x3': 'wino'}),
                  ('generic IBRNet kernels', {'ibr': 'generic'})]
     for case in cases:

@@ -17,6 +17,7 @@
 // registers one k-step ahead (a lane needs exactly one dword per product).  fp32 error of F(4x4): 2-4e-6 of full scale (F(2x2): 2e-7) -- inside every tolerance of the parity tests;
 // chosen per layer shape against the F(2x2) kernel by the executor's one-off timing.
 #include "nf_common.h"
+#include "nf_wino4.h"
 
 typedef float q16 __attribute__((ext_vector_type(16)));
 typedef float q2a __attribute__((ext_vector_type(2)));                    // 8-byte aligned LDS pair

@@ -5,7 +5,7 @@ OUT=$REPO/gpurun_out/pmc_render
 mkdir -p $OUT
 for mode in fused separate; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    NERFOOL_GATHER_FUSION=$mode rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${mode}_$c -o p -- python3 $REPO/tools/render_chunks.py 8 > /dev/null 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${mode}_$c -o p -- python3 $REPO/tools/render_chunks.py 8 $mode > /dev/null 2>&1
   done
 done
 python3 - <<'PY' > $REPO/gpurun_out/pmc_render.txt

@@ -1,6 +1,6 @@
 """Forward-only rendering of 4096-ray chunks (800x800, V = 4, 64 samples coarse only) -- the program profiled with rocprofv3 --pmc
-for the HBM traffic of the render path with and without the gather fused into the row kernel (NERFOOL_GATHER_FUSION).
-usage: python tools/render_chunks.py [chunks]"""
+for the HBM traffic of the render path with and without the gather fused into the row kernel.
+usage: python tools/render_chunks.py [chunks] [fused|separate]"""
 import argparse
 import os
 import sys
@@ -13,8 +13,10 @@ import bench                                              # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    from nerfool_amd.ibrnet import mlp_network
+    mlp_network.GATHER_BWD_FUSION = sys.argv[2] if len(sys.argv) > 2 else 'fused'
     a = argparse.Namespace(gpus=1, steps=1, warmup=0, n_rand=512, height=800, width=800, views=4, samples=64, importance=0, render_chunks=n,
-                           model='ibrnet', config='c2', precision='fp32', depth=8, cnn_shard='view', scaling='weak', cpu_iters=0, extras=0)
+                           model='ibrnet', config='c2', precision='fp32', depth=8, cnn_shard='replicated', scaling='weak', cpu_iters=0, extras=0)
     dev = torch.device('cuda', 0)
     args, data, model, sampler, src, projector, _ = bench.build_problem(a, dev)
     from nerfool_amd.ibrnet.render_ray import render_rays
