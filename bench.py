@@ -102,6 +102,8 @@ def parse():
                     help='N > 1: --n-rand rays per rank (weak) or split over the ranks (strong)')
     ap.add_argument('--cpu-iters', type=int, default=10, help='timed CPU-oracle PGD iterations for cpu_baseline after 2 warm-ups (0 = skip)')
     ap.add_argument('--extras', type=int, default=1, help='0 = only the headline timed region (profiling runs)')
+    ap.add_argument('--event-every', type=int, default=4,
+                    help='HIP-event brackets around the roofline kernels on every N-th timed step (1 = every step, 0 = never)')
     return ap.parse_args()
 
 
@@ -219,18 +221,22 @@ def cpu_baseline(a, args, data, model):
             'attack_s_per_iter': dt, 'render_rays_per_s': 4096 / rdt}
 
 
-def time_steps(attack, data, steps, warmup, barrier, timer_ctx=None):
-    """`warmup` untimed + exactly `steps` timed PGD steps between barrier + synchronize brackets -> seconds (this rank)"""
+def time_steps(attack, data, steps, warmup, barrier, timer=None, every=1):
+    """`warmup` untimed + exactly `steps` timed PGD steps between barrier + synchronize brackets -> seconds (this rank).
+    timer: a prof.KernelTimer whose HIP-event brackets are live on every `every`-th timed step (steps 0, every, 2 every, ...): an
+    event record is a marker packet that costs the GPU ~5.6 us before and after the bracketed launch (profiles/r02_step_timeline.txt:
+    every gap of the step sits next to a bracketed kernel), ~0.7 ms per step with the ~65 bracketed launches of a step -- sampling
+    the steps keeps the per-launch durations live and inside the timed region without putting that cost on every step."""
+    from nerfool_amd import prof
     for _ in range(warmup):
         attack.step(data)
     barrier()
     t0 = time.perf_counter()
-    if timer_ctx is not None:
-        with timer_ctx:
-            for _ in range(steps):
+    for i in range(steps):
+        if timer is not None and every > 0 and i % every == 0:
+            with prof.timing(timer):
                 attack.step(data)
-    else:
-        for _ in range(steps):
+        else:
             attack.step(data)
     barrier()
     return time.perf_counter() - t0
@@ -362,7 +368,8 @@ def main():
     # HIP events only around the kernels the roofline table prices (~10 of the ~250 launches of a step): bracketing every
     # launch costs ~1.5 ms of host time per step, which is visible now that the step is close to launch-bound
     timer = prof.KernelTimer(only=ROOFLINE_KERNELS)
-    elapsed = max_over_ranks(time_steps(attack, data, a.steps, a.warmup, barrier, prof.timing(timer)))
+    elapsed = max_over_ranks(time_steps(attack, data, a.steps, a.warmup, barrier, timer, a.event_every))
+    timed_steps = len(range(0, a.steps, a.event_every)) if a.event_every > 0 else 0
     kernels = timer.summary()
     final_loss = float(attack.last_loss)
     rays_per_step = a.n_rand * (world if a.scaling == 'weak' else 1)
@@ -565,6 +572,9 @@ def main():
                    'rays_per_step_all_ranks': rays_per_step, 'parallelism': par,
                    'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step},
         'roofline': roofline,
+        'roofline_sampling': {'steps_with_hip_events': timed_steps, 'of_timed_steps': a.steps, 'every': a.event_every,
+                              'note': 'per-launch durations from HIP events on the launch stream, live inside the timed region on every '
+                                      'N-th step (an event pair costs the GPU ~11 us around the launch it brackets)'},
         'cpu_baseline': None,
         'extra': {'attack_s_per_1000_iters': ms_step, 'final_loss': final_loss, 'kernels': table, 'whole_step': whole,
                   'hand_written_kernel_ms_per_step': None if hand_written_ms is None else round(hand_written_ms, 4),

@@ -51,3 +51,58 @@ __device__ __forceinline__ float nf_wave_max(float v) {
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, NF_WAVE));
     return v;
 }
+
+// ---- partner-lane exchange without the LDS crossbar ---------------------------------------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt: an LDS round trip (~100+ cycles) per butterfly step, and the wait
+// also drains every A-operand read queued behind it.  Inside a row of 16 lanes the data-parallel-primitive modifiers do the same
+// exchange in the adding instruction itself (v_add_f32_dpp: one VALU slot, no memory latency); the two wave halves swap through
+// gfx950's v_permlane32_swap.
+template <int CTRL>
+__device__ __forceinline__ float nf_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+#define NF_DPP_XOR1 0xB1           // quad_perm:[1,0,3,2]
+#define NF_DPP_XOR2 0x4E           // quad_perm:[2,3,0,1]
+#define NF_DPP_HALF_MIRROR 0x141   // lane i <-> 7 - i of its group of 8
+#define NF_DPP_MIRROR 0x140        // lane i <-> 15 - i of its row of 16
+
+// butterfly reduction over groups of V adjacent lanes (V a power of two <= 32); every lane gets the result.  Steps 4 and 8 use
+// the mirror patterns: after the quad steps all lanes of a quad (of a group of 8) hold the same partial, so "7 - i" / "15 - i"
+// delivers the same value as "i ^ 4" / "i ^ 8" -- the result is bit-identical to the xor butterfly.
+struct NfAdd { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct NfMin { __device__ __forceinline__ float operator()(float a, float b) const { return fminf(a, b); } };
+struct NfMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+template <int V, typename Op>
+__device__ __forceinline__ float nf_grp_reduce(float x, Op op) {
+    if (V >= 2) x = op(x, nf_dpp<NF_DPP_XOR1>(x));
+    if (V >= 4) x = op(x, nf_dpp<NF_DPP_XOR2>(x));
+    if (V >= 8) x = op(x, nf_dpp<NF_DPP_HALF_MIRROR>(x));
+    if (V >= 16) x = op(x, nf_dpp<NF_DPP_MIRROR>(x));
+    if (V >= 32) x = op(x, __shfl_xor(x, 16, NF_WAVE));
+    return x;
+}
+// v_permlane32_swap vdst, src: lanes 32-63 of vdst swap with lanes 0-31 of src.  With both operands = x the results are
+// (x of the low half in every lane, x of the high half in every lane).  (Take the results through a NAMED vector type and .x / .y:
+// with `auto r` + r[1] this hipcc reads element 0 twice.)
+typedef unsigned nf_u32x2 __attribute__((ext_vector_type(2)));
+struct NfHalves { float lo, hi; };
+__device__ __forceinline__ NfHalves nf_halves(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const nf_u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return NfHalves{__builtin_bit_cast(float, (unsigned)r.x), __builtin_bit_cast(float, (unsigned)r.y)};
+}
+// x(lane ^ 32)
+__device__ __forceinline__ float nf_half_other(float x) {
+    const NfHalves v = nf_halves(x);
+    return (threadIdx.x & 32) ? v.lo : v.hi;
+}
+// max(x(lane), x(lane ^ 32))
+__device__ __forceinline__ float nf_half_max(float x) {
+    const NfHalves v = nf_halves(x);
+    return fmaxf(v.lo, v.hi);
+}
+// x(lane) + x(lane ^ 32)
+__device__ __forceinline__ float nf_half_sum(float x) {
+    const NfHalves v = nf_halves(x);
+    return v.lo + v.hi;
+}

@@ -250,8 +250,9 @@ __device__ __forceinline__ g16 gm_tile(const float* __restrict__ tb, int h) {   
     for (int r = 0; r < 16; ++r) a[r] = b[r];
     return a;
 }
-__device__ __forceinline__ float gm_half_sum(float x) { return x + __shfl_xor(x, 32, NF_WAVE); }
-__device__ __forceinline__ float gm_half_max(float x) { return fmaxf(x, __shfl_xor(x, 32, NF_WAVE)); }
+// the two lane halves swap through v_permlane32_swap (nf_common.h): no LDS round trip
+__device__ __forceinline__ float gm_half_sum(float x) { return nf_half_sum(x); }
+__device__ __forceinline__ float gm_half_max(float x) { return nf_half_max(x); }
 
 // acc += sum over NSTEPS k-steps: records at rec (global, L2), B operand = x[r]
 // makes a (wave-uniform) pointer opaque to the optimiser: without it the loop-invariant record loads of the view loop --

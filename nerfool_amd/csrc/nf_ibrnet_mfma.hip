@@ -382,25 +382,15 @@ __device__ __forceinline__ float mf_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float mf_elu(float x) { return x > 0.f ? x : mf_exp(x) - 1.f; }
 __device__ __forceinline__ float mf_sigmoid(float x) { return 1.f / (1.f + mf_exp(-x)); }
 
+// cross-view reductions of a sample: butterflies over its V adjacent lanes, as DPP modifiers of the combining instruction
+// (nf_common.h) -- ~170 of them per 32-row tile, formerly as many LDS round trips
 template <int V>
-__device__ __forceinline__ float grp_sum(float x) {
-#pragma unroll
-    for (int m = 1; m < V; m <<= 1) x += __shfl_xor(x, m, NF_WAVE);
-    return x;
-}
+__device__ __forceinline__ float grp_sum(float x) { return nf_grp_reduce<V>(x, NfAdd()); }
 template <int V>
-__device__ __forceinline__ float grp_min(float x) {
-#pragma unroll
-    for (int m = 1; m < V; m <<= 1) x = fminf(x, __shfl_xor(x, m, NF_WAVE));
-    return x;
-}
+__device__ __forceinline__ float grp_min(float x) { return nf_grp_reduce<V>(x, NfMin()); }
 template <int V>
-__device__ __forceinline__ float grp_max(float x) {
-#pragma unroll
-    for (int m = 1; m < V; m <<= 1) x = fmaxf(x, __shfl_xor(x, m, NF_WAVE));
-    return x;
-}
-__device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32, NF_WAVE); }
+__device__ __forceinline__ float grp_max(float x) { return nf_grp_reduce<V>(x, NfMax()); }
+__device__ __forceinline__ float half_sum(float x) { return nf_half_sum(x); }
 
 __device__ __forceinline__ f32x16 bias_tile(const float* lds, int tile, int h) {
     f32x16 a;
@@ -870,8 +860,7 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
     //      rows 0-3 and 8 sit in the low lane half (registers 0-3, 4), rows 4-7 in the high half (registers 0-3)
     {
         float lo0 = g_col[0], lo1 = g_col[1], lo2 = g_col[2], lo3 = g_col[3], lo4 = g_col[4];
-        float o0 = __shfl_xor(lo0, 32, NF_WAVE), o1 = __shfl_xor(lo1, 32, NF_WAVE), o2 = __shfl_xor(lo2, 32, NF_WAVE),
-              o3 = __shfl_xor(lo3, 32, NF_WAVE), o4 = __shfl_xor(lo4, 32, NF_WAVE);
+        float o0 = nf_half_other(lo0), o1 = nf_half_other(lo1), o2 = nf_half_other(lo2), o3 = nf_half_other(lo3), o4 = nf_half_other(lo4);
         // value of tile row i for this (row, either half): low half owns rows {0,1,2,3,8}, high half rows {4,5,6,7}
         float row0 = h ? o0 : lo0, row1 = h ? o1 : lo1, row2 = h ? o2 : lo2, row3 = h ? o3 : lo3, row8 = h ? o4 : lo4;
         float row4 = h ? lo0 : o0, row5 = h ? lo1 : o1, row6 = h ? lo2 : o2, row7 = h ? lo3 : o3;

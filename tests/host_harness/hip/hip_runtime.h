@@ -17,6 +17,7 @@
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -93,6 +94,28 @@ template <typename T>
 static inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; int s = hip_emu::lane() + (int)d; return hip_emu::exchange(v, s > 63 ? hip_emu::lane() : s); }
 template <typename T>
 static inline T __shfl(T v, int src, int width = 64) { (void)width; return hip_emu::exchange(v, src & 63); }
+
+// data-parallel-primitive lane patterns (quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140) and gfx950's
+// v_permlane32_swap, as used by nf_common.h
+static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+    const int l = hip_emu::lane();
+    int from = l;
+    if (ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+    else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+    else { fprintf(stderr, "hip_emu: dpp control 0x%x not emulated\n", ctrl); abort(); }
+    return hip_emu::exchange(src, from);
+}
+struct nf_emu_u32x2 {
+    unsigned x, y;
+};
+// vdst[32:63] <-> vsrc[0:31]; returns (vdst', vsrc')
+static inline nf_emu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+    const int l = hip_emu::lane();
+    const unsigned a_from = hip_emu::exchange(b, l - 32 < 0 ? l : l - 32);      // upper lanes of a' take b's lower half
+    const unsigned b_from = hip_emu::exchange(a, l + 32 > 63 ? l : l + 32);      // lower lanes of b' take a's upper half
+    return nf_emu_u32x2{l >= 32 ? a_from : a, l < 32 ? b_from : b};
+}
 
 static inline float atomicAdd(float* addr, float val) {
     uint32_t* p = (uint32_t*)addr;

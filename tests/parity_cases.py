@@ -1193,6 +1193,63 @@ def check_bf16_config5(dev):
         assert err <= 1.5e-1
 
 
+def check_bf16_attack(dev):
+    """The ATTACK with args.ibrnet_precision = 'bf16' (BASELINE config 5 names a universal attack on the bf16 path): PGD steps of the
+    view-specific loop and the reference's universal loop over two target views, teacher-forced from the reference's fp32 captures
+    (attack_tiny.npz, attack_extra.npz).  STATED TOLERANCES of the bf16 path, as in check_bf16_config5: loss within 3e-2 relative of
+    the reference's; d loss / d delta within 1.5e-1 relative L2 of the reference's fp32 gradient and pointing the same way (cosine
+    >= 0.985) -- the update only uses the Adam-normalised gradient / its sign; the fused update itself is fp32 and must reproduce
+    torch-Adam on the bf16 path's OWN gradient to 2e-7.  Achieved numbers are printed."""
+    from fixtures import second_target_view
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    gx = Golden('attack_extra')
+    for net in (model.net_coarse, model.net_fine):
+        net.precision = 'bf16'
+    src = sampler.get_all()
+    eps = args.epsilon / 255.0
+
+    def compare(tag, grad, ref_grad, loss, ref_loss):
+        a, b = grad.detach().cpu().double().reshape(-1), torch.as_tensor(ref_grad).double().reshape(-1)
+        rel = float((a - b).norm() / b.norm())
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        lerr = abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))
+        print('[bf16 attack] %s: loss rel err %.2e | d loss / d delta vs the reference fp32: rel-L2 %.3e, cosine %.5f' % (tag, lerr, rel, cos))
+        assert lerr <= 3e-2, tag
+        assert rel <= 1.5e-1 and cos >= 0.985, tag
+
+    # view-specific loop: three teacher-forced Adam steps + the update on the path's own gradient
+    deltas = [g.t('in/delta0', dev)] + [g.t('adam/delta_%d' % i, dev) for i in (1, 2, 3)]
+    picks = g.np('adam/selected_inds')
+    attack = EA.PGDAttack(args, model, Projector(dev), src, delta=deltas[0].clone().requires_grad_(True))
+    assert attack.model.net_coarse.precision == 'bf16'
+    opt = atk.AdamAscent(deltas[0].shape, args.adam_lr, args.lr_step_size, args.lr_gamma)
+    for t in range(3):
+        attack.delta.data.copy_(deltas[t])
+        grad = attack.gradient(data, select_inds=picks[t], lookahead=False).clone()
+        compare('view-specific iter %d' % t, grad, g.np('adam/grad_iter%d' % t), attack.last_loss, g.np('adam/losses')[t])
+        want = atk.project(opt.step(deltas[t].cpu(), grad.cpu()), data['src_rgbs'], eps)
+        attack.apply(grad)
+        assert_close(attack.delta.data, want, 0, 2e-7, 'bf16 path: delta after the fused Adam step %d' % (t + 1))
+    # universal loop (eval_adv.py:634-740) over two target views: teacher-forced steps, then the free-running loop's invariants
+    views = [data, second_target_view(data)]
+    n_steps = int(gx.np('universal/cfg')[1])
+    upicks = gx.np('universal/selected_inds')
+    udeltas = [g.t('in/delta0', dev)] + [gx.t('universal/delta_%d' % (t + 1), dev) for t in range(n_steps)]
+    uni = EA.PGDAttack(args, model, Projector(dev), src, delta=udeltas[0].clone().requires_grad_(True))
+    for t in range(min(3, n_steps)):
+        uni.delta.data.copy_(udeltas[t])
+        grad = uni.gradient(views[t % 2], select_inds=upicks[t], lookahead=False)
+        compare('universal step %d' % t, grad, gx.np('universal/grad_%d' % t), uni.last_loss, gx.np('universal/losses')[t])
+    product_sample_ray.rng.seed(234)
+    free = EA.PGDAttack(args, model, Projector(dev), src, delta=g.t('in/delta0', dev).clone().requires_grad_(True))
+    free.run_universal(views, n_iters=2)
+    assert free.iters == 3
+    d = free.delta.detach()
+    assert float(d.abs().max()) <= eps + 1e-7
+    x = src['src_rgbs'] + d
+    assert float(x.min()) >= -1e-7 and float(x.max()) <= 1 + 1e-7
+
+
 def check_conv_s2(dev, shapes=None):
     """csrc/nf_conv_s2.hip (the stride-2 7x7 stem and 3x3 convolutions on pre-padded input, forward and backward-data) against
     a float64 CPU convolution: ragged sizes, odd remainders (rows / columns the convolution never reads must get zero

@@ -32,12 +32,41 @@ rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 if world > 1:
     dist.init_process_group('gloo', rank=rank, world_size=world)
 torch.set_num_threads(2)
-g, args, model, data, sampler, dims = pc._attack_setup('cpu')
-src = sampler.get_all()
-picks = g.np('adam/selected_inds')[0]
+mode = os.environ.get('MODE', 'ibrnet')
 draw = os.environ.get('DRAW') == '1'        # the step draws its own pixels: args.N_rand is the GLOBAL batch (split_n_rand)
 shard = EA.RayShard(shard_views=os.environ['SHARD_VIEWS'] == '1', split_n_rand=draw) if world > 1 else None
-atk = EA.PGDAttack(args, model, Projector('cpu'), src, shard=shard, delta=g.t('in/delta0').clone().requires_grad_(True))
+if mode == 'gnt':
+    # BASELINE config 4's flavour: GNT renderer on single_net feature maps (one map serves both levels: the view exchange moves it
+    # once), unmasked MSE; V = 3 source views over 2 ranks is a ragged 2 + 1 split
+    from types import SimpleNamespace
+    from nerfool_amd.gnt import eval_adv as GEA
+    from nerfool_amd.gnt.model import GNTModel
+    from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
+    from nerfool_amd.synthetic import make_scene
+    torch.manual_seed(0)
+    H, W, V, R, S, depth = 48, 64, 3, 24, 8, 2
+    args = SimpleNamespace(netwidth=64, trans_depth=depth, single_net=True, ret_alpha=False, coarse_feat_dim=32, fine_feat_dim=32,
+                           N_rand=R, N_samples=S, N_importance=0, inv_uniform=True, det=True, white_bkgd=False, epsilon=8, adv_lr=2,
+                           use_adam=True, adam_lr=1e-3, lr_step_size=100, lr_gamma=0.5, adv_iters=1, sample_mode='uniform',
+                           center_ratio=0.8, ckpt_path=None)
+    model = GNTModel(args, device='cpu')
+    model.switch_to_eval()
+    data = make_scene(H, W, V, seed=21, tilt=0.3)
+    sampler = RaySamplerSingleImage(data, 'cpu')
+    src = sampler.get_all()
+    picks = np.random.RandomState(5).choice(H * W, size=(R,), replace=False)
+    delta0 = (torch.rand(data['src_rgbs'].shape, generator=torch.Generator().manual_seed(9)) * 2 - 1) * (8.0 / 255.0)
+    atk = GEA.PGDAttack(args, model, Projector('cpu'), src, shard=shard, delta=delta0.clone().requires_grad_(True))
+else:
+    g, args, model, data, sampler, dims = pc._attack_setup('cpu')
+    if mode == 'bf16':
+        # BASELINE config 5's precision: the row network on bf16 matrix-core operands -- needs the matrix-core kernels
+        mlp_network.KERNEL_PATH = 'auto'
+        for net in (model.net_coarse, model.net_fine):
+            net.precision = 'bf16'
+    src = sampler.get_all()
+    picks = g.np('adam/selected_inds')[0]
+    atk = EA.PGDAttack(args, model, Projector('cpu'), src, shard=shard, delta=g.t('in/delta0').clone().requires_grad_(True))
 if draw:
     from nerfool_amd.ibrnet import sample_ray
     sample_ray.rng.seed(234)
@@ -46,7 +75,7 @@ else:
     mine = picks if world == 1 else picks[rank::world]
     grad = atk.gradient(data, select_inds=mine).clone()
 atk.apply(grad)
-tag = os.environ['SHARD_VIEWS'] + ('d' if draw else '')
+tag = os.environ['SHARD_VIEWS'] + ('d' if draw else '') + ('' if mode == 'ibrnet' else mode)
 np.savez(os.path.join(%(out)r, 'rank%%d_of_%%d_%%s.npz' %% (rank, world, tag)), grad=grad.numpy(), delta=atk.delta.detach().numpy(),
          loss=float(atk.last_loss), collectives=0 if shard is None else shard.collectives)
 if world > 1:
@@ -63,10 +92,10 @@ def _build_and_script(tmp_path):
     return script
 
 
-def _run_world(script, env, world, shard_views, draw=False):
+def _run_world(script, env, world, shard_views, draw=False, mode='ibrnet'):
     procs = [subprocess.Popen([sys.executable, str(script)],
                               env=dict(env, RANK=str(r), WORLD_SIZE=str(world), SHARD_VIEWS='1' if shard_views else '0',
-                                       DRAW='1' if draw else '0'))
+                                       DRAW='1' if draw else '0', MODE=mode))
              for r in range(world)]
     assert all(p.wait() == 0 for p in procs)
 
@@ -104,6 +133,30 @@ def test_sharded_step_equals_single_process(tmp_path):
     got = np.load(tmp_path / 'rank1_of_2_1d.npz')
     assert np.abs(got['grad'] - ref_d['grad']).max() <= 2e-4 * scale
     assert abs(float(got['loss']) - float(ref_d['loss'])) <= 1e-5 * abs(float(ref_d['loss']))
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize('mode', ['gnt', 'bf16'])
+def test_sharded_step_of_the_8_gpu_configs(tmp_path, mode):
+    """The two BASELINE configurations that name 8 GPUs besides config 3: the GNT attack step (config 4; precedent
+    eval/gnt/eval_adv.py:1211-1214) and the IBRNet step with the bf16 row network (config 5), world 2, both CNN placements --
+    replicated (2 collectives) and sharded by source view (4 collectives; GNT: V = 3 over 2 ranks, the single_net map) -- each
+    equal to its single-process result on the same rays."""
+    script = _build_and_script(tmp_path)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29581' if mode == 'gnt' else '29591', OMP_NUM_THREADS='2')
+    _run_world(script, env, 1, False, mode=mode)
+    ref = np.load(tmp_path / ('rank0_of_1_0%s.npz' % mode))
+    scale = np.abs(ref['grad']).max()
+    assert scale > 0
+    for i, shard_views in enumerate((False, True)):
+        _run_world(script, dict(env, MASTER_PORT=str(int(env['MASTER_PORT']) + 1 + i)), 2, shard_views, mode=mode)
+        ranks = [np.load(tmp_path / ('rank%d_of_2_%d%s.npz' % (r, shard_views, mode))) for r in range(2)]
+        assert np.abs(ranks[0]['grad'] - ref['grad']).max() <= 2e-4 * scale, (mode, shard_views, np.abs(ranks[0]['grad'] - ref['grad']).max() / scale)
+        for r in ranks:
+            assert np.array_equal(ranks[0]['grad'], r['grad']) and np.array_equal(ranks[0]['delta'], r['delta'])
+            assert abs(float(r['loss']) - float(ref['loss'])) <= 1e-5 * abs(float(ref['loss']))
+            assert int(r['collectives']) == (4 if shard_views else 2)
+        assert np.abs(ranks[0]['delta'] - ref['delta']).mean() <= 1e-6
 
 
 VIEW_WORKER = r'''

@@ -117,6 +117,16 @@ def test_universal_trajectory():
         pc.check_universal_trajectory('cpu', steps=2)      # both target views once; the full loop runs on the GPU
 
 
+def test_bf16_attack_steps_and_universal_loop():
+    """the bf16 row network (emulated v_mfma_f32_32x32x16_bf16) inside PGD steps; the CNN on the nn.Module graph"""
+    from nerfool_amd.ibrnet import feature_network
+    saved, feature_network.CNN_PATH = feature_network.CNN_PATH, 'torch'
+    try:
+        pc.check_bf16_attack('cpu')
+    finally:
+        feature_network.CNN_PATH = saved
+
+
 def test_gather_fused_forward():
     pc.check_gather_fused_forward('cpu', shapes=((3, 32, 4),))
 

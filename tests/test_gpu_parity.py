@@ -45,6 +45,10 @@ def test_bf16_row_network_config5():
     pc.check_bf16_config5('cuda')
 
 
+def test_bf16_attack_steps_and_universal_loop():
+    pc.check_bf16_attack('cuda')
+
+
 def test_ray_sampler():
     pc.check_ray_sampler('cuda')
 
