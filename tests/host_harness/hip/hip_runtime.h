@@ -106,15 +106,16 @@ static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, 
     else { fprintf(stderr, "hip_emu: dpp control 0x%x not emulated\n", ctrl); abort(); }
     return hip_emu::exchange(src, from);
 }
-struct nf_emu_u32x2 {
-    unsigned x, y;
-};
+typedef unsigned nf_emu_u32x2 __attribute__((ext_vector_type(2)));
 // vdst[32:63] <-> vsrc[0:31]; returns (vdst', vsrc')
 static inline nf_emu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
     const int l = hip_emu::lane();
     const unsigned a_from = hip_emu::exchange(b, l - 32 < 0 ? l : l - 32);      // upper lanes of a' take b's lower half
     const unsigned b_from = hip_emu::exchange(a, l + 32 > 63 ? l : l + 32);      // lower lanes of b' take a's upper half
-    return nf_emu_u32x2{l >= 32 ? a_from : a, l < 32 ? b_from : b};
+    nf_emu_u32x2 r;
+    r.x = l >= 32 ? a_from : a;
+    r.y = l < 32 ? b_from : b;
+    return r;
 }
 
 static inline float atomicAdd(float* addr, float val) {
