@@ -108,7 +108,8 @@ int nf_ibrnet_bwd(const float* blob, const float* pos_enc, const float* rgb_feat
                   const float* mask, const float* d_raw, int64_t n_rays, int n_samples, int n_views,
                   int anti_alias_pooling, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 
-/* Matrix-core (MFMA, exact fp32) path of the same function for V in {1,2,4,8,16,32}: two kernels per level
+/* Matrix-core (MFMA, exact fp32) path of the same function for any V <= 32 (a sample's views sit on the next power of two of V
+ * adjacent lanes; the reference's default num_source_views = 10 runs on 16 with neutral padding lanes): two kernels per level
  * (per-(sample,view) rows on v_mfma_f32_32x32x2_f32, then per-ray attention).  mfma_blob = the natural blob re-ordered
  * into MFMA operand order by nf_ibrnet_pack_mfma (HOST pointers in, HOST pointers out; no GPU needed).
  * workspace: nf_ibrnet_mfma_workspace_floats(R, S) floats. */

@@ -5,7 +5,7 @@
 // (sample fastest => coalesced); weights are read with wave-uniform addresses (scalar loads).
 //
 // These kernels are the shape-generic path and the on-device cross-check of the MFMA tile kernels in
-// nf_ibrnet_mfma.hip (V a power of two, S a multiple of 8).
+// nf_ibrnet_mfma.hip (V <= 32).
 //
 // ref: ibrnet/mlp_network.py:222-274 (IBRNet.forward), :69-119 (MultiHeadAttention), :23-43 (attention core).
 // The backward follows oracle/ibrnet_manual_bwd.py step by step (d/d rgb_feat only).

@@ -1,4 +1,6 @@
-// IBRNet on the matrix cores (a4/a5), V in {1,2,4,8,16,32}.
+// IBRNet on the matrix cores (a4/a5), any V <= 32: a sample's views occupy VP = the next power of two of V adjacent lanes (the
+// reference's default num_source_views = 10 -> 16 lanes, 2 samples per 32-row tile); the padding lanes carry mask 0 and are neutral
+// in every cross-view reduction (RowIn::pad).
 //
 // Forward = two kernels per level:
 //   A  k_ibr_rows_fwd  -- everything that lives on a (sample, view) ROW: direction MLP, first pooling, base_fc, vis_fc,
@@ -464,7 +466,33 @@ __device__ __forceinline__ float dot_frag16(const float* vec_h, const f32x16& x)
 struct RowIn {
     f32x16 feat;                 // rgb_feat channels 3 + n(r,h)
     float c[3], rd[4], mk;       // clean colour taps, ray_diff, validity
+    bool pad;                    // a padding lane (view index >= the real view count): mk = 0, all inputs 0
+    float inv_nv;                // 1 / real view count
 };
+
+// lane -> (sample, view) of a 32-row tile when a sample's nv views sit on V = 2^k >= nv adjacent lanes
+template <int V>
+struct RowMap {
+    int64_t sample, row;         // row = sample * nv + view: the index into rgb_feat / ray_diff / mask / d rgb_feat
+    int v;
+    bool live, pad;
+    __device__ __forceinline__ RowMap(int64_t tile, int m, int nv, int64_t n_samples) {
+        sample = tile * (32 / V) + m / V;
+        v = m % V;
+        pad = v >= nv;
+        live = sample < n_samples && !pad;
+        if (sample >= n_samples) sample = n_samples - 1;       // whole groups beyond the end recompute the last sample (nothing written)
+        row = sample * nv + (pad ? 0 : v);
+    }
+};
+
+__device__ __forceinline__ void pad_row(RowIn& in) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) in.feat[r] = 0.f;
+    in.c[0] = in.c[1] = in.c[2] = 0.f;
+    in.rd[0] = in.rd[1] = in.rd[2] = in.rd[3] = 0.f;
+    in.mk = 0.f;
+}
 
 struct RowActs {
     f32x16 F, MEAN, VAR, H1a, H1b, H, V1, XV, X2, U, MEAN2, VAR2;
@@ -498,10 +526,9 @@ struct RowGather {
     int H, W, Hf, Wf;
 };
 
-template <int V>
-__device__ __forceinline__ void load_row_gather(const RowGather& g, int64_t row, int64_t sample, int v, int h, bool live, RowIn& in) {
+__device__ __forceinline__ void load_row_gather(const RowGather& g, int nv, int64_t row, int64_t sample, int v, int h, bool live, RowIn& in) {
     const float* cam = g.cam_ws + (int64_t)v * NF_CAM_STRIDE;
-    const float* qc = g.cam_ws + (int64_t)V * NF_CAM_STRIDE;
+    const float* qc = g.cam_ws + (int64_t)nv * NF_CAM_STRIDE;
     const float x = g.xyz[sample * 3 + 0], y = g.xyz[sample * 3 + 1], z = g.xyz[sample * 3 + 2];
     float px, py;
     bool front;
@@ -590,7 +617,7 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
     // ---- first pooling weight (:234-241)
     float w;
     if (aa) {
-        float e = mf_exp(s_abs * (in.rd[3] - 1.f));
+        float e = in.pad ? 3.0e38f : mf_exp(s_abs * (in.rd[3] - 1.f));      // padding lanes never are the minimum
         w = (e - grp_min<V>(e)) * in.mk;
     } else {
         w = in.mk;
@@ -642,7 +669,7 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
     }
     a.vsum = grp_sum<V>(a.vis2) + 1e-8f;
     a.w2 = a.vis2 / a.vsum;
-    a.wmean = grp_sum<V>(a.w2) / (float)V;
+    a.wmean = grp_sum<V>(a.w2) * in.inv_nv;
     a.nval = grp_sum<V>(in.mk);
     // ---- second pooling (:255-257)
 #pragma unroll
@@ -671,7 +698,8 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
             y = fmaf(lds[MS_RGB2 + j], a.r2[j], y);
         }
     }
-    if (in.mk == 0.f) y = -1e9f;
+    if (in.mk == 0.f) y = in.pad ? -3.0e38f : -1e9f;      // masked_fill(-1e9) for real views; a padding lane gets weight 0 even
+                                                          // when every real view is masked (softmax of equal logits = 1 / nv)
     float p = mf_exp(y - grp_max<V>(y));
     a.beta = p / grp_sum<V>(p);
 #pragma unroll
@@ -681,31 +709,32 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
 template <int V, bool BF, bool GATH>
 __global__ void __launch_bounds__(64 * NF_ROWS_FWD_WAVES, NF_ROWS_FWD_OCC) k_ibr_rows_fwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
-                                                         int64_t n_samples, int aa, float* __restrict__ smp, RowGather gather) {
+                                                         int64_t n_samples, int nv, int aa, float* __restrict__ smp, RowGather gather) {
     HIP_DYNAMIC_SHARED(float, lds)
     static_assert(NF_BF_FWD_FLOATS == NF_MFMA_FWD_FLOATS, "both forward images are MS_END floats");
     for (int i = threadIdx.x; i < NF_MFMA_FWD_FLOATS; i += blockDim.x) lds[i] = wblob[i];      // BF: wblob is the bf16 image
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
-    const int64_t n_rows = n_samples * V;
-    const int64_t n_tiles = (n_rows + 31) / 32;
+    const int64_t n_tiles = (n_samples + 32 / V - 1) / (32 / V);
     for (int64_t tile = (int64_t)blockIdx.x * NF_ROWS_FWD_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NF_ROWS_FWD_WAVES) {
         // compiler barrier: keeps the (tile-invariant) weight reads from being hoisted out of the loop into 200+ VGPRs
         asm volatile("" ::: "memory");
-        int64_t row = tile * 32 + m;
-        const bool live = row < n_rows;
-        if (!live) row = n_rows - 1;
-        const int64_t sample = row / V;
-        const int v = (int)(row - sample * V);
+        const RowMap<V> rm(tile, m, nv, n_samples);
+        const int64_t row = rm.row, sample = rm.sample;
+        const int v = rm.v;
+        const bool live = rm.live;
         RowIn in;
-        if (GATH) load_row_gather<V>(gather, row, sample, v, h, live, in);
+        in.pad = rm.pad;
+        in.inv_nv = 1.f / (float)nv;
+        if (rm.pad) pad_row(in);
+        else if (GATH) load_row_gather(gather, nv, row, sample, v, h, live, in);
         else load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
         RowActs a;
         rows_forward<V, BF>(lds, lane, h, aa, in, a);
         // per-sample record; the lane holding view 0 writes (both lane halves, 16 features each)
         float* out = smp + sample * NF_SMP_STRIDE;
-        if (live && v == 0) {
+        if (rm.live && v == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 out[nf_nidx(r, h)] = a.MEAN2[r];
@@ -796,7 +825,7 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
             part = fmaf(a.X2[r], dm, part);
             part = fmaf(dev * dev, d_var2[r], part);
         }
-        float d_w2 = half_sum(part) + d_wmean / (float)V;
+        float d_w2 = half_sum(part) + d_wmean * in.inv_nv;
         float sdw = grp_sum<V>(d_w2 * a.w2);
         d_vis2 += (d_w2 - sdw) / a.vsum;
     }
@@ -903,23 +932,24 @@ struct RowScatter {
 template <int V, bool BF, bool SCAT, bool GATH>
 __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_OCC) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
-                                                         const float* __restrict__ d_smp, int64_t n_samples, int aa,
+                                                         const float* __restrict__ d_smp, int64_t n_samples, int nv, int aa,
                                                          float* __restrict__ d_rgb_feat, RowScatter sc, RowGather gather) {
     HIP_DYNAMIC_SHARED(float, lds)
     for (int i = threadIdx.x; i < (BF ? (int)NF_BF_BLOB_FLOATS : (int)NF_ROWS_BLOB_FLOATS); i += blockDim.x) lds[i] = wblob[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
-    const int64_t n_rows = n_samples * V;
-    const int64_t n_tiles = (n_rows + 31) / 32;
+    const int64_t n_tiles = (n_samples + 32 / V - 1) / (32 / V);
     for (int64_t tile = (int64_t)blockIdx.x * NF_ROWS_BWD_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NF_ROWS_BWD_WAVES) {
         asm volatile("" ::: "memory");
-        int64_t row = tile * 32 + m;
-        const bool live = row < n_rows;
-        if (!live) row = n_rows - 1;
-        const int64_t sample = row / V;
+        const RowMap<V> rm(tile, m, nv, n_samples);
+        const int64_t row = rm.row, sample = rm.sample;
+        const bool live = rm.live;
         RowIn in;
-        if (GATH) load_row_gather<V>(gather, row, sample, (int)(row - sample * V), h, live, in);      // the recompute gathers again: no rgb_feat anywhere
+        in.pad = rm.pad;
+        in.inv_nv = 1.f / (float)nv;
+        if (rm.pad) pad_row(in);
+        else if (GATH) load_row_gather(gather, nv, row, sample, rm.v, h, live, in);      // (a recompute that gathers again: experiments only)
         else load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
         RowActs a;
         rows_forward<V, BF>(lds, lane, h, aa, in, a);
@@ -942,9 +972,9 @@ __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_O
 #pragma unroll
             for (int r = 0; r < 16; ++r) gt[m * RS_ROW + nf_nidx(r, h)] = d_feat[r];
             if (h == 0) {
-                const int v = (int)(row - sample * V);
+                const int v = rm.pad ? 0 : rm.v;
                 const float* cam = sc.cam_ws + (int64_t)v * NF_CAM_STRIDE;
-                const float* qc = sc.cam_ws + (int64_t)V * NF_CAM_STRIDE;
+                const float* qc = sc.cam_ws + (int64_t)nv * NF_CAM_STRIDE;
                 float px, py;
                 bool front;
                 nf_project_point(cam, sc.xyz[sample * 3 + 0], sc.xyz[sample * 3 + 1], sc.xyz[sample * 3 + 2], px, py, front);
@@ -1720,8 +1750,14 @@ __global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int nf_ibrnet_mfma_supported(int n_samples, int n_views) {
-    bool v_ok = n_views >= 1 && n_views <= 32 && (n_views & (n_views - 1)) == 0;
-    return (v_ok && n_samples >= 1 && n_samples <= NF_IBR_MAX_S) ? 1 : 0;
+    return (n_views >= 1 && n_views <= 32 && n_samples >= 1 && n_samples <= NF_IBR_MAX_S) ? 1 : 0;
+}
+
+// lanes per sample: the next power of two of the view count
+static int rows_lanes_per_sample(int n_views) {
+    int vp = 1;
+    while (vp < n_views) vp <<= 1;
+    return vp;
 }
 
 extern "C" int64_t nf_ibrnet_mfma_workspace_floats(int64_t n_rays, int n_samples) {
@@ -1730,13 +1766,13 @@ extern "C" int64_t nf_ibrnet_mfma_workspace_floats(int64_t n_rays, int n_samples
 
 template <int V>
 static void launch_rows_fwd(const float* wblob, const float* bf_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
-                            int64_t n_samples, int aa, float* smp, const RowGather& g, hipStream_t st) {
-    int64_t tiles = (n_samples * V + 31) / 32;
+                            int64_t n_samples, int nv, int aa, float* smp, const RowGather& g, hipStream_t st) {
+    int64_t tiles = (n_samples + 32 / V - 1) / (32 / V);
     int64_t blocks = (tiles + NF_ROWS_FWD_WAVES - 1) / NF_ROWS_FWD_WAVES;
     if (blocks > 1024) blocks = 1024;     // persistent-ish: 2 workgroups per CU hold the 58 KB weight image each
 #define NF_ROWS_FWD_GO(BFV, GV, blobp, floats)                                                                                          \
     hipLaunchKernelGGL((k_ibr_rows_fwd<V, BFV, GV>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_FWD_WAVES), (floats) * sizeof(float), st, \
-                       blobp, rgb_feat, ray_diff, mask, n_samples, aa, smp, g)
+                       blobp, rgb_feat, ray_diff, mask, n_samples, nv, aa, smp, g)
     if (g.featmap) {
         if (bf_blob) NF_ROWS_FWD_GO(true, true, bf_blob, NF_BF_FWD_FLOATS);
         else NF_ROWS_FWD_GO(false, true, wblob, NF_MFMA_FWD_FLOATS);
@@ -1750,17 +1786,17 @@ static void launch_rows_fwd(const float* wblob, const float* bf_blob, const floa
 static int ibrnet_fwd_impl(const char* who, const float* bf_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
                            const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_rays, int n_samples, int n_views,
                            int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream, const RowGather& gather = RowGather{}) {
-    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: V must be a power of two <= 32 (got %d)", who, n_views);
+    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: 1 <= V <= 32 (got %d)", who, n_views);
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int64_t ns = n_rays * n_samples;
-    switch (n_views) {
-        case 1: launch_rows_fwd<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
-        case 2: launch_rows_fwd<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
-        case 4: launch_rows_fwd<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
-        case 8: launch_rows_fwd<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
-        case 16: launch_rows_fwd<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
-        default: launch_rows_fwd<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st); break;
+    switch (rows_lanes_per_sample(n_views)) {
+        case 1: launch_rows_fwd<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, n_views, anti_alias_pooling, workspace, gather, st); break;
+        case 2: launch_rows_fwd<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, n_views, anti_alias_pooling, workspace, gather, st); break;
+        case 4: launch_rows_fwd<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, n_views, anti_alias_pooling, workspace, gather, st); break;
+        case 8: launch_rows_fwd<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, n_views, anti_alias_pooling, workspace, gather, st); break;
+        case 16: launch_rows_fwd<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, n_views, anti_alias_pooling, workspace, gather, st); break;
+        default: launch_rows_fwd<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, n_views, anti_alias_pooling, workspace, gather, st); break;
     }
     NF_LAUNCH_CHECK("nf_ibrnet_fwd_mfma (rows)");
     if (n_samples == 32 || n_samples == 64 || n_samples == 128 || n_samples == 256) {       // per-ray part on the matrix cores as well
@@ -1838,7 +1874,7 @@ extern "C" int nf_ibrnet_fwd_mfma_bf16(const float* bf16_blob, const float* mfma
 
 template <int V, bool BF, bool SCAT, bool GATH>
 static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask,
-                           const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, const RowGather& ga,
+                           const float* d_smp, int64_t n_samples, int nv, int aa, float* d_rgb_feat, const RowScatter& sc, const RowGather& ga,
                            hipStream_t st) {
     static bool configured_on[NF_MAX_DEVICES] = {};      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel and device
     bool& configured = configured_on[nf_current_device()];
@@ -1852,25 +1888,25 @@ static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const floa
         }
         configured = true;
     }
-    int64_t tiles = (n_samples * V + 31) / 32;
+    int64_t tiles = (n_samples + 32 / V - 1) / (32 / V);
     int64_t blocks = (tiles + NF_ROWS_BWD_WAVES - 1) / NF_ROWS_BWD_WAVES;
     // fp32: one workgroup per CU holds the 113 KB weight image (fwd + transposed); bf16: 64 KB, two per CU
     const int64_t cap = BF ? 1024 : 512;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF, SCAT, GATH>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask,
-                       d_smp, n_samples, aa, d_rgb_feat, sc, ga);
+                       d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga);
     return 0;
 }
 
 template <int V>
 static int launch_rows_bwd_any(const float* wblob, const float* bf_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
-                               const float* d_smp, int64_t n_samples, int aa, float* d_rgb_feat, const RowScatter& sc, const RowGather& ga,
+                               const float* d_smp, int64_t n_samples, int nv, int aa, float* d_rgb_feat, const RowScatter& sc, const RowGather& ga,
                                hipStream_t st) {
     if (sc.d_featmap) {     // fused scatter: exact-fp32 rows only (the bf16 image leaves no LDS for the staging tiles at two workgroups per CU)
-        return launch_rows_bwd<V, false, true, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st);
+        return launch_rows_bwd<V, false, true, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga, st);
     }
-    return bf_blob ? launch_rows_bwd<V, true, false, false>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st)
-                   : launch_rows_bwd<V, false, false, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, aa, d_rgb_feat, sc, ga, st);
+    return bf_blob ? launch_rows_bwd<V, true, false, false>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga, st)
+                   : launch_rows_bwd<V, false, false, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga, st);
 }
 
 template <int WPR, int NWV>
@@ -1905,7 +1941,7 @@ static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* m
                            const float* rgb_feat, const float* ray_diff, const float* mask, const float* smp, const float* d_raw,
                            int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat,
                            float* d_workspace, nf_stream_t stream, const RowScatter& sc = RowScatter{}, const RowGather& ga = RowGather{}) {
-    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: V must be a power of two <= 32 (got %d)", who, n_views);
+    NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: 1 <= V <= 32 (got %d)", who, n_views);
     NF_REQUIRE(!(sc.d_featmap && bf_blob), "%s: the fused scatter runs with the fp32 row kernels", who);
     NF_REQUIRE(!ga.featmap || sc.d_featmap, "%s: the gathering recompute comes with the fused scatter", who);
     if (n_rays == 0) return 0;
@@ -1934,13 +1970,13 @@ static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* m
     NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (ray)");
     int64_t ns = n_rays * n_samples;
     int rc;
-    switch (n_views) {
-        case 1: rc = launch_rows_bwd_any<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
-        case 2: rc = launch_rows_bwd_any<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
-        case 4: rc = launch_rows_bwd_any<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
-        case 8: rc = launch_rows_bwd_any<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
-        case 16: rc = launch_rows_bwd_any<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
-        default: rc = launch_rows_bwd_any<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+    switch (rows_lanes_per_sample(n_views)) {
+        case 1: rc = launch_rows_bwd_any<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, n_views, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        case 2: rc = launch_rows_bwd_any<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, n_views, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        case 4: rc = launch_rows_bwd_any<4>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, n_views, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        case 8: rc = launch_rows_bwd_any<8>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, n_views, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        case 16: rc = launch_rows_bwd_any<16>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, n_views, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
+        default: rc = launch_rows_bwd_any<32>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, d_workspace, ns, n_views, anti_alias_pooling, d_rgb_feat, sc, ga, st); break;
     }
     if (rc) return rc;
     NF_LAUNCH_CHECK("nf_ibrnet_bwd_mfma (rows)");

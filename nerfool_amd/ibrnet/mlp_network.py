@@ -40,7 +40,7 @@ def sinusoid_table(n_samples, d_hid=16):
 
 
 # Test / diagnostic hook (tests/ and tools/ set it; nothing reads the environment): 'auto' = matrix-core kernels whenever the shape
-# allows (V a power of two), 'generic' = shape-generic kernels only (the CPU stand-in emulates those ~30x faster)
+# allows (any V <= 32, S <= 256), 'generic' = shape-generic kernels only
 KERNEL_PATH = 'auto'
 
 
@@ -50,7 +50,7 @@ class _IBRNetFunction(torch.autograd.Function):
         S, V = rgb_feat.shape[1], rgb_feat.shape[2]
         ctx.mfma = KERNEL_PATH != 'generic' and mfma_blob is not None and ops.ibrnet_mfma_supported(S, V)
         if bf16_blob is not None and not ctx.mfma:
-            raise RuntimeError('the bf16 IBRNet path needs the matrix-core kernels (V a power of two <= 32; got V=%d)' % V)
+            raise RuntimeError('the bf16 IBRNet path needs the matrix-core kernels (V <= 32; got V=%d)' % V)
         ctx.bf16 = bf16_blob is not None
         if ctx.mfma:
             raw, smp = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias, bf16_blob=bf16_blob)

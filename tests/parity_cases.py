@@ -603,7 +603,7 @@ def check_evaluate_view(dev):
     assert abs(clean['fine_psnr'] - zero['fine_psnr']) < 1e-3, (clean['fine_psnr'], zero['fine_psnr'])
 
 
-def check_gather_fused_forward(dev, shapes=((12, 64, 4), (5, 32, 8), (3, 128, 2))):
+def check_gather_fused_forward(dev, shapes=((12, 64, 4), (5, 32, 8), (3, 128, 2), (4, 64, 10), (3, 32, 5))):
     """The row kernel with Projector.compute folded in (no-grad rendering, ops.ibrnet_fwd_mfma_gather) against the stand-alone
     gather + the row kernel on its output: same arithmetic tap by tap, so raw and mask must agree to the last bit (1e-6 allowed
     for a differently contracted address computation); cameras that put samples behind a view and outside the maps included."""

@@ -128,7 +128,7 @@ def test_bf16_attack_steps_and_universal_loop():
 
 
 def test_gather_fused_forward():
-    pc.check_gather_fused_forward('cpu', shapes=((3, 32, 4),))
+    pc.check_gather_fused_forward('cpu', shapes=((3, 32, 4), (2, 16, 5), (2, 32, 10)))
 
 
 def test_ragged_ray_batches():
@@ -153,11 +153,13 @@ def test_render_single_image():
 
 
 def test_mfma_kernels_match_generic_kernels():
-    """matrix-core forward (emulated v_mfma_f32_32x32x2_f32) vs the generic kernel, ragged tile count, V = 4 and 2."""
+    """matrix-core forward / backward (emulated v_mfma_f32_32x32x2_f32) vs the generic kernels: ragged tile counts, V = 4 and 2,
+    and view counts that are not a power of two -- 3, 5, 10 (the reference's default num_source_views), 12 -- whose samples sit
+    on 4 / 8 / 16 lanes with neutral padding lanes; a sample whose views are all masked (softmax over equal -1e9 logits)."""
     import torch
     from nerfool_amd import ops
     from oracle.ibrnet_ref import random_ibrnet_params
-    for R, S, V in ((3, 10, 4), (2, 9, 2), (5, 32, 4), (3, 64, 2)):      # S = 32 / 64: per-ray part on MFMA too
+    for R, S, V in ((3, 10, 4), (2, 9, 2), (5, 32, 4), (3, 64, 2), (3, 11, 3), (2, 7, 5), (3, 32, 10), (2, 5, 12), (1, 3, 1)):      # S = 32 / 64: per-ray part on MFMA too
         gen = torch.Generator().manual_seed(S)
         p = random_ibrnet_params(S, seed=3)
         blob = ops.pack_ibrnet_blob(p, 'cpu')
@@ -166,7 +168,7 @@ def test_mfma_kernels_match_generic_kernels():
         rd = torch.randn(R, S, V, 4, generator=gen)
         rd[..., 3] = 1 - 0.05 * torch.rand(R, S, V, generator=gen)
         mask = (torch.rand(R, S, V, generator=gen) > 0.25).float()
-        mask[0, :3] = 0
+        mask[0, :3] = 0                  # every view of these samples masked
         args = (p['pos_encoding'], rgb_feat, rd, mask, True)
         a = ops.ibrnet_fwd(blob, *args)
         b, _ = ops.ibrnet_fwd_mfma(mblob, blob, *args)

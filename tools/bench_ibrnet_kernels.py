@@ -25,7 +25,7 @@ def main():
     for (R, S, V, prec) in ((512, 64, 4, 'fp32'), (512, 128, 4, 'fp32'), (4096, 64, 4, 'fp32'), (4096, 128, 4, 'fp32'),
                             (512, 128, 8, 'fp32'), (512, 128, 8, 'bf16'), (512, 256, 8, 'fp32'), (512, 256, 8, 'bf16'),
                             (4096, 128, 8, 'fp32'), (4096, 128, 8, 'bf16'), (4096, 256, 8, 'fp32'), (4096, 256, 8, 'bf16'),
-                            (4096, 128, 4, 'bf16')):
+                            (4096, 128, 4, 'bf16'), (512, 64, 10, 'fp32'), (4096, 64, 10, 'fp32'), (4096, 64, 16, 'fp32')):
         torch.manual_seed(3)
         net = IBRNet(SimpleNamespace(anti_alias_pooling=1, ibrnet_precision=prec), in_feat_ch=32, n_samples=S).to(dev)
         blob, mblob = net._packed(dev)
