@@ -129,8 +129,9 @@ int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, const float* p
 /* The same backward with the adjoint of Projector.compute's feature gather (autograd of F.grid_sample, ibrnet/projection.py:116-125)
  * fused into its output stage: d rgb_feat is not written, its 32 feature channels are scattered straight into the feature-map
  * gradient.  xyz [n_rays * n_samples][3] and cam_ws exactly as given to nf_project_gather_fwd; d_featmap [V][32][Hf][Wf]
- * through element strides, ZEROED by the caller (the kernel adds, float atomics like nf_project_gather_bwd). */
-int nf_ibrnet_bwd_mfma_scatter(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
+ * through element strides, ZEROED by the caller (the kernel adds, float atomics like nf_project_gather_bwd).  bf16_blob: nullptr =
+ * exact fp32 rows; else the bf16-operand row network of nf_ibrnet_bwd_mfma_bf16 (8-wave workgroups: image + one staging tile per wave). */
+int nf_ibrnet_bwd_mfma_scatter(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
                                const float* ray_diff, const float* mask, const float* smp, const float* d_raw, int64_t n_rays,
                                int n_samples, int n_views, int anti_alias_pooling, float* d_workspace, const float* xyz,
                                const float* cam_ws, float* d_featmap, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,

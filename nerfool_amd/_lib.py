@@ -46,7 +46,7 @@ _PROTOTYPES = {
     'nf_ibrnet_bwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_ibrnet_fwd_mfma_gather': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                           c_int64, c_int, c_int, c_int, _P, _P, _P, _P]),
-    'nf_ibrnet_bwd_mfma_scatter': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64,
+    'nf_ibrnet_bwd_mfma_scatter': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, c_int64,
                                            c_int64, c_int64, c_int, c_int, _P]),
     'nf_ibrnet_mfma_bf16_blob_floats': (c_int64, []),
     'nf_ibrnet_pack_mfma_bf16': (c_int, [_P, _P]),

@@ -929,8 +929,13 @@ struct RowScatter {
 #define RS_TAP 8              // per row: 4 tap weights, x0, y0 (as int bits), view, pad
 #define RS_FLOATS (32 * RS_ROW + 32 * RS_TAP)
 
+// waves per workgroup / workgroups per CU of the backward row kernel: fp32 image (113 KB): 4 x 1; bf16 image (64 KB): 4 x 2, or --
+// with the fused scatter, whose staging tiles leave no room for a second workgroup -- 8 x 1 (two waves per SIMD either way)
+__host__ __device__ constexpr int rows_bwd_waves(bool bf, bool scat) { return (bf && scat) ? 8 : NF_ROWS_BWD_WAVES; }
+__host__ __device__ constexpr int rows_bwd_occ(bool bf, bool scat) { return (bf && !scat) ? 2 : NF_ROWS_BWD_OCC; }
+
 template <int V, bool BF, bool SCAT, bool GATH>
-__global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_OCC) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
+__global__ void __launch_bounds__(64 * rows_bwd_waves(BF, SCAT), rows_bwd_occ(BF, SCAT)) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                          const float* __restrict__ d_smp, int64_t n_samples, int nv, int aa,
                                                          float* __restrict__ d_rgb_feat, RowScatter sc, RowGather gather) {
@@ -940,7 +945,8 @@ __global__ void __launch_bounds__(64 * NF_ROWS_BWD_WAVES, BF ? 2 : NF_ROWS_BWD_O
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (n_samples + 32 / V - 1) / (32 / V);
-    for (int64_t tile = (int64_t)blockIdx.x * NF_ROWS_BWD_WAVES + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NF_ROWS_BWD_WAVES) {
+    constexpr int NWV = rows_bwd_waves(BF, SCAT);
+    for (int64_t tile = (int64_t)blockIdx.x * NWV + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NWV) {
         asm volatile("" ::: "memory");
         const RowMap<V> rm(tile, m, nv, n_samples);
         const int64_t row = rm.row, sample = rm.sample;
@@ -1879,7 +1885,8 @@ static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const floa
     static bool configured_on[NF_MAX_DEVICES] = {};      // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel and device
     bool& configured = configured_on[nf_current_device()];
     // the weight image (+ one staging tile per wave for the fused scatter)
-    const size_t smem = ((BF ? (size_t)NF_BF_BLOB_FLOATS : (size_t)NF_ROWS_BLOB_FLOATS) + (SCAT ? NF_ROWS_BWD_WAVES * RS_FLOATS : 0)) * sizeof(float);
+    constexpr int NWV = rows_bwd_waves(BF, SCAT);
+    const size_t smem = ((BF ? (size_t)NF_BF_BLOB_FLOATS : (size_t)NF_ROWS_BLOB_FLOATS) + (SCAT ? NWV * RS_FLOATS : 0)) * sizeof(float);
     if (!configured) {
         if (hipFuncSetAttribute((const void*)k_ibr_rows_bwd<V, BF, SCAT, GATH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
             hipSuccess) {
@@ -1889,11 +1896,11 @@ static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const floa
         configured = true;
     }
     int64_t tiles = (n_samples + 32 / V - 1) / (32 / V);
-    int64_t blocks = (tiles + NF_ROWS_BWD_WAVES - 1) / NF_ROWS_BWD_WAVES;
-    // fp32: one workgroup per CU holds the 113 KB weight image (fwd + transposed); bf16: 64 KB, two per CU
-    const int64_t cap = BF ? 1024 : 512;
+    int64_t blocks = (tiles + NWV - 1) / NWV;
+    // fp32: one workgroup per CU holds the 113 KB weight image (fwd + transposed); bf16: 64 KB, two per CU (one of 8 waves with the scatter)
+    const int64_t cap = rows_bwd_occ(BF, SCAT) == 2 ? 1024 : 512;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF, SCAT, GATH>), dim3((unsigned)blocks), dim3(64 * NF_ROWS_BWD_WAVES), smem, st, wblob, rgb_feat, ray_diff, mask,
+    hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF, SCAT, GATH>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, wblob, rgb_feat, ray_diff, mask,
                        d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga);
     return 0;
 }
@@ -1902,8 +1909,9 @@ template <int V>
 static int launch_rows_bwd_any(const float* wblob, const float* bf_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
                                const float* d_smp, int64_t n_samples, int nv, int aa, float* d_rgb_feat, const RowScatter& sc, const RowGather& ga,
                                hipStream_t st) {
-    if (sc.d_featmap) {     // fused scatter: exact-fp32 rows only (the bf16 image leaves no LDS for the staging tiles at two workgroups per CU)
-        return launch_rows_bwd<V, false, true, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga, st);
+    if (sc.d_featmap) {     // fused scatter
+        return bf_blob ? launch_rows_bwd<V, true, true, false>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga, st)
+                       : launch_rows_bwd<V, false, true, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga, st);
     }
     return bf_blob ? launch_rows_bwd<V, true, false, false>(bf_blob, rgb_feat, ray_diff, mask, d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga, st)
                    : launch_rows_bwd<V, false, false, false>(wblob, rgb_feat, ray_diff, mask, d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga, st);
@@ -1942,7 +1950,6 @@ static int ibrnet_bwd_impl(const char* who, const float* bf_blob, const float* m
                            int64_t n_rays, int n_samples, int n_views, int anti_alias_pooling, float* d_rgb_feat,
                            float* d_workspace, nf_stream_t stream, const RowScatter& sc = RowScatter{}, const RowGather& ga = RowGather{}) {
     NF_REQUIRE(nf_ibrnet_mfma_supported(n_samples, n_views), "%s: 1 <= V <= 32 (got %d)", who, n_views);
-    NF_REQUIRE(!(sc.d_featmap && bf_blob), "%s: the fused scatter runs with the fp32 row kernels", who);
     NF_REQUIRE(!ga.featmap || sc.d_featmap, "%s: the gathering recompute comes with the fused scatter", who);
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -1995,7 +2002,7 @@ extern "C" int nf_ibrnet_bwd_mfma(const float* mfma_blob, const float* blob, con
 /* nf_ibrnet_bwd_mfma with the scatter of d rgb_feat into the feature-map gradient fused into the row kernel (d rgb_feat is not
  * written): xyz [n_rays * n_samples][3] and cam_ws as given to nf_project_gather_fwd, d_featmap [V][32][Hf][Wf] through element
  * strides, ZEROED by the caller (the kernel adds). */
-extern "C" int nf_ibrnet_bwd_mfma_scatter(const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
+extern "C" int nf_ibrnet_bwd_mfma_scatter(const float* bf16_blob, const float* mfma_blob, const float* blob, const float* pos_enc, const float* rgb_feat,
                                           const float* ray_diff, const float* mask, const float* smp, const float* d_raw, int64_t n_rays,
                                           int n_samples, int n_views, int anti_alias_pooling, float* d_workspace, const float* xyz,
                                           const float* cam_ws, float* d_featmap, int64_t fs_v, int64_t fs_c, int64_t fs_h, int64_t fs_w,
@@ -2003,7 +2010,7 @@ extern "C" int nf_ibrnet_bwd_mfma_scatter(const float* mfma_blob, const float* b
     if (n_rays == 0) return 0;       // nothing to add
     NF_REQUIRE(xyz && cam_ws && d_featmap && Hf >= 1 && Wf >= 1, "nf_ibrnet_bwd_mfma_scatter: bad arguments");
     const RowScatter sc = {xyz, cam_ws, d_featmap, fs_v, fs_c, fs_h, fs_w, Hf, Wf};
-    return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma_scatter", nullptr, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, n_rays,
+    return ibrnet_bwd_impl("nf_ibrnet_bwd_mfma_scatter", bf16_blob, mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, n_rays,
                            n_samples, n_views, anti_alias_pooling, nullptr, d_workspace, stream, sc);
 }
 

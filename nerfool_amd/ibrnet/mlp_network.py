@@ -79,18 +79,19 @@ class _IBRNetGatherFunction(torch.autograd.Function):
     `featmaps` with the sample points / cameras handed over next to it."""
 
     @staticmethod
-    def forward(ctx, featmaps, rgb_feat, ray_diff, mask, blob, mfma_blob, pos_enc, anti_alias, pts, cam_ws):
-        raw, smp = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias)
-        ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp, pts, cam_ws)
+    def forward(ctx, featmaps, rgb_feat, ray_diff, mask, blob, mfma_blob, pos_enc, anti_alias, pts, cam_ws, bf16_blob=None):
+        raw, smp = ops.ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias, bf16_blob=bf16_blob)
+        ctx.bf16 = bf16_blob is not None
+        ctx.save_for_backward(rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp, pts, cam_ws, *((bf16_blob,) if ctx.bf16 else ()))
         ctx.anti_alias, ctx.feat_shape = anti_alias, tuple(featmaps.shape)
         return raw
 
     @staticmethod
     def backward(ctx, d_raw):
-        rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp, pts, cam_ws = ctx.saved_tensors
+        rgb_feat, ray_diff, mask, blob, pos_enc, mfma_blob, smp, pts, cam_ws = ctx.saved_tensors[:9]
         d_feat = ops.ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, ctx.anti_alias, pts, cam_ws,
-                                             ctx.feat_shape)
-        return (d_feat,) + (None,) * 9
+                                             ctx.feat_shape, bf16_blob=ctx.saved_tensors[9] if ctx.bf16 else None)
+        return (d_feat,) + (None,) * 10
 
 
 # Test hook: 'fused' (default) -- rendering gathers inside the row kernel (no rgb_feat at all); the attack's forward runs the
@@ -178,11 +179,11 @@ class IBRNet(nn.Module):
         gather = getattr(rgb_feat, '_nf_gather', None)
         if gather is not None and gather[3] != rgb_feat._version:
             gather = None           # edited in place since Projector.compute: it is no longer the gather of those maps
-        if (gather is not None and GATHER_BWD_FUSION == 'fused' and self.precision == 'fp32' and KERNEL_PATH != 'generic'
+        if (gather is not None and GATHER_BWD_FUSION == 'fused' and KERNEL_PATH != 'generic'
                 and ops.GATHER_BWD != 'deterministic' and torch.is_grad_enabled() and gather[2].requires_grad
                 and gather[2].shape[1] == 32 and ops.ibrnet_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])):
             pts, cam_ws, featmaps = gather[:3]
             return _IBRNetGatherFunction.apply(featmaps, rgb_feat.detach(), ray_diff, mask[..., 0], blob, mfma_blob, self.pos_encoding,
-                                               bool(self.anti_alias_pooling), pts, cam_ws)
+                                               bool(self.anti_alias_pooling), pts, cam_ws, self._bf16_blob if self.precision == 'bf16' else None)
         return _IBRNetFunction.apply(rgb_feat, ray_diff, mask[..., 0], blob, mfma_blob, self.pos_encoding,
                                      bool(self.anti_alias_pooling), self._bf16_blob if self.precision == 'bf16' else None)

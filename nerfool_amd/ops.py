@@ -281,9 +281,10 @@ def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_r
     return d_rgb_feat
 
 
-def ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias, xyz, cam_ws, feat_shape):
+def ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_raw, anti_alias, xyz, cam_ws, feat_shape,
+                            bf16_blob=None):
     """ibrnet_bwd_mfma + project_gather_bwd in one: d_raw [R,S,4] -> d_featmaps [V,C,Hf,Wf] (channels-last storage); the
-    gradient of rgb_feat never exists in memory."""
+    gradient of rgb_feat never exists in memory.  bf16_blob: the row network on bf16 matrix-core operands."""
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     d_raw, xyz = _c(d_raw, 'd_raw'), _c(xyz, 'xyz')
     R, S, V, _ = rgb_feat.shape
@@ -294,8 +295,8 @@ def ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, 
     d_ws = torch.empty_like(smp)
     d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
     sv, sc, sh, sw = d_feat.stride()
-    with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
-        _done(_lib.lib().nf_ibrnet_bwd_mfma_scatter(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
+    with prof.launch('nf_ibrnet_bwd_mfma_bf16' if bf16_blob is not None else 'nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
+        _done(_lib.lib().nf_ibrnet_bwd_mfma_scatter(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
                                                          _ptr(smp), _ptr(d_raw), R, S, V, int(bool(anti_alias)), _ptr(d_ws), _ptr(xyz),
                                                          _ptr(cam_ws), _ptr(d_feat), sv, sc, sh, sw, Hf, Wf, _stream(d_raw)),
                    'nf_ibrnet_bwd_mfma_scatter')

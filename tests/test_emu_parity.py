@@ -117,6 +117,11 @@ def test_universal_trajectory():
         pc.check_universal_trajectory('cpu', steps=2)      # both target views once; the full loop runs on the GPU
 
 
+def test_bf16_row_network_config5():
+    """BASELINE config 5's shape (V 8, 128 + 256 samples) through the emulated v_mfma_f32_32x32x16_bf16 rows, fused and stand-alone scatter"""
+    pc.check_bf16_config5('cpu')
+
+
 def test_bf16_attack_steps_and_universal_loop():
     """the bf16 row network (emulated v_mfma_f32_32x32x16_bf16) inside PGD steps; the CNN on the nn.Module graph"""
     from nerfool_amd.ibrnet import feature_network
