@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-STAGE_CASES = ['ibrnet_tiny_invu', 'ibrnet_tiny_lin_white', 'ibrnet_tiny_noaa_v5', 'ibrnet_medium']
+STAGE_CASES = ['ibrnet_tiny_invu', 'ibrnet_tiny_lin_white', 'ibrnet_tiny_noaa_v5', 'ibrnet_tiny_v10', 'ibrnet_medium']
 # end-to-end captures only (no per-stage tensors): the medium case and the BASELINE-config-5-shaped one (V = 8, 128 + 128 samples)
 END_TO_END_ONLY = ['ibrnet_medium', 'ibrnet_c5_v8']
 
