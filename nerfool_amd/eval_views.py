@@ -145,16 +145,21 @@ def render_frames(args, model, projector, frames, delta=None, crop_ratio=0.075, 
     return out
 
 
-def evaluate_views(args, model, projector, loader, delta_for=None):
+def evaluate_views(args, model, projector, loader, delta_for=None, shard=None):
     """The loop of eval.py:65-160: running means of PSNR / SSIM over the views of `loader`; `delta_for(data)` (optional) returns
-    the perturbation to apply to that view's source images."""
+    the perturbation to apply to that view's source images.  shard: every view is rendered by all ranks (ray-range sharding); the
+    metrics exist on the rank that receives the images, the others return None."""
     sums, n = {}, 0
     per_view = []
     for data in loader:
-        m = evaluate_view(args, model, projector, data, None if delta_for is None else delta_for(data))
+        m = evaluate_view(args, model, projector, data, None if delta_for is None else delta_for(data), shard=shard)
+        if m is None:
+            continue
         m.pop('ret')
         per_view.append(m)
         for k, v in m.items():
             sums[k] = sums.get(k, 0.0) + v
         n += 1
+    if shard is not None and shard.world > 1 and shard.gather_render_to is not None and shard.rank != shard.gather_render_to:
+        return None
     return {'mean': {k: v / max(n, 1) for k, v in sums.items()}, 'per_view': per_view}

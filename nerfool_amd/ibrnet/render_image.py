@@ -155,12 +155,14 @@ class ShardCollector:
         """-> the reference's return schema on the gathering rank (host tensors), None on the others"""
         shard = self.shard
         dist = shard.dist
-        if self.n_chunks < shard.world:       # some rank rendered nothing and has no schema yet
+        if self.n_chunks < shard.world:       # some rank rendered nothing and has no schema yet (the same test on every rank)
             box = [self.schema if shard.rank == 0 else None]
             dist.broadcast_object_list(box, src=shard.global_rank(0), group=shard.group)
-            if self.schema is None:
+            if self.schema is None and box[0] is not None:
                 self.schema = box[0]
                 self._alloc()
+        if self.schema is None:               # an image without rays: nothing to assemble
+            return OrderedDict([('outputs_coarse', OrderedDict()), ('outputs_fine', OrderedDict())])
         dst = shard.gather_render_to
         full = shard.gather_rows(self.buf, dst)
         if full is None:
