@@ -135,7 +135,8 @@ class ShardCollector:
 
     def _alloc(self):
         width = sum(self._width(s) for _, k, s, _ in self.schema if k is not None and s is not None)
-        self.buf = torch.zeros(self.rows, width, dtype=torch.float32, device=self.device)
+        # (no fill here: chunks arrive on alternating streams, a fill enqueued with the first one could land on top of the second's rows)
+        self.buf = torch.empty(self.rows, width, dtype=torch.float32, device=self.device)
 
     def add(self, i, ret):
         if self.schema is None:
@@ -163,6 +164,9 @@ class ShardCollector:
                 self._alloc()
         if self.schema is None:               # an image without rays: nothing to assemble
             return OrderedDict([('outputs_coarse', OrderedDict()), ('outputs_fine', OrderedDict())])
+        n_mine = max(0, min(self.hi * self.chunk_size, self.n_rays) - self.lo * self.chunk_size)
+        if n_mine < self.rows:
+            self.buf[n_mine:].zero_()         # the padding rows (dropped again on the gathering rank)
         dst = shard.gather_render_to
         full = shard.gather_rows(self.buf, dst)
         if full is None:

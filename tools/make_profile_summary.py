@@ -44,7 +44,7 @@ def main():
               '      -> %(r)s_rocprofv3_kernel_stats_cN.csv, %(r)s_steady_state_kernels_cN.txt (tools/steady_state_kernels.py), %(r)s_step_timeline_cN.txt\n'
               'rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- python3 bench.py [--config cN] --steps 3 --warmup 2 --extras 0 --event-every 0\n'
               'rocprofv3 --pmc WRITE_SIZE --kernel-trace ... -- (same)   -> %(r)s_pmc_traffic_cN.txt (tools/pmc_kernels.py), %(r)s_pmc_traffic.json (c2)\n'
-              'python3 bench.py --config c4 --steps 5 --warmup 2 --render-chunks 2              -> %(r)s_bench_gnt.json\n'
+              'python3 bench.py --config c4 --steps 5 --warmup 2 --render-chunks 4              -> %(r)s_bench_gnt.json\n'
               'python3 bench.py --config c5 [--precision fp32] --steps 10 --warmup 3            -> %(r)s_bench_c5_bf16.json, %(r)s_bench_c5_fp32.json\n'
               'bash tools/pmc_render.sh                                                         -> %(r)s_pmc_render_traffic.txt\n'
               'python3 -m pytest tests -m gpu -q -s | grep ...                                  -> %(r)s_parity_numbers.txt\n'

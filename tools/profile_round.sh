@@ -27,7 +27,7 @@ profile() {   # $1 tag, $2.. bench flags
 profile c2
 profile c4 --config c4
 profile c5 --config c5
-python3 $REPO/bench.py --config c4 --steps 5 --warmup 2 --render-chunks 2 > $OUT/bench_gnt.json 2> $OUT/bench_gnt.err
+python3 $REPO/bench.py --config c4 --steps 5 --warmup 2 --render-chunks 4 > $OUT/bench_gnt.json 2> $OUT/bench_gnt.err
 python3 $REPO/bench.py --config c5 --steps 10 --warmup 3 > $OUT/bench_c5_bf16.json 2> $OUT/bench_c5.err
 python3 $REPO/bench.py --config c5 --precision fp32 --steps 10 --warmup 3 > $OUT/bench_c5_fp32.json 2> $OUT/bench_c5_fp32.err
 bash $REPO/tools/pmc_render.sh > $OUT/pmc_render.log 2>&1; cp $REPO/gpurun_out/pmc_render.txt $OUT/pmc_render_traffic.txt
