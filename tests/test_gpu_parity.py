@@ -1,5 +1,7 @@
 """GPU (MI355X): the parity tests proper.  Everything goes through libnerfool_hip.so (C ABI); the checker is the CPU
 oracle / the reference's golden vectors.  Tolerances are written next to each comparison in parity_cases.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -347,3 +349,85 @@ def test_gnt_full_size_properties():
     rgb_p, _ = ops.gnt_fwd_mfma(mblob, rgb_feat[perm], ray_diff[perm], mask[..., 0][perm], pts[perm], rb['ray_d'][perm], depth,
                                 save=False)
     assert float((rgb_p - rgb_m[perm]).abs().max()) == 0.0                                         # rays are independent
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+from nerfool_amd import eval_adv as EA
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)          # 'nccl' IS RCCL on ROCm
+shard = EA.RayShard(shard_views=True)
+assert (shard.rank, shard.world) == (0, 1)
+V, C, Hf, Wf = 4, 64, 12, 16
+gen = torch.Generator().manual_seed(0)
+# all_gather_into_tensor on the permuted (channels-last) view of the feature maps, reduce_scatter_tensor of their gradient
+local = torch.randn(V, Hf, Wf, C, generator=gen).to(dev).permute(0, 3, 1, 2)
+full = shard.gather_views_nhwc(local, 0, V, V)
+assert torch.equal(full, local) and full.is_contiguous(memory_format=torch.channels_last)
+g = torch.randn(V, Hf, Wf, C, generator=gen).to(dev).permute(0, 3, 1, 2)
+want = g.clone()
+got = shard.scatter_views_nhwc(g, 0, V)
+assert torch.equal(got, want)
+# a slice of the views as the local part
+full2 = shard.gather_views_nhwc(local[:3], 0, 3, 3)
+assert torch.equal(full2, local[:3])
+# d(delta): all-gather of the owners' slices (views sharded) and the plain all-reduce (replicated CNN)
+grad = torch.randn(1, V, 20, 24, 3, generator=gen).to(dev)
+ref = grad.clone()
+assert torch.equal(shard.all_reduce_grad(grad), ref)
+shard.shard_views = False
+assert torch.equal(shard.all_reduce_grad(grad), ref)
+# the 16-byte counts / loss all-reduce
+ret = {'outputs_coarse': {'rgb': torch.rand(7, 3, device=dev), 'mask': torch.ones(7, dtype=torch.bool, device=dev)}, 'outputs_fine': None}
+counts, loss = shard.global_counts_and_loss(ret, {'rgb': torch.rand(7, 3, device=dev)})
+assert float(counts[0]) == 7 and float(loss) > 0
+# image assembly of the sharded render: gather to rank 0 and all-gather
+buf = torch.randn(50, 9, generator=gen).to(dev)
+assert torch.equal(shard.gather_rows(buf, 0)[0], buf) and torch.equal(shard.gather_rows(buf, None)[0], buf)
+box = [{'schema': 1}]
+dist.broadcast_object_list(box, src=0)
+t = torch.ones(3, device=dev)
+dist.broadcast(t, src=0)
+dist.barrier()
+assert shard.collectives == 8, shard.collectives
+# one whole PGD step through the sharded flow (16-byte counts all-reduce, loss normalisation by the global counts, d(delta)
+# all-reduce, broadcast of delta at construction) against the unsharded step on the same rays
+sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import parity_cases as pc
+from nerfool_amd.ibrnet.projection import Projector
+g, args, model, data, sampler, dims = pc._attack_setup('cuda')
+src = sampler.get_all()
+picks = g.np('adam/selected_inds')[0]
+d0 = g.t('in/delta0', 'cuda')
+plain = EA.PGDAttack(args, model, Projector('cuda'), src, delta=d0.clone().requires_grad_(True))
+g_plain = plain.gradient(data, select_inds=picks, lookahead=False).clone()
+for views in (False, True):
+    sh = EA.RayShard(shard_views=views)
+    atk = EA.PGDAttack(args, model, Projector('cuda'), src, shard=sh, delta=d0.clone().requires_grad_(True))
+    g_sh = atk.gradient(data, select_inds=picks, lookahead=False).clone()
+    assert sh.collectives == 2, sh.collectives
+    assert float((g_sh - g_plain).abs().max()) <= 1e-5 * float(g_plain.abs().max())
+    assert abs(float(atk.last_loss) - float(plain.last_loss)) <= 1e-6 * abs(float(plain.last_loss))
+dist.destroy_process_group()
+print('RCCL world-1 collectives OK')
+'''
+
+
+def test_rccl_collectives_on_a_one_rank_group(tmp_path):
+    """Every torch.distributed call of the sharded paths (eval_adv.RayShard, the sharded render) on the RCCL backend itself, on a
+    ONE-rank group -- the only RCCL set-up a single-GPU box allows: init_process_group('nccl', device_id=...), all_gather_into_tensor on
+    the permuted channels-last view, reduce_scatter_tensor, all_reduce, gather into views of one buffer, broadcast(_object_list).
+    The arithmetic across ranks is covered on gloo (tests/test_distributed_gloo.py); this pins the API / layout constraints RCCL has."""
+    import subprocess
+    import sys
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(RCCL_WORKER % dict(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29617', RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'RCCL world-1 collectives OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
