@@ -414,6 +414,23 @@ for views in (False, True):
     assert sh.collectives == 2, sh.collectives
     assert float((g_sh - g_plain).abs().max()) <= 1e-5 * float(g_plain.abs().max())
     assert abs(float(atk.last_loss) - float(plain.last_loss)) <= 1e-6 * abs(float(plain.last_loss))
+# the sharded image assembly (packed per-ray records -> gather -> split -> host) against the single-GPU collector on the same chunks
+from nerfool_amd.ibrnet import render_image as RI
+from nerfool_amd.ibrnet.render_ray import render_rays
+with torch.no_grad():
+    fm = model.feature_net((src['src_rgbs'] + d0).squeeze(0).permute(0, 3, 1, 2))
+    n_rays, chunk = 700, 256                      # three chunks, the last one ragged
+    rb = {k: (v[:n_rays] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in src.items()}
+    cols = [RI.ShardCollector(n_rays, chunk, EA.RayShard(shard_views=False), torch.device('cuda', 0)), RI.HostCollector(n_rays, torch.device('cuda', 0))]
+    for i in range(0, n_rays, chunk):
+        c = {k: (v[i:i + chunk] if k in ('ray_o', 'ray_d', 'rgb') else v) for k, v in rb.items()}
+        ret = render_rays(c, model, fm, Projector('cuda'), args.N_samples, inv_uniform=True, N_importance=args.N_importance, det=True, src_ray_batch=src)
+        for col in cols:
+            col.add(i, ret)
+    a, b = cols[0].finish(7, 100), cols[1].finish(7, 100)
+    for level in ('outputs_coarse', 'outputs_fine'):
+        for k in b[level]:
+            assert a[level][k].dtype == b[level][k].dtype and torch.equal(a[level][k], b[level][k]), (level, k)
 dist.destroy_process_group()
 print('RCCL world-1 collectives OK')
 '''
