@@ -589,8 +589,11 @@ __device__ __forceinline__ f32x16 base0_tile(const float* lds, int lane, int h, 
     return acc;
 }
 
+// rows_forward = rows_forward_early (direction MLP, first pooling, base_fc.0: F, MEAN, VAR, H1a, H1b and the pooling weight w) followed by
+// rows_forward_late (everything behind base_fc.0).  The two-phase backward re-runs the early half instead of keeping its 80
+// registers of activations alive across the late half of the backward.
 template <int V, bool BF>
-__device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, int aa, const RowIn& in, RowActs& a) {
+__device__ __forceinline__ void rows_forward_early(const float* lds, int lane, int h, int aa, const RowIn& in, RowActs& a) {
     const float s_abs = lds[MS_RGB2 + 9];
     // ---- direction MLP 4 -> 16 -> 35, f = rgb_feat + dir_feat   (mlp_network.py:231-233)
     f32x16 d1 = bias_tile(lds, BT_DIR0, h);
@@ -641,6 +644,12 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
     // ---- base_fc.0 (105 -> 64) as two 32-output tiles, base_fc.2 (64 -> 32)
     a.H1a = elu16(base0_tile<BF, 0>(lds, lane, h, a));
     a.H1b = elu16(base0_tile<BF, 1>(lds, lane, h, a));
+}
+
+template <int V, bool BF>
+__device__ __forceinline__ void rows_forward_late(const float* lds, int lane, int h, const RowIn& in, RowActs& a) {
+    const float w = a.w;
+    // ---- base_fc.2 (64 -> 32)
     {
         f32x16 acc = bias_tile(lds, BT_BASE1, h);
         acc = gemm_frag<BF, 16>(lds, MR_BASE1, lane, a.H1a, acc);
@@ -704,6 +713,12 @@ __device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, 
     a.beta = p / grp_sum<V>(p);
 #pragma unroll
     for (int c = 0; c < 3; ++c) a.rgb[c] = grp_sum<V>(a.beta * in.c[c]);
+}
+
+template <int V, bool BF>
+__device__ __forceinline__ void rows_forward(const float* lds, int lane, int h, int aa, const RowIn& in, RowActs& a) {
+    rows_forward_early<V, BF>(lds, lane, h, aa, in, a);
+    rows_forward_late<V, BF>(lds, lane, h, in, a);
 }
 
 template <int V, bool BF, bool GATH>
@@ -785,10 +800,13 @@ __device__ __forceinline__ f32x16 gemm_frag_T(const float* lds, int rec, int lan
 }
 
 // d_feat[r] = d rgb_feat[row][3 + n(r,h)], d_col[c] = d rgb_feat[row][c]
+// rows_backward = rows_backward_late (colour head, second pooling, vis_fc2, vis_fc: -> d h, the gradient w.r.t. base_fc's output BEFORE
+// its ELU) followed by rows_backward_early (base_fc, first pooling: -> d rgb_feat); the late half reads only the late activations,
+// the early half only F, MEAN, H1a, H1b, fc, mc, w, beta.
 template <int V, bool BF>
-__device__ __forceinline__ void rows_backward(const float* lds, int lane, int h, const RowIn& in, const RowActs& a,
-                                              const f32x16& d_mean2, const f32x16& d_var2, float d_wmean,
-                                              const float (&d_rgb)[3], f32x16& d_feat, float (&d_col)[3]) {
+__device__ __forceinline__ void rows_backward_late(const float* lds, int lane, int h, const RowIn& in, const RowActs& a,
+                                                   const f32x16& d_mean2, const f32x16& d_var2, float d_wmean,
+                                                   const float (&d_rgb)[3], f32x16& d_h) {
     // ---- colour head: blend softmax over views, rgb_fc 1 <- 8 <- 16 <- 37
     f32x16 d_x2;
     float d_vis2;
@@ -846,7 +864,6 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
         d_vis1 = half_sum(t);
     }
     // ---- vis_fc (33 <- 32 <- 32) on h * w ; x2 = h + xv[:32]
-    f32x16 d_h;
     {
         float d_logit = d_vis1 * in.mk * a.sig1 * (1.f - a.sig1) * mf_elu_grad(a.logit);
         f32x16 d_xv;
@@ -860,6 +877,11 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
 #pragma unroll
         for (int r = 0; r < 16; ++r) d_h[r] = (d_x2[r] + d_t[r] * a.w) * mf_elu_grad(a.H[r]);
     }
+}
+
+template <int V, bool BF>
+__device__ __forceinline__ void rows_backward_early(const float* lds, int lane, int h, const RowIn& in, const RowActs& a, const f32x16& d_h,
+                                                    const float (&d_rgb)[3], f32x16& d_feat, float (&d_col)[3]) {
     // ---- base_fc (32 <- 64 <- 105)
     f32x16 g_mean, g_var, g_f, g_col;
     {
@@ -906,6 +928,15 @@ __device__ __forceinline__ void rows_backward(const float* lds, int lane, int h,
     }
 }
 
+template <int V, bool BF>
+__device__ __forceinline__ void rows_backward(const float* lds, int lane, int h, const RowIn& in, const RowActs& a,
+                                              const f32x16& d_mean2, const f32x16& d_var2, float d_wmean,
+                                              const float (&d_rgb)[3], f32x16& d_feat, float (&d_col)[3]) {
+    f32x16 d_h;
+    rows_backward_late<V, BF>(lds, lane, h, in, a, d_mean2, d_var2, d_wmean, d_rgb, d_h);
+    rows_backward_early<V, BF>(lds, lane, h, in, a, d_h, d_rgb, d_feat, d_col);
+}
+
 // The scatter of d rgb_feat into the feature-map gradient (autograd of F.grid_sample, ibrnet/projection.py:120-121), fused into
 // the row kernel's output stage: d rgb_feat never goes to memory (north-star design: no rgb_feat round trip on the way back) and
 // the float atomics -- fire and forget -- drain while the matrix work of the next tile runs, where the stand-alone scatter kernel
@@ -929,10 +960,24 @@ struct RowScatter {
 #define RS_TAP 8              // per row: 4 tap weights, x0, y0 (as int bits), view, pad
 #define RS_FLOATS (32 * RS_ROW + 32 * RS_TAP)
 
-// waves per workgroup / workgroups per CU of the backward row kernel: fp32 image (113 KB): 4 x 1; bf16 image (64 KB): 4 x 2, or --
-// with the fused scatter, whose staging tiles leave no room for a second workgroup -- 8 x 1 (two waves per SIMD either way)
-__host__ __device__ constexpr int rows_bwd_waves(bool bf, bool scat) { return (bf && scat) ? 8 : NF_ROWS_BWD_WAVES; }
-__host__ __device__ constexpr int rows_bwd_occ(bool bf, bool scat) { return (bf && !scat) ? 2 : NF_ROWS_BWD_OCC; }
+// Two waves per SIMD in every form of the backward row kernel.  fp32 rows (113 KB weight image, one workgroup per CU): 8-wave
+// workgroups and the TWO-PHASE backward below, which fits 256 registers; bf16 rows (64 KB image): 4-wave workgroups x 2 per CU, or -- with
+// the fused scatter, whose staging tiles leave no room for a second workgroup -- 8 waves x 1.
+#ifndef NF_ROWS_BWD_TWO_PHASE
+#define NF_ROWS_BWD_TWO_PHASE 1
+#endif
+__host__ __device__ constexpr bool rows_bwd_two_phase(bool bf) { return NF_ROWS_BWD_TWO_PHASE && !bf; }
+__host__ __device__ constexpr int rows_bwd_waves(bool bf, bool scat) { return (rows_bwd_two_phase(bf) || (bf && scat)) ? 8 : NF_ROWS_BWD_WAVES; }
+__host__ __device__ constexpr int rows_bwd_occ(bool bf, bool scat) { return (rows_bwd_two_phase(bf) || bf) ? 2 : NF_ROWS_BWD_OCC; }
+__host__ __device__ constexpr int rows_bwd_wgs_per_cu(bool bf, bool scat) { return (bf && !scat) ? 2 : 1; }
+
+// makes a value opaque to the optimiser (the two-phase backward RECOMPUTES the early activations from the laundered inputs: without
+// it the compiler proves them equal to the first evaluation and keeps those registers alive instead)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NF_LAUNDER_F(x) asm volatile("" : "+v"(x))
+#else
+#define NF_LAUNDER_F(x) asm volatile("" : "+x"(x))
+#endif
 
 template <int V, bool BF, bool SCAT, bool GATH>
 __global__ void __launch_bounds__(64 * rows_bwd_waves(BF, SCAT), rows_bwd_occ(BF, SCAT)) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
@@ -959,6 +1004,7 @@ __global__ void __launch_bounds__(64 * rows_bwd_waves(BF, SCAT), rows_bwd_occ(BF
         else load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
         RowActs a;
         rows_forward<V, BF>(lds, lane, h, aa, in, a);
+        if constexpr (rows_bwd_two_phase(BF)) asm volatile("" ::: "memory");       // the 35 gradient values are not fetched above the forward
         const float* g = d_smp + sample * NF_SMP_STRIDE;
         f32x16 d_mean2, d_var2;
 #pragma unroll
@@ -969,7 +1015,26 @@ __global__ void __launch_bounds__(64 * rows_bwd_waves(BF, SCAT), rows_bwd_occ(BF
         float d_rgb[3] = {g[65], g[66], g[67]};
         f32x16 d_feat;
         float d_col[3];
-        rows_backward<V, BF>(lds, lane, h, in, a, d_mean2, d_var2, g[64], d_rgb, d_feat, d_col);
+        if constexpr (rows_bwd_two_phase(BF)) {
+            // late half of the backward on the late activations, then the early half on a RE-EVALUATION of the early activations
+            // (direction MLP, first pooling, base_fc.0: 118 of the forward's 217 matrix instructions): F, MEAN, VAR, H1a, H1b need not
+            // survive the late half, which is what takes the kernel from 391 registers to two waves per SIMD
+            f32x16 d_h;
+            rows_backward_late<V, BF>(lds, lane, h, in, a, d_mean2, d_var2, g[64], d_rgb, d_h);
+            const float beta = a.beta;
+            // the row's inputs are READ AGAIN (L2 hits) rather than kept in 24 registers across the late half; the memory clobber
+            // keeps the compiler from re-using the first loads
+            asm volatile("" ::: "memory");
+            if (rm.pad) pad_row(in);
+            else if (GATH) load_row_gather(gather, nv, row, sample, rm.v, h, live, in);
+            else load_row<V>(rgb_feat, ray_diff, mask, row, h, in);
+            RowActs e;
+            rows_forward_early<V, BF>(lds, lane, h, aa, in, e);
+            e.beta = beta;
+            rows_backward_early<V, BF>(lds, lane, h, in, e, d_h, d_rgb, d_feat, d_col);
+        } else {
+            rows_backward<V, BF>(lds, lane, h, in, a, d_mean2, d_var2, g[64], d_rgb, d_feat, d_col);
+        }
         if (SCAT) {
             // the wave's 32 rows x 32 channels pass through a private LDS tile so that lane = channel afterwards: one atomic
             // instruction then adds 2 rows x 128 contiguous bytes (as the stand-alone kernel does), not 64 scattered floats
@@ -1898,7 +1963,7 @@ static int launch_rows_bwd(const float* wblob, const float* rgb_feat, const floa
     int64_t tiles = (n_samples + 32 / V - 1) / (32 / V);
     int64_t blocks = (tiles + NWV - 1) / NWV;
     // fp32: one workgroup per CU holds the 113 KB weight image (fwd + transposed); bf16: 64 KB, two per CU (one of 8 waves with the scatter)
-    const int64_t cap = rows_bwd_occ(BF, SCAT) == 2 ? 1024 : 512;
+    const int64_t cap = 512 * rows_bwd_wgs_per_cu(BF, SCAT);          // two rounds of resident workgroups
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_ibr_rows_bwd<V, BF, SCAT, GATH>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, wblob, rgb_feat, ray_diff, mask,
                        d_smp, n_samples, nv, aa, d_rgb_feat, sc, ga);
