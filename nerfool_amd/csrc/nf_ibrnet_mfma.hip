@@ -161,6 +161,8 @@ enum {
 static_assert(bf_grp_fwd(MR_RGB0 + 16) == BF_FWD_GROUPS - 1, "forward group count");
 static_assert(bf_grp_bwd(MT_BASE0 + 120) == BF_BWD_GROUPS - 1, "backward group count");
 static_assert(BF_BWD_IN_GAP >= 1 && BF_BWD_IN_GAP < BF_BWD_GROUPS && MS_END % 4 == 0, "bf16 image layout");
+static_assert(MS_BIAS % 4 == 0 && MS_VIS1L % 4 == 0 && MS_VISB1 % 4 == 0 && RYF_FLOATS % 4 == 0 && RY_FLOATS % 4 == 0,
+              "16-byte LDS reads of the VALU tables and of the per-ray K / V rows");
 __host__ __device__ constexpr int bf_fwd_off(int g) { return g * BF_GROUP_FLOATS; }
 __host__ __device__ constexpr int bf_bwd_off(int g) {
     return g < BF_BWD_IN_GAP ? (BF_FWD_GROUPS + g) * BF_GROUP_FLOATS : MS_END + (g - BF_BWD_IN_GAP) * BF_GROUP_FLOATS;
@@ -394,13 +396,18 @@ template <int V>
 __device__ __forceinline__ float grp_max(float x) { return nf_grp_reduce<V>(x, NfMax()); }
 __device__ __forceinline__ float half_sum(float x) { return nf_half_sum(x); }
 
-__device__ __forceinline__ f32x16 bias_tile(const float* lds, int tile, int h) {
+// 16 consecutive floats of a VALU-side table as four 16-byte LDS reads (every table row starts on a multiple of 4 floats): as
+// scalars they become ds_read2_b32 pairs with an address add each
+__device__ __forceinline__ f32x16 lds_row16(const float* b) {
     f32x16 a;
-    const float* b = lds + MS_BIAS + tile * 32 + h * 16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = b[r];
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(b + 4 * q);
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
     return a;
 }
+__device__ __forceinline__ f32x16 bias_tile(const float* lds, int tile, int h) { return lds_row16(lds + MS_BIAS + tile * 32 + h * 16); }
 
 __device__ __forceinline__ bf16x8 pack_bf8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
     bf16x8 b;
@@ -453,9 +460,10 @@ __device__ __forceinline__ f32x16 elu16(f32x16 a) {
 
 // dot of a fragment with an [h][16] VALU vector, summed over both lane halves (all 32 features of the row)
 __device__ __forceinline__ float dot_frag16(const float* vec_h, const f32x16& x) {
+    const f32x16 w = lds_row16(vec_h);
     float d = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d = fmaf(vec_h[r], x[r], d);
+    for (int r = 0; r < 16; ++r) d = fmaf(w[r], x[r], d);
     return half_sum(d);
 }
 
@@ -611,9 +619,11 @@ __device__ __forceinline__ void rows_forward_early(const float* lds, int lane, i
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* wv = lds + MS_DIR1C + c * 16 + h * 8;
+        const float4 wa = *reinterpret_cast<const float4*>(wv), wb = *reinterpret_cast<const float4*>(wv + 4);
+        const float wr[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
         float d = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) d = fmaf(wv[r], d1[r], d);
+        for (int r = 0; r < 8; ++r) d = fmaf(wr[r], d1[r], d);
         d = half_sum(d) + lds[MS_DIR1C + 48 + c];
         a.fc[c] = in.c[c] + mf_elu(d);
     }
@@ -700,9 +710,11 @@ __device__ __forceinline__ void rows_forward_late(const float* lds, int lane, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float* wv = lds + MS_RGB1 + j * 16 + h * 8;
+            const float4 wa = *reinterpret_cast<const float4*>(wv), wb = *reinterpret_cast<const float4*>(wv + 4);
+            const float wr[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
             float t = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) t = fmaf(wv[r], a.r1[r], t);
+            for (int r = 0; r < 8; ++r) t = fmaf(wr[r], a.r1[r], t);
             a.r2[j] = mf_elu(half_sum(t) + lds[MS_RGB1 + 128 + j]);
             y = fmaf(lds[MS_RGB2 + j], a.r2[j], y);
         }
@@ -852,8 +864,9 @@ __device__ __forceinline__ void rows_backward_late(const float* lds, int lane, i
     {
         float d_z2 = d_vis2 * in.mk * a.sig2 * (1.f - a.sig2);
         f32x16 d_u;
+        const f32x16 wvb = lds_row16(lds + MS_VISB1 + h * 16);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d_u[r] = lds[MS_VISB1 + h * 16 + r] * d_z2 * mf_elu_grad(a.U[r]);
+        for (int r = 0; r < 16; ++r) d_u[r] = wvb[r] * d_z2 * mf_elu_grad(a.U[r]);
         f32x16 d_xvis = gemm_frag_T<BF, 16>(lds, MT_VISB0, lane, d_u, zero16());
         float t = 0.f;
 #pragma unroll
@@ -870,9 +883,10 @@ __device__ __forceinline__ void rows_backward_late(const float* lds, int lane, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) d_xv[r] = d_x2[r] * mf_elu_grad(a.XV[r]);
         f32x16 d_v1 = gemm_frag_T<BF, 16>(lds, MT_VIS1, lane, d_xv, zero16());
+        const f32x16 wv1 = lds_row16(lds + MS_VIS1L + h * 16);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            d_v1[r] = fmaf(lds[MS_VIS1L + h * 16 + r], d_logit, d_v1[r]) * mf_elu_grad(a.V1[r]);
+            d_v1[r] = fmaf(wv1[r], d_logit, d_v1[r]) * mf_elu_grad(a.V1[r]);
         f32x16 d_t = gemm_frag_T<BF, 16>(lds, MT_VIS0, lane, d_v1, zero16());
 #pragma unroll
         for (int r = 0; r < 16; ++r) d_h[r] = (d_x2[r] + d_t[r] * a.w) * mf_elu_grad(a.H[r]);
@@ -1550,8 +1564,10 @@ __device__ __forceinline__ void ray_attention(const float* Ks, const float* Vs, 
             float sc[8], bm = -3.0e38f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float* kp = Ks + (k0 + i) * 16 + head * 4;
-                sc[i] = fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0])));
+                // one 16-byte LDS read per key and head (rows are 64 bytes, a head's slice 16: aligned) -- as four scalars the
+                // compiler emits ds_read2_b32 pairs, whose 1 KB offset range costs an address add per read
+                const float4 kv = *reinterpret_cast<const float4*>(Ks + (k0 + i) * 16 + head * 4);
+                sc[i] = fmaf(q3, kv.w, fmaf(q2, kv.z, fmaf(q1, kv.y, q0 * kv.x)));
                 bm = fmaxf(bm, sc[i]);
             }
             if (bm > mx) {                            // the maximum moves: bring the sums to the new reference
@@ -1561,10 +1577,10 @@ __device__ __forceinline__ void ray_attention(const float* Ks, const float* Vs, 
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float* vp = Vs + (k0 + i) * 16 + head * 4;
+                const float4 vv = *reinterpret_cast<const float4*>(Vs + (k0 + i) * 16 + head * 4);
                 const float p = mf_exp(sc[i] - mx);
                 l += p;
-                a0 = fmaf(p, vp[0], a0); a1 = fmaf(p, vp[1], a1); a2 = fmaf(p, vp[2], a2); a3 = fmaf(p, vp[3], a3);
+                a0 = fmaf(p, vv.x, a0); a1 = fmaf(p, vv.y, a1); a2 = fmaf(p, vv.z, a2); a3 = fmaf(p, vv.w, a3);
             }
         }
         float rl = 1.f / l;
@@ -1747,13 +1763,13 @@ __global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd
                 float g0 = d_o[4 * j], g1 = d_o[4 * j + 1], g2 = d_o[4 * j + 2], g3 = d_o[4 * j + 3];
                 const float4 own = *reinterpret_cast<const float4*>(MLD + (s * 4 + head) * 4);
                 float mx = a.mx[j], rl = own.y, D = own.z;
-                for (int k = 0; k < S; ++k) {
-                    const float* kp = Ks + k * 16 + head * 4;
-                    const float* vp = Vs + k * 16 + head * 4;
-                    float p = mf_exp(fmaf(q3, kp[3], fmaf(q2, kp[2], fmaf(q1, kp[1], q0 * kp[0]))) - mx) * rl;
-                    float dA = fmaf(g3, vp[3], fmaf(g2, vp[2], fmaf(g1, vp[1], g0 * vp[0])));
+                for (int k = 0; k < S; ++k) {           // 16-byte LDS reads (see ray_attention)
+                    const float4 kv = *reinterpret_cast<const float4*>(Ks + k * 16 + head * 4);
+                    const float4 vv = *reinterpret_cast<const float4*>(Vs + k * 16 + head * 4);
+                    float p = mf_exp(fmaf(q3, kv.w, fmaf(q2, kv.z, fmaf(q1, kv.y, q0 * kv.x))) - mx) * rl;
+                    float dA = fmaf(g3, vv.w, fmaf(g2, vv.z, fmaf(g1, vv.y, g0 * vv.x)));
                     float dS = p * (dA - D);
-                    a0 = fmaf(dS, kp[0], a0); a1 = fmaf(dS, kp[1], a1); a2 = fmaf(dS, kp[2], a2); a3 = fmaf(dS, kp[3], a3);
+                    a0 = fmaf(dS, kv.x, a0); a1 = fmaf(dS, kv.y, a1); a2 = fmaf(dS, kv.z, a2); a3 = fmaf(dS, kv.w, a3);
                 }
             }
             dq[4 * j] = a0 * 0.5f; dq[4 * j + 1] = a1 * 0.5f; dq[4 * j + 2] = a2 * 0.5f; dq[4 * j + 3] = a3 * 0.5f;
@@ -1761,13 +1777,13 @@ __global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd
             float v0 = a.v[4 * j], v1 = a.v[4 * j + 1], v2 = a.v[4 * j + 2], v3 = a.v[4 * j + 3];
             float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
             for (int qi = 0; qi < S; ++qi) {
-                const float* qp = Qs + qi * 16 + head * 4;
-                const float* gp = Gs + qi * 16 + head * 4;
-                float q0 = qp[0], q1 = qp[1], q2 = qp[2], q3 = qp[3];          // pre-scaled; zero for masked query rows
+                const float4 qv = *reinterpret_cast<const float4*>(Qs + qi * 16 + head * 4);
+                const float4 gv = *reinterpret_cast<const float4*>(Gs + qi * 16 + head * 4);
+                float q0 = qv.x, q1 = qv.y, q2 = qv.z, q3 = qv.w;              // pre-scaled; zero for masked query rows
                 const float4 mld = *reinterpret_cast<const float4*>(MLD + (qi * 4 + head) * 4);
                 float p = mf_exp(fmaf(q3, k3, fmaf(q2, k2, fmaf(q1, k1, q0 * k0))) - mld.x) * mld.y;
-                c0 = fmaf(p, gp[0], c0); c1 = fmaf(p, gp[1], c1); c2 = fmaf(p, gp[2], c2); c3 = fmaf(p, gp[3], c3);
-                float dA = fmaf(gp[3], v3, fmaf(gp[2], v2, fmaf(gp[1], v1, gp[0] * v0)));
+                c0 = fmaf(p, gv.x, c0); c1 = fmaf(p, gv.y, c1); c2 = fmaf(p, gv.z, c2); c3 = fmaf(p, gv.w, c3);
+                float dA = fmaf(gv.w, v3, fmaf(gv.z, v2, fmaf(gv.y, v1, gv.x * v0)));
                 float dS = p * (dA - mld.z);
                 b0 = fmaf(dS, q0, b0); b1 = fmaf(dS, q1, b1); b2 = fmaf(dS, q2, b2); b3 = fmaf(dS, q3, b3);
             }

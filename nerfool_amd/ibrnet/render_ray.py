@@ -62,12 +62,27 @@ def sample_fine_depths(z_vals, weights, N_importance, inv_uniform=False, det=Fal
     return ops.sample_fine(z_vals.detach(), weights.detach(), N_importance, inv_uniform, u)
 
 
+_CAMERA_WS = [None]      # (query camera tensor, source cameras tensor, their versions, workspace) of the last call
+
+
+def _camera_workspace(camera, src_cameras):
+    """ops.camera_setup(camera, src_cameras), remembered while the SAME two tensor objects (unmodified: version counters) come
+    back -- every chunk of an image and every step of an attack on one target view do.  The cache holds the tensors themselves,
+    so their addresses cannot be re-used by other cameras while it is valid."""
+    c = _CAMERA_WS[0]
+    if c is not None and c[0] is camera and c[1] is src_cameras and c[2] == (camera._version, src_cameras._version):
+        return c[3]
+    ws = ops.camera_setup(camera.detach(), src_cameras.detach())
+    _CAMERA_WS[0] = (camera, src_cameras, (camera._version, src_cameras._version), ws)
+    return ws
+
+
 def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo_noise, cams):
     """cams: one-element list caching the camera workspace of this render_rays call (both levels see the same cameras)"""
     can = getattr(net, 'can_gather', None)
     ours = isinstance(projector, Projector)
     if ours and cams[0] is None:
-        cams[0] = ops.camera_setup(ray_batch['camera'].detach(), src['src_cameras'].detach())
+        cams[0] = _camera_workspace(ray_batch['camera'], src['src_cameras'])
     if can is not None and ours and can(featmap, pts.shape[1], src['src_cameras'].shape[1]):
         # projection + bilinear gather run inside the network's row kernel (and their adjoint inside its backward)
         raw, mask = net.forward_gathered(pts, cams[0], src['src_rgbs'][0], featmap)
