@@ -542,33 +542,43 @@ __device__ __forceinline__ void load_row_gather(const RowGather& g, int nv, int6
     bool front;
     nf_project_point(cam, x, y, z, px, py, front);
     const NfTaps tf = nf_bilinear_taps(px, py, qc[0], qc[1], g.Hf, g.Wf);
-    const float* fbase = g.featmap + (int64_t)v * g.fs_v + 4 * h;        // this lane half's channels: 8 q + 4 h + (0 .. 3)
+    // Branch-free taps: a tap outside the map carries weight 0 (nf_bilinear_taps), so it is read from the nearest in-map position
+    // and adds val * 0 -- the same sum as skipping it, without 4 + 4 divergent branches per row.  Addresses are a wave-uniform base
+    // plus a 32-bit element offset (the maps of one level hold < 2^31 floats: checked by the host wrapper).
+    {
+        const int xa = min(max(tf.x0, 0), g.Wf - 1), xb = min(max(tf.x0 + 1, 0), g.Wf - 1);
+        const int ya = min(max(tf.y0, 0), g.Hf - 1), yb = min(max(tf.y0 + 1, 0), g.Hf - 1);
+        const unsigned lane_off = (unsigned)(v * (int)g.fs_v + 4 * h);        // this lane half's channels: 8 q + 4 h + (0 .. 3)
+        const unsigned off[4] = {lane_off + (unsigned)(ya * (int)g.fs_h + xa * (int)g.fs_w), lane_off + (unsigned)(ya * (int)g.fs_h + xb * (int)g.fs_w),
+                                 lane_off + (unsigned)(yb * (int)g.fs_h + xa * (int)g.fs_w), lane_off + (unsigned)(yb * (int)g.fs_h + xb * (int)g.fs_w)};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (tf.in[t]) {
-                const int xx = tf.x0 + (t & 1), yy = tf.y0 + (t >> 1);
-                const float4 val = *reinterpret_cast<const float4*>(fbase + (int64_t)yy * g.fs_h + (int64_t)xx * g.fs_w + 8 * q);
+            for (int t = 0; t < 4; ++t) {
+                const float4 val = *reinterpret_cast<const float4*>(g.featmap + (off[t] + 8u * q));
                 acc.x = acc.x + val.x * tf.w[t];
                 acc.y = acc.y + val.y * tf.w[t];
                 acc.z = acc.z + val.z * tf.w[t];
                 acc.w = acc.w + val.w * tf.w[t];
             }
+            in.feat[4 * q + 0] = acc.x;
+            in.feat[4 * q + 1] = acc.y;
+            in.feat[4 * q + 2] = acc.z;
+            in.feat[4 * q + 3] = acc.w;
         }
-        in.feat[4 * q + 0] = acc.x;
-        in.feat[4 * q + 1] = acc.y;
-        in.feat[4 * q + 2] = acc.z;
-        in.feat[4 * q + 3] = acc.w;
     }
     const NfTaps ti = nf_bilinear_taps(px, py, qc[0], qc[1], g.H, g.W);
-    const float* ibase = g.src_rgbs + (int64_t)v * g.H * g.W * 3;
     float r = 0.f, gg = 0.f, b = 0.f;
+    {
+        const int xa = min(max(ti.x0, 0), g.W - 1), xb = min(max(ti.x0 + 1, 0), g.W - 1);
+        const int ya = min(max(ti.y0, 0), g.H - 1), yb = min(max(ti.y0 + 1, 0), g.H - 1);
+        const unsigned img = (unsigned)(v * g.H * g.W);
+        const unsigned off[4] = {3u * (img + (unsigned)(ya * g.W + xa)), 3u * (img + (unsigned)(ya * g.W + xb)),
+                                 3u * (img + (unsigned)(yb * g.W + xa)), 3u * (img + (unsigned)(yb * g.W + xb))};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (ti.in[t]) {
-            const float* p = ibase + ((int64_t)(ti.y0 + (t >> 1)) * g.W + (ti.x0 + (t & 1))) * 3;
+        for (int t = 0; t < 4; ++t) {
+            const float* p = g.src_rgbs + off[t];
             r = r + p[0] * ti.w[t];
             gg = gg + p[1] * ti.w[t];
             b = b + p[2] * ti.w[t];
@@ -1942,6 +1952,8 @@ extern "C" int nf_ibrnet_fwd_mfma_gather(const float* bf16_blob, const float* mf
     if (n_rays == 0) return 0;
     NF_REQUIRE(xyz && cam_ws && src_rgbs && featmap && mask_out && H >= 1 && W >= 1 && Hf >= 1 && Wf >= 1,
                "nf_ibrnet_fwd_mfma_gather: bad arguments");
+    NF_REQUIRE((int64_t)n_views * fs_v < ((int64_t)1 << 31) && (int64_t)n_views * H * W * 3 < ((int64_t)1 << 31),
+               "nf_ibrnet_fwd_mfma_gather: feature maps / source images too large for 32-bit element offsets");
     NF_REQUIRE(fs_c == 1 && fs_v % 4 == 0 && fs_h % 4 == 0 && fs_w % 4 == 0 && ((uintptr_t)featmap) % 16 == 0,
                "nf_ibrnet_fwd_mfma_gather: the feature maps must be channels-last with 16-byte aligned pixel records");
     const RowGather g = {xyz, cam_ws, src_rgbs, featmap, mask_out, fs_v, fs_h, fs_w, H, W, Hf, Wf};

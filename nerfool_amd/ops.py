@@ -231,7 +231,7 @@ def ibrnet_gather_layout_ok(featmaps):
     """the layout the gather-fused forward reads: 32 channels, channels-last, 16-byte aligned pixel records"""
     sv, sc, sh, sw = featmaps.stride()
     return (featmaps.dim() == 4 and featmaps.shape[1] == 32 and featmaps.dtype == torch.float32 and sc == 1 and sv % 4 == 0 and sh % 4 == 0
-            and sw % 4 == 0 and featmaps.data_ptr() % 16 == 0)
+            and sw % 4 == 0 and featmaps.data_ptr() % 16 == 0 and featmaps.shape[0] * sv < 2 ** 31)       # 32-bit element offsets
 
 
 def ibrnet_fwd_mfma_gather(mfma_blob, blob, pos_enc, xyz, cam_ws, src_rgbs, featmaps, anti_alias, bf16_blob=None):
