@@ -61,18 +61,29 @@ NF_HD bool nf_inbound(float px, float py, float h, float w) {
 }
 
 // ref: ibrnet/projection.py:72-85.  cq/cv: query / source camera centres.  out[0..2] unit difference, out[3] dot.
+// The three normalisations multiply by ONE reciprocal each (v_rcp_f32, 1 ulp) instead of dividing three times (an IEEE division is
+// a ten-instruction sequence on the vector pipe, and vector instructions are paid in matrix-pipe time): the direction features move by
+// <= 2 ulp, which feeds a continuous MLP -- unlike the projection and the tap positions above / below, whose divisions stay exact because
+// they decide masks and tap indices.
+NF_HD float nf_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.f / x;
+#endif
+}
 NF_HD void nf_ray_diff(const float* cq, const float* cv, float x, float y, float z, float* out) {
     float tx = cq[0] - x, ty = cq[1] - y, tz = cq[2] - z;
-    float tn = sqrtf(tx * tx + ty * ty + tz * tz) + 1e-6f;
-    tx = tx / tn; ty = ty / tn; tz = tz / tn;
+    const float rt = nf_rcp(sqrtf(tx * tx + ty * ty + tz * tz) + 1e-6f);
+    tx = tx * rt; ty = ty * rt; tz = tz * rt;
     float sx = cv[0] - x, sy = cv[1] - y, sz = cv[2] - z;
-    float sn = sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f;
-    sx = sx / sn; sy = sy / sn; sz = sz / sn;
+    const float rs = nf_rcp(sqrtf(sx * sx + sy * sy + sz * sz) + 1e-6f);
+    sx = sx * rs; sy = sy * rs; sz = sz * rs;
     float dx = tx - sx, dy = ty - sy, dz = tz - sz;
-    float dn = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f);
-    out[0] = dx / dn;
-    out[1] = dy / dn;
-    out[2] = dz / dn;
+    const float rd = nf_rcp(fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-6f));
+    out[0] = dx * rd;
+    out[1] = dy * rd;
+    out[2] = dz * rd;
     out[3] = tx * sx + ty * sy + tz * sz;
 }
 
