@@ -38,6 +38,16 @@ static inline int nf_current_device() {
     return d;
 }
 
+// 1 / x as ONE vector instruction (v_rcp_f32, 1 ulp) where the result feeds continuous arithmetic; x / y stays an IEEE division (a
+// ten-instruction sequence) wherever it decides a mask, an index or a bin
+NF_HD float nf_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.f / x;
+#endif
+}
+
 static inline unsigned nf_blocks(int64_t work, int per_block) { return (unsigned)((work + per_block - 1) / per_block); }
 
 // wave64 butterflies (all 64 lanes must call)

@@ -65,13 +65,6 @@ NF_HD bool nf_inbound(float px, float py, float h, float w) {
 // a ten-instruction sequence on the vector pipe, and vector instructions are paid in matrix-pipe time): the direction features move by
 // <= 2 ulp, which feeds a continuous MLP -- unlike the projection and the tap positions above / below, whose divisions stay exact because
 // they decide masks and tap indices.
-NF_HD float nf_rcp(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_rcpf(x);
-#else
-    return 1.f / x;
-#endif
-}
 NF_HD void nf_ray_diff(const float* cq, const float* cv, float x, float y, float z, float* out) {
     float tx = cq[0] - x, ty = cq[1] - y, tz = cq[2] - z;
     const float rt = nf_rcp(sqrtf(tx * tx + ty * ty + tz * tz) + 1e-6f);

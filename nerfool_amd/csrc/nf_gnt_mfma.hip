@@ -603,7 +603,12 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) u.t[t][r] = acc.t[t][r] / sum.t[t][r];
+                for (int r = 0; r < 16; ++r) {
+                    // one reciprocal per channel (v_rcp_f32, 1 ulp), re-used by the V normalised weights below: an IEEE division is a
+                    // ten-instruction vector sequence, and this block divides 32 (V + 1) times per sample and layer
+                    sum.t[t][r] = nf_rcp(sum.t[t][r]);
+                    u.t[t][r] = acc.t[t][r] * sum.t[t][r];
+                }
             if (sv) {       // the backward wants the normalised attention weights where the raw logits were parked
                 for (int v = 0; v < V; ++v)
 #pragma unroll
@@ -611,7 +616,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             float* pp = gm_row_at(c, lr + RWL_PROB + 32 * t + gm_nidx(r, 0), v) + c.row_lane;
-                            *pp = __expf(*pp - mx.t[t][r]) / sum.t[t][r];
+                            *pp = __expf(*pp - mx.t[t][r]) * sum.t[t][r];
                         }
             }
             const V64 o = gm_lin64_s(w, tb + MB_VOUT, lane, h, u);
@@ -721,8 +726,9 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                     gm_smp_at(c, ls + SL_ML + hd)[c.s] = mxh;
                     gm_smp_at(c, ls + SL_ML + 4 + hd)[c.s] = l;
                 }
+                const float rl = nf_rcp(l);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) att.t[hd >> 1][8 * (hd & 1) + j] = o[j] / l;
+                for (int j = 0; j < 8; ++j) att.t[hd >> 1][8 * (hd & 1) + j] = o[j] * rl;
             }
             __syncthreads();        // K / V of this layer are dead: the next layer may overwrite the LDS image
             if (sv) gm_store_smp(c, ls + SL_OUTA, att);
