@@ -409,6 +409,24 @@ __device__ __forceinline__ f32x16 lds_row16(const float* b) {
 }
 __device__ __forceinline__ f32x16 bias_tile(const float* lds, int tile, int h) { return lds_row16(lds + MS_BIAS + tile * 32 + h * 16); }
 
+// A 16-register fragment <-> 32 consecutive floats in memory (feature n(r, h) at base[n]): registers 4 q .. 4 q + 3 of lane half h are the
+// four CONSECUTIVE features 8 q + 4 h + (0 .. 3), so a fragment is four 16-byte accesses instead of sixteen 4-byte ones (base 16-byte
+// aligned: the per-sample records are 288 bytes apart).  A lane's record is 288 bytes from its neighbour's: every access instruction touches
+// 32 cache lines either way, so the instruction count is what the texture path pays for.
+__device__ __forceinline__ f32x16 frag_load32(const float* base, int h) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(base + 8 * q + 4 * h);
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+    return a;
+}
+__device__ __forceinline__ void frag_store32(float* base, int h, const f32x16& a) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(base + 8 * q + 4 * h) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+}
+
 __device__ __forceinline__ bf16x8 pack_bf8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
     bf16x8 b;
     b[0] = (__bf16)v0; b[1] = (__bf16)v1; b[2] = (__bf16)v2; b[3] = (__bf16)v3;
@@ -772,16 +790,10 @@ __global__ void __launch_bounds__(64 * NF_ROWS_FWD_WAVES, NF_ROWS_FWD_OCC) k_ibr
         // per-sample record; the lane holding view 0 writes (both lane halves, 16 features each)
         float* out = smp + sample * NF_SMP_STRIDE;
         if (rm.live && v == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                out[nf_nidx(r, h)] = a.MEAN2[r];
-                out[32 + nf_nidx(r, h)] = a.VAR2[r];
-            }
+            frag_store32(out, h, a.MEAN2);
+            frag_store32(out + 32, h, a.VAR2);
             if (h == 0) {
-                out[64] = a.wmean;
-                out[65] = a.rgb[0];
-                out[66] = a.rgb[1];
-                out[67] = a.rgb[2];
+                *reinterpret_cast<float4*>(out + 64) = make_float4(a.wmean, a.rgb[0], a.rgb[1], a.rgb[2]);
                 out[68] = a.nval;
                 out[69] = a.vsum;
             }
@@ -1031,11 +1043,8 @@ __global__ void __launch_bounds__(64 * rows_bwd_waves(BF, SCAT), rows_bwd_occ(BF
         if constexpr (rows_bwd_two_phase(BF)) asm volatile("" ::: "memory");       // the 35 gradient values are not fetched above the forward
         const float* g = d_smp + sample * NF_SMP_STRIDE;
         f32x16 d_mean2, d_var2;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            d_mean2[r] = g[nf_nidx(r, h)];
-            d_var2[r] = g[32 + nf_nidx(r, h)];
-        }
+        d_mean2 = frag_load32(g, h);
+        d_var2 = frag_load32(g + 32, h);
         float d_rgb[3] = {g[65], g[66], g[67]};
         f32x16 d_feat;
         float d_col[3];
@@ -1518,12 +1527,9 @@ __device__ __forceinline__ f32x16 ray_gemm8(const float* rs, int rec, int lane, 
 // per-sample forward up to q/k/v (rs = LDS pointer to the ray section)
 __device__ __forceinline__ void ray_forward_a(const float* rs, int lane, int h, const float* __restrict__ rec,
                                               const float* __restrict__ pe, RayActs& a) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        a.MEAN2[r] = rec[nf_nidx(r, h)];
-        a.VAR2[r] = rec[32 + nf_nidx(r, h)];
-    }
-    a.wmean = rec[64];
+    a.MEAN2 = frag_load32(rec, h);
+    a.VAR2 = frag_load32(rec + 32, h);
+    a.wmean = rec[64];          // (the colours at 65 .. 67 go straight to the output, see the kernel)
     a.nval = rec[68];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -1600,6 +1606,70 @@ __device__ __forceinline__ void ray_attention(const float* Ks, const float* Vs, 
     }
 }
 
+// The same attention with the lane's TWO heads (h and h + 2) carried side by side in packed registers: every multiply-add of a key is one
+// v_pk_fma_f32 for both heads, the exponent arguments one v_pk_add / v_pk_mul -- 15 vector instructions per key where the scalar form
+// above issues ~28 (vector instructions are paid in matrix-pipe time).  Kp / Vp: [S][16] with the two heads of a lane half INTERLEAVED,
+// position 8 h + 2 d + j for head h + 2 j, dimension d (ray_kv_slot), so that one 16-byte read delivers (d0: both heads, d1: both heads).
+// Element for element the arithmetic of ray_attention (same fma chains, same block-wise running maximum, v_exp_f32 of the same
+// argument), except that a head whose maximum did not move is rescaled by exp(0) = 1 instead of being skipped.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ constexpr int ray_kv_slot(int r, int h) { return 8 * h + 2 * (r & 3) + (r >> 2); }       // fragment register r of lane half h
+__device__ __forceinline__ f32x2 nf_exp2x2(f32x2 x) {      // 2^x per element
+#if defined(__HIP_DEVICE_COMPILE__)
+    return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+#else
+    return f32x2{exp2f(x.x), exp2f(x.y)};
+#endif
+}
+__device__ __forceinline__ void ray_attention_pk(const float* Kp, const float* Vp, int S, int h, RayActs& a) {
+    const bool row_on = a.nval > 1.f;
+    const f32x2 log2e = {1.44269502f, 1.44269502f};          // 0x3fb8aa3b: the constant __expf multiplies by
+    f32x2 q[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) q[d] = row_on ? f32x2{a.q[d] * 0.5f, a.q[4 + d] * 0.5f} : f32x2{0.f, 0.f};
+    f32x2 mx = {-3.0e38f, -3.0e38f}, l = {0.f, 0.f}, acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < S; k0 += 8) {          // S is a multiple of 32
+        f32x2 sc[8], bm = mx;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 ka = *reinterpret_cast<const float4*>(Kp + (k0 + i) * 16 + 8 * h);
+            const float4 kb = *reinterpret_cast<const float4*>(Kp + (k0 + i) * 16 + 8 * h + 4);
+            f32x2 t = q[0] * f32x2{ka.x, ka.y};
+            t = __builtin_elementwise_fma(q[1], f32x2{ka.z, ka.w}, t);
+            t = __builtin_elementwise_fma(q[2], f32x2{kb.x, kb.y}, t);
+            t = __builtin_elementwise_fma(q[3], f32x2{kb.z, kb.w}, t);
+            sc[i] = t;
+            bm = __builtin_elementwise_max(bm, t);
+        }
+        // bring the sums to the block's reference (exp(0) = 1 for a head whose maximum stays; first block: exp(-3e38) = 0 on zero sums)
+        const f32x2 rsc = nf_exp2x2((mx - bm) * log2e);
+        l = l * rsc;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[d] = acc[d] * rsc;
+        mx = bm;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 va = *reinterpret_cast<const float4*>(Vp + (k0 + i) * 16 + 8 * h);
+            const float4 vb = *reinterpret_cast<const float4*>(Vp + (k0 + i) * 16 + 8 * h + 4);
+            const f32x2 p = nf_exp2x2((sc[i] - mx) * log2e);
+            l = l + p;
+            acc[0] = __builtin_elementwise_fma(p, f32x2{va.x, va.y}, acc[0]);
+            acc[1] = __builtin_elementwise_fma(p, f32x2{va.z, va.w}, acc[1]);
+            acc[2] = __builtin_elementwise_fma(p, f32x2{vb.x, vb.y}, acc[2]);
+            acc[3] = __builtin_elementwise_fma(p, f32x2{vb.z, vb.w}, acc[3]);
+        }
+    }
+    const f32x2 rl = {1.f / l.x, 1.f / l.y};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const f32x2 o = acc[d] * rl;
+        a.o[d] = o.x;
+        a.o[4 + d] = o.y;
+    }
+    a.mx[0] = mx.x; a.mx[1] = mx.y;
+    a.l[0] = l.x; a.l[1] = l.y;
+}
+
 // fc + residual, LayerNorm (eps 1e-6), out_geometry_fc -> sigma
 __device__ __forceinline__ float ray_forward_b(const float* rs, int lane, int h, RayActs& a) {
     f32x16 pre = ray_gemm8<8>(rs, RYR_FC, lane, a.o, zero16());
@@ -1657,16 +1727,17 @@ __global__ void __launch_bounds__(WPR > 4 ? 64 * WPR : 256, 2) k_ibr_ray_fwd_mfm
         float* Ks = kv + (wave / WPR) * (S * 32);
         float* Vs = Ks + S * 16;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            Ks[s * 16 + nf_nidx(r, h)] = a.k[r];
-            Vs[s * 16 + nf_nidx(r, h)] = a.v[r];
+        for (int r = 0; r < 8; ++r) {              // the two heads of a lane half interleaved: ray_attention_pk
+            Ks[s * 16 + ray_kv_slot(r, h)] = a.k[r];
+            Vs[s * 16 + ray_kv_slot(r, h)] = a.v[r];
         }
         __syncthreads();
-        ray_attention(Ks, Vs, S, h, a);
+        ray_attention_pk(Ks, Vs, S, h, a);
         float sigma = ray_forward_b(rs, lane, h, a);
         if (live && h == 0) {
             float* ro = raw + (ray * S + s) * 4;
-            ro[0] = rec[65]; ro[1] = rec[66]; ro[2] = rec[67]; ro[3] = sigma;
+            const float4 tail = *reinterpret_cast<const float4*>(rec + 64);          // wmean | rgb
+            *reinterpret_cast<float4*>(ro) = make_float4(tail.y, tail.z, tail.w, sigma);
         }
         __syncthreads();      // K/V of this iteration are dead before the next one overwrites them
     }
@@ -1827,11 +1898,8 @@ __global__ void __launch_bounds__(64 * (WPR > NWV ? WPR : NWV), 1) k_ibr_ray_bwd
         f32x16 d_var2 = ray_gemm_T<16>(rs, RYT_GEO0 + 48, lane, d_g1b, ray_gemm_T<16>(rs, RYT_GEO0 + 32, lane, d_g1a, zero16()));
         if (live) {
             float* out = d_smp + (ray * S + s) * NF_SMP_STRIDE;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                out[nf_nidx(r, h)] = d_mean2[r];
-                out[32 + nf_nidx(r, h)] = d_var2[r];
-            }
+            frag_store32(out, h, d_mean2);
+            frag_store32(out + 32, h, d_var2);
             if (h == 0) {
                 out[64] = dw;
                 out[65] = graw[0];
@@ -1899,7 +1967,7 @@ static int ibrnet_fwd_impl(const char* who, const float* bf_blob, const float* m
     if (n_samples == 32 || n_samples == 64 || n_samples == 128 || n_samples == 256) {       // per-ray part on the matrix cores as well
         const int wpr = n_samples / 32, nw = wpr > 4 ? wpr : 4, rpi = nw / wpr;
         int64_t iters = (n_rays + rpi - 1) / rpi;
-        unsigned blocks = (unsigned)(iters < 768 ? iters : 768);
+        unsigned blocks = (unsigned)(iters < 768 ? iters : 768);        // three workgroups per CU (512 and 1024 measured 8 % slower)
         size_t smem_ray = (size_t)(RYF_FLOATS + nw * 32 * 32) * sizeof(float);
         if (wpr == 1)
             hipLaunchKernelGGL(k_ibr_ray_fwd_mfma<1>, dim3(blocks), dim3(256), smem_ray, st, mfma_blob, pos_enc, workspace, n_rays, raw);

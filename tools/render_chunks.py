@@ -1,6 +1,6 @@
 """Forward-only rendering of 4096-ray chunks (800x800, V = 4, 64 samples coarse only) -- the program profiled with rocprofv3 --pmc
 for the HBM traffic of the render path with and without the gather fused into the row kernel.
-usage: python tools/render_chunks.py [chunks] [fused|separate]"""
+usage: python tools/render_chunks.py [chunks] [fused|separate] [library.so]"""
 import argparse
 import os
 import sys
@@ -15,6 +15,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     from nerfool_amd.ibrnet import mlp_network
     mlp_network.GATHER_BWD_FUSION = sys.argv[2] if len(sys.argv) > 2 else 'fused'
+    if len(sys.argv) > 3:          # a tuning build (tools/build_variant.sh)
+        from nerfool_amd import _lib
+        _lib.use_library_for_tests(sys.argv[3], emulated=False)
     a = argparse.Namespace(gpus=1, steps=1, warmup=0, n_rand=512, height=800, width=800, views=4, samples=64, importance=0, render_chunks=n,
                            model='ibrnet', config='c2', precision='fp32', depth=8, cnn_shard='replicated', scaling='weak', cpu_iters=0, extras=0)
     dev = torch.device('cuda', 0)
