@@ -243,12 +243,29 @@ __device__ __forceinline__ g16 gm_zero() {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
     return a;
 }
-__device__ __forceinline__ g16 gm_tile(const float* __restrict__ tb, int h) {      // one [h][16] tile of a table
+__device__ __forceinline__ g16 gm_tile(const float* __restrict__ tb, int h) {      // one [h][16] tile of a table (16-byte aligned)
     g16 a;
-    const float* b = tb + h * 16;
+    const float4* b = reinterpret_cast<const float4*>(tb + h * 16);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = b[r];
+    for (int q = 0; q < 4; ++q) {
+        const float4 x = b[q];
+        a[4 * q] = x.x; a[4 * q + 1] = x.y; a[4 * q + 2] = x.z; a[4 * q + 3] = x.w;
+    }
     return a;
+}
+// ---- LDS parking of a wave's own V64 (lane-private values, [t][q][lane][4]: 16-byte accesses of consecutive lanes)
+#define GM_PARK_FLOATS 2048
+__device__ __forceinline__ void gm_park4(float* p, int lane, int t, int q, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p + ((t * 4 + q) * 64 + lane) * 4) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ float4 gm_parked4(const float* p, int lane, int t, int q) {
+    return *reinterpret_cast<const float4*>(p + ((t * 4 + q) * 64 + lane) * 4);
+}
+__device__ __forceinline__ void gm_park(float* p, int lane, const V64& x) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gm_park4(p, lane, t, q, x.t[t][4 * q], x.t[t][4 * q + 1], x.t[t][4 * q + 2], x.t[t][4 * q + 3]);
 }
 // the two lane halves swap through v_permlane32_swap (nf_common.h): no LDS round trip
 __device__ __forceinline__ float gm_half_sum(float x) { return nf_half_sum(x); }
@@ -429,12 +446,29 @@ __device__ __forceinline__ V64 gm_ff(const GmCtx& c, GmW& w, const float* __rest
 
 // LDS image of a ray's keys / values as MFMA A-operand records
 #define GM_VT_STRIDE 65      // odd record stride: the transposing V^T writes of a wave spread over the banks
+// In front of it: the layer's small records (pos_fc, attn_fc.2) and its bias / LayerNorm tables -- read inside the view loop, where a
+// load from L2 would sit fully exposed (one wave per SIMD).  The K / V^T image is dead while the views are walked: each wave
+// parks ITS q and v + pos there (2 x GM_PARK_FLOATS).
+#define GM_TAB_REC (18 * 64)
+#define GM_TAB_FLOATS (GM_TAB_REC + MB_FLOATS)
 template <int NW> struct GmLds {
     static constexpr int K_FLOATS = 4 * NW * 8 * 64;
     static constexpr int VT_FLOATS = 4 * NW * 16 * GM_VT_STRIDE;
     static constexpr int RED_FLOATS = NW * 4;
-    static constexpr int FLOATS = K_FLOATS + VT_FLOATS + RED_FLOATS;
+    static constexpr int FLOATS = GM_TAB_FLOATS + K_FLOATS + VT_FLOATS + RED_FLOATS;
+    static_assert(K_FLOATS + VT_FLOATS >= NW * 2 * GM_PARK_FLOATS, "the parked q / v + pos alias the K / V^T image");
 };
+// a wave-uniform zero the optimiser cannot see through: added to a table pointer inside the view loop it keeps the loop-invariant
+// table reads -- 178 registers' worth -- from being hoisted out of the loop and spilled
+__device__ __forceinline__ int gm_opaque_zero() {
+    int z = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(z));
+#else
+    asm volatile("" : "+r"(z));
+#endif
+    return z;
+}
 
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restrict__ wb, const float* __restrict__ rgb_feat_all,
@@ -444,12 +478,15 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                                                           int64_t row_floats, int64_t smp_floats, float* __restrict__ alpha_out) {
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int S = 32 * NW;
-    float* Kl = lds;
-    float* Vl = lds + GmLds<NW>::K_FLOATS;
+    float* tab = lds;
+    float* Kl = lds + GM_TAB_FLOATS;
+    float* Vl = Kl + GmLds<NW>::K_FLOATS;
     float* red = Vl + GmLds<NW>::VT_FLOATS;
     const int64_t ray = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 31, h = lane >> 5;
+    float* Qp = Kl + wave * 2 * GM_PARK_FLOATS;       // view phase: this wave's q | v + pos
+    float* VPp = Qp + GM_PARK_FLOATS;
     GmCtx c;
     c.S = S; c.V = V; c.s = wave * 32 + m; c.h = h;
     c.smp_lane = (unsigned)(4 * h * S + c.s);
@@ -520,20 +557,28 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
     gm_w_start(w, wb + gm_layer_base(0) + MG_STREAM * 64, lane);
     for (int i = 0; i < depth; ++i) {
         const float* Lbase = wb + gm_layer_base(i);
-        const float* tbase = Lbase + (size_t)MG_LAYER_RECORDS * 64;
-        const float* L = Lbase;
-        const float* tb = tbase;
         const float* Lst = Lbase + MG_STREAM * 64;                                        // this layer's stream
         const float* next_stream = i + 1 < depth ? wb + gm_layer_base(i + 1) + MG_STREAM * 64 : nullptr;
         const int ls = SW_BASE + (sv ? i : 0) * SW_LAYER;
         const int lr = RW_BASE + (sv ? i : 0) * RW_LAYER;
+        // ---- the layer's small records and tables -> LDS (the previous layer's are dead behind the first barrier)
+        __syncthreads();
+        {
+            const float4* src_rec = reinterpret_cast<const float4*>(Lbase);
+            const float4* src_tab = reinterpret_cast<const float4*>(Lbase + (size_t)MG_LAYER_RECORDS * 64);
+            float4* dst = reinterpret_cast<float4*>(tab);
+            for (int k = threadIdx.x; k < GM_TAB_REC / 4; k += 64 * NW) dst[k] = src_rec[k];
+            for (int k = threadIdx.x; k < MB_FLOATS / 4; k += 64 * NW) dst[GM_TAB_REC / 4 + k] = src_tab[k];
+        }
+        __syncthreads();
+        const float* tb = tab + GM_TAB_REC;
         // ================= view transformer =================
         {
             V64 y = gm_layernorm(c, cur, tb + MB_LN, tb + MB_LN + 64, 1e-6f, sv, ls + SL_XH1, ls + SL_RSTD1);
-            // the running state of the online softmax needs 96 registers: the residual stream and Q wait in the (L2-resident)
-            // workspace while the views are walked
+            // the running state of the online softmax needs 96 registers: the residual stream waits in the (L2-resident)
+            // workspace and Q in this wave's LDS slab while the views are walked
             gm_store_smp(c, SW_CUR, cur);
-            gm_store_smp(c, SW_QV, gm_lin64_s(w, nullptr, lane, h, y));
+            gm_park(Qp, lane, gm_lin64_s(w, nullptr, lane, h, y));
             V64 mx, sum, acc;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -543,21 +588,23 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                     sum.t[t][r] = 0.f;
                     acc.t[t][r] = 0.f;
                 }
+            // X_v, the view's ray difference and mask are fetched one view ahead (issued in front of the softmax arithmetic of
+            // the previous view, which covers their HBM latency)
+            V64 X = gm_load_row(c, RW_X, 0);
+            float rd0 = ray_diff[(size_t)c.s * V * 4 + h], rd1 = ray_diff[(size_t)c.s * V * 4 + 2 + h];
+            float mk = mask[(size_t)c.s * V];
             for (int v = 0; v < V; ++v) {
-                const float* L = Lbase;
-                const float* tb = tbase;
-                GM_LAUNDER(L);
-                GM_LAUNDER(tb);
-                // register budget: the running softmax state (96) stays live across the views, so V + pos is parked in its
-                // workspace slot (the backward wants it there anyway) and Q is read per element instead of held
+                const int oz = gm_opaque_zero();
+                const float* L = tab + oz;
+                const float* tb = tab + GM_TAB_REC + oz;
+                // register budget: the running softmax state (96) stays live across the views, so V + pos is parked in LDS
+                // (and stored for the backward) and Q is read back per four channels instead of held
                 V64 T2;
                 {
-                    const V64 X = gm_load_row(c, RW_X, v);
                     const V64 K = gm_lin64_s(w, nullptr, lane, h, X);
-                    const float* rd = ray_diff + ((size_t)c.s * V + v) * 4;
                     g16 rin = gm_zero();
-                    rin[0] = rd[h];
-                    rin[1] = rd[2 + h];
+                    rin[0] = rd0;
+                    rin[1] = rd1;
                     g16 h0 = gm_gemm<2>(L + MG_POS0 * 64, lane, rin, gm_tile(tb + MB_POS0, h));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) h0[r] = fmaxf(h0[r], 0.f);
@@ -566,10 +613,18 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                     for (int t = 0; t < 2; ++t) {
                         const g16 pos = gm_gemm<4>(L + (MG_POS2 + 4 * t) * 64, lane, h0, gm_tile(tb + MB_POS2 + t * 32, h));
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int f0 = 32 * t + gm_nidx(r, 0);
-                            gm_row_at(c, lr + RWL_VP + f0, v)[c.row_lane] = Vv.t[t][r] + pos[r];
-                            T2.t[t][r] = K.t[t][r] - gm_smp_at(c, SW_QV + f0)[c.smp_lane] + pos[r];      // k - q + pos
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 qv = gm_parked4(Qp, lane, t, q);
+                            const float qq[4] = {qv.x, qv.y, qv.z, qv.w};
+                            float vp[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 4 * q + e;
+                                vp[e] = Vv.t[t][r] + pos[r];
+                                if (sv) gm_row_at(c, lr + RWL_VP + 32 * t + gm_nidx(r, 0), v)[c.row_lane] = vp[e];
+                                T2.t[t][r] = K.t[t][r] - qq[e] + pos[r];      // k - q + pos
+                            }
+                            gm_park4(VPp, lane, t, q, vp[0], vp[1], vp[2], vp[3]);
                         }
                     }
                 }
@@ -581,21 +636,33 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
 #pragma unroll
                     for (int r = 0; r < 4; ++r) gm_row_at(c, lr + RWL_H + r, v)[c.row_lane] = hid[r];
                 }
-                const float mk = mask[(size_t)c.s * V + v];
+                const float mk_v = mk;
+                {   // the next view's inputs (the last view re-reads itself)
+                    const int vn = v + 1 < V ? v + 1 : v;
+                    X = gm_load_row(c, RW_X, vn);
+                    const float* rd = ray_diff + ((size_t)c.s * V + vn) * 4;
+                    rd0 = rd[h];
+                    rd1 = rd[2 + h];
+                    mk = mask[(size_t)c.s * V + vn];
+                }
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     g16 a = gm_gemm<4>(L + (MG_ATT2 + 4 * t) * 64, lane, hid, gm_tile(tb + MB_ATT2 + t * 32, h));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float lg = mk == 0.f ? -1e9f : a[r];
-                        const int f0 = 32 * t + gm_nidx(r, 0);
-                        if (sv) gm_row_at(c, lr + RWL_PROB + f0, v)[c.row_lane] = lg;
-                        const float vp = gm_row_at(c, lr + RWL_VP + f0, v)[c.row_lane];
-                        const float mn = fmaxf(mx.t[t][r], lg);
-                        const float sc = __expf(mx.t[t][r] - mn), p = __expf(lg - mn);
-                        sum.t[t][r] = sum.t[t][r] * sc + p;
-                        acc.t[t][r] = acc.t[t][r] * sc + p * vp;
-                        mx.t[t][r] = mn;
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 pv = gm_parked4(VPp, lane, t, q);
+                        const float vpq[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * q + e;
+                            const float lg = mk_v == 0.f ? -1e9f : a[r];
+                            if (sv) gm_row_at(c, lr + RWL_PROB + 32 * t + gm_nidx(r, 0), v)[c.row_lane] = lg;
+                            const float mn = fmaxf(mx.t[t][r], lg);
+                            const float sc = __expf(mx.t[t][r] - mn), p = __expf(lg - mn);
+                            sum.t[t][r] = sum.t[t][r] * sc + p;
+                            acc.t[t][r] = acc.t[t][r] * sc + p * vpq[e];
+                            mx.t[t][r] = mn;
+                        }
                     }
                 }
             }
@@ -667,6 +734,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                 // K record (hd, key tile = wave, step j): lane (key m, h) -> K[key][dim n(j, h)]  == own register
                 // V^T record (hd, key tile, step r): lane (dim i < 16, hh) -> V[key n(r, hh)][dim i]: this key is m = n(r, hh)
                 const int rk = ((m & 3) | ((m >> 3) << 2)), hk = (m >> 2) & 1;      // inverse of n(r, hh) for key m
+                __syncthreads();        // every wave is through with its parked q / v + pos, which the image overlays
 #pragma unroll
                 for (int hd = 0; hd < 4; ++hd) {
 #pragma unroll

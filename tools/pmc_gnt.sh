@@ -1,0 +1,32 @@
+# Issue / stall counters of the GNT network kernels at BASELINE config 4 (tools/bench_gnt_kernels.py), one rocprofv3 --pmc pass per
+# counter group.  Writes gpurun_out/pmc_gnt.txt.
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+OUT=$REPO/gpurun_out/pmc_gnt
+mkdir -p $OUT
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
+           "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
+           "SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
+           "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o c -- python3 $REPO/tools/bench_gnt_kernels.py 2 > $OUT/p$i.log 2>&1
+done
+python3 - <<'PY' > $REPO/gpurun_out/pmc_gnt.txt
+import csv, glob, collections, os
+out = os.environ.get('GRAFT_REPO_ROOT', '/root/repo') + '/gpurun_out/pmc_gnt'
+tab = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True)):
+    for row in csv.DictReader(open(f)):
+        k = row['Kernel_Name'].split('(')[0]
+        if 'gnt' not in k:
+            continue
+        tab[k][row['Counter_Name']].append(float(row['Counter_Value']))
+for k, cs in tab.items():
+    print(k)
+    for c, v in sorted(cs.items()):
+        print('   %-28s mean/launch %16.0f  (%d launches)' % (c, sum(v) / len(v), len(v)))
+PY
+cat $REPO/gpurun_out/pmc_gnt.txt
