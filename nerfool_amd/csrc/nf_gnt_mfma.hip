@@ -271,15 +271,20 @@ __device__ __forceinline__ void gm_park(float* p, int lane, const V64& x) {
 __device__ __forceinline__ float gm_half_sum(float x) { return nf_half_sum(x); }
 __device__ __forceinline__ float gm_half_max(float x) { return nf_half_max(x); }
 
-// acc += sum over NSTEPS k-steps: records at rec (global, L2), B operand = x[r]
-// makes a (wave-uniform) pointer opaque to the optimiser: without it the loop-invariant record loads of the view loop --
-// 178 of them -- are hoisted out of the loop into registers and spilled
+// a wave-uniform zero the optimiser cannot see through.  Added to a pointer inside the view loop it keeps the loop-invariant
+// record reads -- 178 registers' worth -- from being hoisted out of the loop and spilled; unlike passing the POINTER through an
+// asm statement it keeps the pointer's address space (a laundered pointer is accessed with flat_load, whose waits are
+// vmcnt(0) lgkmcnt(0): no load stays in flight across one)
+__device__ __forceinline__ int gm_opaque_zero() {
+    int z = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-#define GM_LAUNDER(p) asm volatile("" : "+s"(p))
+    asm volatile("" : "+s"(z));
 #else
-#define GM_LAUNDER(p) asm volatile("" : "+r"(p))
+    asm volatile("" : "+r"(z));
 #endif
-
+    return z;
+}
+// acc += sum over NSTEPS k-steps: records at rec (L2 or LDS), B operand = x[r]
 #ifndef GM_FENCE
 #define GM_FENCE 0
 #endif
@@ -323,15 +328,20 @@ __device__ __forceinline__ g16 gm_mfma16(const g16& wv, const g16& x, g16 acc) {
     for (int r = 0; r < 16; ++r) acc = GM_MFMA(wv[r], x[r], acc);
     return acc;
 }
+// memory operations stay on their side of this point: under register pressure the instruction scheduler otherwise sinks the
+// loads of a chunk down to the MFMAs that consume them (load, s_waitcnt vmcnt(0), MFMA -- the whole L2 latency per record)
+#define GM_PIN() asm volatile("" ::: "memory")
 __device__ __forceinline__ g16 gm_take_a(GmW& w, int lane, const g16& x, g16 acc) {
     acc = gm_mfma16(w.a, x, acc);
     w.a = gm_ld16(w.p, lane);
+    GM_PIN();
     w.p += GM_CHUNK;
     return acc;
 }
 __device__ __forceinline__ g16 gm_take_b(GmW& w, int lane, const g16& x, g16 acc) {
     acc = gm_mfma16(w.b, x, acc);
     w.b = gm_ld16(w.p, lane);
+    GM_PIN();
     w.p += GM_CHUNK;
     return acc;
 }
@@ -458,17 +468,7 @@ template <int NW> struct GmLds {
     static constexpr int FLOATS = GM_TAB_FLOATS + K_FLOATS + VT_FLOATS + RED_FLOATS;
     static_assert(K_FLOATS + VT_FLOATS >= NW * 2 * GM_PARK_FLOATS, "the parked q / v + pos alias the K / V^T image");
 };
-// a wave-uniform zero the optimiser cannot see through: added to a table pointer inside the view loop it keeps the loop-invariant
-// table reads -- 178 registers' worth -- from being hoisted out of the loop and spilled
-__device__ __forceinline__ int gm_opaque_zero() {
-    int z = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(z));
-#else
-    asm volatile("" : "+r"(z));
-#endif
-    return z;
-}
+
 
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restrict__ wb, const float* __restrict__ rgb_feat_all,
@@ -686,6 +686,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                             *pp = __expf(*pp - mx.t[t][r]) * sum.t[t][r];
                         }
             }
+            if (sv) gm_store_smp(c, ls + SL_U, u);
             const V64 o = gm_lin64_s(w, tb + MB_VOUT, lane, h, u);
             cur = gm_load_smp(c, SW_CUR);
 #pragma unroll
@@ -882,11 +883,18 @@ __device__ __forceinline__ V64 gm_ln_bwd(const GmCtx& c, const V64& dy, const fl
 __device__ __forceinline__ V64 gm_ff_bwd(const GmCtx& c, GmW& w, int lane, const V64& dout, int f_slot) {
     V64 dy;
     dy.t[0] = dy.t[1] = gm_zero();
+    g16 fn;                 // the hidden tile's forward activations, fetched one tile ahead of the GEMM that needs them
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fn[r] = gm_smp_at(c, f_slot + gm_nidx(r, 0))[c.smp_lane];
 #pragma unroll 1
     for (int j = 0; j < 8; ++j) {
+        const g16 f = fn;
+        const int jn = j < 7 ? j + 1 : j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fn[r] = gm_smp_at(c, f_slot + 32 * jn + gm_nidx(r, 0))[c.smp_lane];
         g16 df = gm_tile_s(w, lane, dout, gm_zero());
 #pragma unroll
-        for (int r = 0; r < 16; ++r) df[r] = gm_smp_at(c, f_slot + 32 * j + gm_nidx(r, 0))[c.smp_lane] > 0.f ? df[r] : 0.f;
+        for (int r = 0; r < 16; ++r) df[r] = f[r] > 0.f ? df[r] : 0.f;
         dy.t[0] = gm_take_a(w, lane, df, dy.t[0]);
         dy.t[1] = gm_take_b(w, lane, df, dy.t[1]);
     }
@@ -897,7 +905,8 @@ template <int NW> struct GmBwdLds {
     static constexpr int REC = NW * 8 * 64;                    // rows x dims record set (K, V, Q, dO)
     static constexpr int TREC = NW * 16 * GM_VT_STRIDE;        // dims x rows record set (K^T, Q^T, dO^T)
     static constexpr int SCAL = 32 * NW;                       // per-query scalars (max, 1 / sum, D)
-    static constexpr int FLOATS = 4 * REC + 3 * TREC + 3 * SCAL;
+    static constexpr int TAB = 8 * 64 + 512;                   // the layer's attn_fc.0^T records | its four LayerNorm (weight, bias) pairs
+    static constexpr int FLOATS = TAB + 4 * REC + 3 * TREC + 3 * SCAL;
 };
 
 template <int NW>
@@ -907,7 +916,8 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
                                                           int64_t row_floats, int64_t smp_floats) {
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int S = 32 * NW;
-    float* Kr = lds;
+    float* tab = lds;
+    float* Kr = lds + GmBwdLds<NW>::TAB;
     float* Vr = Kr + GmBwdLds<NW>::REC;
     float* Qr = Vr + GmBwdLds<NW>::REC;
     float* Gr = Qr + GmBwdLds<NW>::REC;
@@ -944,26 +954,32 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
             }
         dcur = gm_ln_bwd(c, dm, F + MF_LNW, SW_XHF, SW_RSTDF);
     }
-    // d X_v accumulators start at zero
-    {
-        V64 z;
-        z.t[0] = z.t[1] = gm_zero();
-        for (int v = 0; v < V; ++v) gm_store_row(c, RW_DX, v, z);
-    }
     GmW w;
     gm_w_start(w, wb + gm_bwd_layer_base(depth, depth - 1) + BG_STREAM * 64, lane);
     for (int i = depth - 1; i >= 0; --i) {
-        const float* Lf = wb + gm_layer_base(i);
-        const float* tb = Lf + (size_t)MG_LAYER_RECORDS * 64;                       // forward tables (LayerNorm weights)
         const float* Bl = wb + gm_bwd_layer_base(depth, i);
         const float* Bst = Bl + BG_STREAM * 64;
+        // ---- the layer's attn_fc.0^T records and LayerNorm weights -> LDS (read inside the view loop / right behind a GEMM, where
+        //      a load from L2 sits fully exposed with one wave per SIMD)
+        __syncthreads();
+        {
+            const float4* src_rec = reinterpret_cast<const float4*>(Bl + BG_ATT0T * 64);
+            const float4* src_ln = reinterpret_cast<const float4*>(wb + gm_layer_base(i) + (size_t)MG_LAYER_RECORDS * 64 + MB_LN);
+            float4* dst = reinterpret_cast<float4*>(tab);
+            for (int k = threadIdx.x; k < 128; k += 64 * NW) {
+                dst[k] = src_rec[k];
+                dst[128 + k] = src_ln[k];
+            }
+        }
+        __syncthreads();
+        const float* ln = tab + 512;                                                // LayerNorm tables as at MB_LN of the forward section
         const float* after = i > 0 ? wb + gm_bwd_layer_base(depth, i - 1) + BG_STREAM * 64 : wb + gm_bwd_stem_base(depth);
         const int ls = SW_BASE + i * SW_LAYER;
         const int lr = RW_BASE + i * RW_LAYER;
         // ================= ray transformer backward =================
         {
             const V64 dy = gm_ff_bwd(c, w, lane, dcur, ls + SL_F2);
-            const V64 dl = gm_ln_bwd(c, dy, tb + MB_LN + 384, ls + SL_RXH2, ls + SL_RRSTD2);
+            const V64 dl = gm_ln_bwd(c, dy, ln + 384, ls + SL_RXH2, ls + SL_RRSTD2);
 #pragma unroll
             for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
         }
@@ -1063,7 +1079,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
             V64 dx = gm_lin64_sj(w, lane, dq, nullptr, nullptr);
             dx = gm_lin64_sj(w, lane, dk, &dx, nullptr);
             dx = gm_lin64_sj(w, lane, dv, &dx, (i & 1) ? Bst + BS_VFF * 64 : nullptr);      // odd layers: no positional MLP records
-            const V64 dl = gm_ln_bwd(c, dx, tb + MB_LN + 256, ls + SL_RXH1, ls + SL_RRSTD1);
+            const V64 dl = gm_ln_bwd(c, dx, ln + 256, ls + SL_RXH1, ls + SL_RRSTD1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
         }
@@ -1080,58 +1096,78 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
         // ================= view transformer backward =================
         {
             const V64 dy = gm_ff_bwd(c, w, lane, dcur, ls + SL_F);
-            const V64 dl = gm_ln_bwd(c, dy, tb + MB_LN + 128, ls + SL_XH2, ls + SL_RSTD2);
+            const V64 dl = gm_ln_bwd(c, dy, ln + 128, ls + SL_XH2, ls + SL_RSTD2);
 #pragma unroll
             for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
         }
         {
             const V64 du = gm_lin64_sj(w, lane, dcur, nullptr, nullptr);
             V64 sp, dqs;
-            sp.t[0] = sp.t[1] = dqs.t[0] = dqs.t[1] = gm_zero();
-            for (int v = 0; v < V; ++v) {
-                const V64 pr = gm_load_row(c, lr + RWL_PROB, v), vp = gm_load_row(c, lr + RWL_VP, v);
+            {       // sum_v p_v (v + pos)_v du = u du: the forward left u = sum_v p_v (v + pos)_v in the workspace
+                const V64 u = gm_load_smp(c, ls + SL_U);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sp.t[t][r] = fmaf(pr.t[t][r] * vp.t[t][r], du.t[t][r], sp.t[t][r]);
+                    for (int r = 0; r < 16; ++r) sp.t[t][r] = u.t[t][r] * du.t[t][r];
             }
+            dqs.t[0] = dqs.t[1] = gm_zero();
+            // the view's saved activations are fetched one view ahead: issued in front of the LAST GEMM of the previous view (a
+            // 64-MFMA window, and the point of the body with the fewest live registers)
+            V64 pr = gm_load_row(c, lr + RWL_PROB, 0), vp = gm_load_row(c, lr + RWL_VP, 0);
+            float mk = mask[(size_t)c.s * V];
+            GM_PIN();
             for (int v = 0; v < V; ++v) {
-                const float* Bs = Bst;
-                const float* Bsmall = Bl;
-                GM_LAUNDER(Bs);
-                GM_LAUNDER(Bsmall);
-                const float mk = mask[(size_t)c.s * V + v];
+                const int oz = gm_opaque_zero();
+                const float* Bs = Bst + oz;
+                const float* Bsmall = tab + oz;
                 V64 dlg, dvv;
-                {
-                    const V64 pr = gm_load_row(c, lr + RWL_PROB, v), vp = gm_load_row(c, lr + RWL_VP, v);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            dlg.t[t][r] = mk == 0.f ? 0.f : pr.t[t][r] * (vp.t[t][r] * du.t[t][r] - sp.t[t][r]);
-                            dvv.t[t][r] = pr.t[t][r] * du.t[t][r];
-                        }
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        dlg.t[t][r] = mk == 0.f ? 0.f : pr.t[t][r] * (vp.t[t][r] * du.t[t][r] - sp.t[t][r]);
+                        dvv.t[t][r] = pr.t[t][r] * du.t[t][r];
+                    }
+                float hsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hsv[r] = gm_row_at(c, lr + RWL_H + r, v)[c.row_lane];
+                GM_PIN();
                 g16 dh = gm_tile_s(w, lane, dlg, gm_zero());                       // attn_fc.2^T: 8 <- 64
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dh[r] = gm_row_at(c, lr + RWL_H + r, v)[c.row_lane] > 0.f ? dh[r] : 0.f;
+                for (int r = 0; r < 4; ++r) dh[r] = hsv[r] > 0.f ? dh[r] : 0.f;
                 V64 da;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    da.t[t] = gm_gemm<4>(Bsmall + (BG_ATT0T + 4 * t) * 64, lane, dh, gm_zero());      // attn_fc.0^T: 64 <- 8
+                    da.t[t] = gm_gemm<4>(Bsmall + 4 * t * 64, lane, dh, gm_zero());                   // attn_fc.0^T: 64 <- 8
                     dqs.t[t] += da.t[t];
                 }
                 const V64 dK = gm_lin64_sj(w, lane, dvv, &da, nullptr);            // d K = d a + Wv^T d Vv
-                const V64 acc = gm_load_row(c, RW_DX, v);
-                const V64 dxv = gm_lin64_sj(w, lane, dK, &acc, v + 1 < V ? Bs + BS_VIEW * 64 : nullptr);      // d X_v += Wk^T d K
-                gm_store_row(c, RW_DX, v, dxv);
+                {
+                    const int vn = v + 1 < V ? v + 1 : v;                          // (the last view re-reads itself)
+                    pr = gm_load_row(c, lr + RWL_PROB, vn);
+                    vp = gm_load_row(c, lr + RWL_VP, vn);
+                    mk = mask[(size_t)c.s * V + vn];
+                    GM_PIN();
+                }
+                const V64 dxv = gm_lin64_sj(w, lane, dK, nullptr, v + 1 < V ? Bs + BS_VIEW * 64 : nullptr);      // Wk^T d K
+                // d X_v accumulates over the layers in the workspace: a plain store in the layer the backward starts with, then
+                // device-scope float atomics -- nothing to wait for, no accumulator to fetch (one writer per address: the order of
+                // the additions, and so the result, is fixed)
+                if (i == depth - 1) {
+                    gm_store_row(c, RW_DX, v, dxv);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) atomicAdd(gm_row_at(c, RW_DX + 32 * t + gm_nidx(r, 0), v) + c.row_lane, dxv.t[t][r]);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dqs.t[t][r] = -dqs.t[t][r];          // d Q = - sum_v d a_v
             const V64 dx = gm_lin64_sj(w, lane, dqs, nullptr, after);
-            const V64 dl = gm_ln_bwd(c, dx, tb + MB_LN, ls + SL_XH1, ls + SL_RSTD1);
+            const V64 dl = gm_ln_bwd(c, dx, ln, ls + SL_XH1, ls + SL_RSTD1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
         }
@@ -1141,16 +1177,22 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
         const V64 am = gm_load_smp(c, SW_AMAX);
         const float* St = wb + gm_bwd_stem_base(depth);
         for (int v = 0; v < V; ++v) {
-            const float* Sv = St;
-            GM_LAUNDER(Sv);
-            V64 dxv = gm_load_row(c, RW_DX, v);
+            const float* Sv = St + gm_opaque_zero();
+            V64 dxv;                    // accumulated with L2 atomics: read past the (non-coherent) vector L1
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dxv.t[t][r] = __hip_atomic_load(gm_row_at(c, RW_DX + 32 * t + gm_nidx(r, 0), v) + c.row_lane, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+            const V64 r1 = gm_load_row(c, RW_R1, v);
+            GM_PIN();
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if ((int)am.t[t][r] == v) dxv.t[t][r] += dcur.t[t][r];
             V64 dr = gm_lin64_sj(w, lane, dxv, nullptr, nullptr);                  // rgbfeat_fc.2^T
-            const V64 r1 = gm_load_row(c, RW_R1, v);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll

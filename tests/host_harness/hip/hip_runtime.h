@@ -134,6 +134,11 @@ static inline float atomicAdd(float* addr, float val) {
     }
 }
 
+// __hip_atomic_load is a clang builtin on the host as well; only the scope constants are HIP-mode macros
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
+
 #define __expf(x) expf(x)   // v_exp_f32-based fast exp on the device
 static inline double atomicAdd(double* addr, double val) {
     uint64_t* p = (uint64_t*)addr;
