@@ -331,17 +331,25 @@ __device__ __forceinline__ g16 gm_mfma16(const g16& wv, const g16& x, g16 acc) {
 // memory operations stay on their side of this point: under register pressure the instruction scheduler otherwise sinks the
 // loads of a chunk down to the MFMAs that consume them (load, s_waitcnt vmcnt(0), MFMA -- the whole L2 latency per record)
 #define GM_PIN() asm volatile("" ::: "memory")
+// ... and the MFMAs of the NEXT chunk stay behind it (they start with `next0`, the first record of the other buffer): hoisted
+// above the pin they would run right behind the loads issued for the chunk after them, which shortens the distance between a
+// load and its use from two chunks to a few records
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GM_PIN_CHAIN(next0) asm volatile("" : "+v"(next0) : : "memory")
+#else
+#define GM_PIN_CHAIN(next0) asm volatile("" : "+r"(next0) : : "memory")
+#endif
 __device__ __forceinline__ g16 gm_take_a(GmW& w, int lane, const g16& x, g16 acc) {
     acc = gm_mfma16(w.a, x, acc);
     w.a = gm_ld16(w.p, lane);
-    GM_PIN();
+    GM_PIN_CHAIN(w.b[0]);
     w.p += GM_CHUNK;
     return acc;
 }
 __device__ __forceinline__ g16 gm_take_b(GmW& w, int lane, const g16& x, g16 acc) {
     acc = gm_mfma16(w.b, x, acc);
     w.b = gm_ld16(w.p, lane);
-    GM_PIN();
+    GM_PIN_CHAIN(w.a[0]);
     w.p += GM_CHUNK;
     return acc;
 }
@@ -1176,15 +1184,10 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
     {
         const V64 am = gm_load_smp(c, SW_AMAX);
         const float* St = wb + gm_bwd_stem_base(depth);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // d X_v was accumulated with L2 atomics: the loads below must not be served by the vector L1
         for (int v = 0; v < V; ++v) {
             const float* Sv = St + gm_opaque_zero();
-            V64 dxv;                    // accumulated with L2 atomics: read past the (non-coherent) vector L1
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dxv.t[t][r] = __hip_atomic_load(gm_row_at(c, RW_DX + 32 * t + gm_nidx(r, 0), v) + c.row_lane, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
+            V64 dxv = gm_load_row(c, RW_DX, v);
             const V64 r1 = gm_load_row(c, RW_R1, v);
             GM_PIN();
 #pragma unroll

@@ -134,10 +134,8 @@ static inline float atomicAdd(float* addr, float val) {
     }
 }
 
-// __hip_atomic_load is a clang builtin on the host as well; only the scope constants are HIP-mode macros
-#ifndef __HIP_MEMORY_SCOPE_AGENT
-#define __HIP_MEMORY_SCOPE_AGENT 4
-#endif
+// device-scope fence (an acquire invalidates the non-coherent vector L1 on the device): a host fence here
+static inline void __builtin_amdgcn_fence(int order, const char*) { __atomic_thread_fence(order); }
 
 #define __expf(x) expf(x)   // v_exp_f32-based fast exp on the device
 static inline double atomicAdd(double* addr, double val) {
