@@ -56,8 +56,11 @@ enum { SW_AMAX = 0, SW_CUR = 64, SW_PE = 128, SW_T = 256, SW_U = 512, SW_QV = 57
        SW_BASE = 1288,
        SL_XH1 = 0, SL_RSTD1 = 64, SL_XH2 = 65, SL_RSTD2 = 129, SL_F = 130, SL_G = 386, SL_RXH1 = 450, SL_RRSTD1 = 514, SL_QH = 515,
        SL_KH = 579, SL_VH = 643, SL_ML = 707, SL_OUTA = 715, SL_RXH2 = 779, SL_RRSTD2 = 843, SL_F2 = 844,
-       SL_U = 1100,       // view-attention output before out_fc: written by the matrix-core forward for the matrix-core backward only
-       SW_LAYER = 1164 };
+       // written by the matrix-core forward for the matrix-core backward only (which in turn reads RWL_PROB as the masked LOGITS and
+       // SL_F / SL_F2 / RW_R1 as sign-bit words -- see nf_gnt_mfma.hip): view-attention output before out_fc, running maximum and
+       // reciprocal sum of the view softmax
+       SL_U = 1100, SL_MX = 1164, SL_RS = 1228,
+       SW_LAYER = 1292 };
 
 static int64_t gnt_row_floats(int depth, int save) { return RW_BASE + (int64_t)(save ? depth : 1) * RW_LAYER; }
 static int64_t gnt_smp_floats(int depth, int save) { return SW_BASE + (int64_t)(save ? depth : 1) * SW_LAYER; }

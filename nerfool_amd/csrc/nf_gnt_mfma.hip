@@ -439,6 +439,17 @@ __device__ __forceinline__ V64 gm_layernorm(const GmCtx& c, const V64& x, const 
     return y;
 }
 
+// What the backward needs of a ReLU layer is the sign of its 16 outputs per lane and tile: ONE word instead of 16 floats
+// (the feed-forward hidden layers alone were 512 of the 1168 floats saved per sample and layer).  Word j of lane half h lands in
+// slot gm_sign_slot(j) + 4 h (the half offset is part of the lane offset), so words 0..7 occupy 16 slots.
+__device__ __forceinline__ float gm_sign_word(const g16& f) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bits |= (f[r] > 0.f ? 1u : 0u) << r;
+    return __uint_as_float(bits);
+}
+__host__ __device__ constexpr int gm_sign_slot(int j) { return (j & 3) + 8 * (j >> 2); }
+
 // feed-forward 64 -> 256 (ReLU) -> 64, hidden tile j chained straight into fc2; returns FF(y) (bias included).
 // jump (nullable): where the stream continues behind this block when that is not the next record in memory.
 __device__ __forceinline__ V64 gm_ff(const GmCtx& c, GmW& w, const float* __restrict__ b1, const float* __restrict__ b2, int lane,
@@ -452,10 +463,7 @@ __device__ __forceinline__ V64 gm_ff(const GmCtx& c, GmW& w, const float* __rest
         if (j == 7 && jump) w.p = jump;
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[r] = fmaxf(f[r], 0.f);
-        if (save) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gm_smp_at(c, f_slot + 32 * j + gm_nidx(r, 0))[c.smp_lane] = f[r];
-        }
+        if (save) gm_smp_at(c, f_slot + gm_sign_slot(j))[c.smp_lane] = gm_sign_word(f);      // the backward needs relu' only
         o.t[0] = gm_take_a(w, lane, f, o.t[0]);
         o.t[1] = gm_take_b(w, lane, f, o.t[1]);
     }
@@ -528,7 +536,10 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
             for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
             r1.t[t] = acc;
         }
-        if (sv) gm_store_row(c, RW_R1, v, r1);
+        if (sv) {       // relu' of the stem's hidden layer: the two tiles' sign bits in one word
+            const unsigned bits = __float_as_uint(gm_sign_word(r1.t[0])) | (__float_as_uint(gm_sign_word(r1.t[1])) << 16);
+            gm_row_at(c, RW_R1, v)[c.row_lane] = __uint_as_float(bits);
+        }
         V64 x = gm_lin64(wb + MS_L2 * 64, wb + MS_B2, lane, h, r1);
         gm_store_row(c, RW_X, v, x);
 #pragma unroll
@@ -684,15 +695,9 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                     sum.t[t][r] = nf_rcp(sum.t[t][r]);
                     u.t[t][r] = acc.t[t][r] * sum.t[t][r];
                 }
-            if (sv) {       // the backward wants the normalised attention weights where the raw logits were parked
-                for (int v = 0; v < V; ++v)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float* pp = gm_row_at(c, lr + RWL_PROB + 32 * t + gm_nidx(r, 0), v) + c.row_lane;
-                            *pp = __expf(*pp - mx.t[t][r]) * sum.t[t][r];
-                        }
+            if (sv) {       // the logits stay where the loop parked them: the backward re-forms p_v = exp(logit_v - max) / sum
+                gm_store_smp(c, ls + SL_MX, mx);
+                gm_store_smp(c, ls + SL_RS, sum);
             }
             if (sv) gm_store_smp(c, ls + SL_U, u);
             const V64 o = gm_lin64_s(w, tb + MB_VOUT, lane, h, u);
@@ -891,18 +896,16 @@ __device__ __forceinline__ V64 gm_ln_bwd(const GmCtx& c, const V64& dy, const fl
 __device__ __forceinline__ V64 gm_ff_bwd(const GmCtx& c, GmW& w, int lane, const V64& dout, int f_slot) {
     V64 dy;
     dy.t[0] = dy.t[1] = gm_zero();
-    g16 fn;                 // the hidden tile's forward activations, fetched one tile ahead of the GEMM that needs them
+    float sg[8];            // relu' of the 8 hidden tiles: one sign word each (gm_sign_word)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fn[r] = gm_smp_at(c, f_slot + gm_nidx(r, 0))[c.smp_lane];
-#pragma unroll 1
+    for (int j = 0; j < 8; ++j) sg[j] = gm_smp_at(c, f_slot + gm_sign_slot(j))[c.smp_lane];
+    GM_PIN();
+#pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const g16 f = fn;
-        const int jn = j < 7 ? j + 1 : j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) fn[r] = gm_smp_at(c, f_slot + 32 * jn + gm_nidx(r, 0))[c.smp_lane];
         g16 df = gm_tile_s(w, lane, dout, gm_zero());
+        const unsigned bits = __float_as_uint(sg[j]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) df[r] = f[r] > 0.f ? df[r] : 0.f;
+        for (int r = 0; r < 16; ++r) df[r] = (bits >> r) & 1u ? df[r] : 0.f;
         dy.t[0] = gm_take_a(w, lane, df, dy.t[0]);
         dy.t[1] = gm_take_b(w, lane, df, dy.t[1]);
     }
@@ -1110,13 +1113,19 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
         }
         {
             const V64 du = gm_lin64_sj(w, lane, dcur, nullptr, nullptr);
-            V64 sp, dqs;
-            {       // sum_v p_v (v + pos)_v du = u du: the forward left u = sum_v p_v (v + pos)_v in the workspace
-                const V64 u = gm_load_smp(c, ls + SL_U);
+            // the view softmax: p_v = exp(logit_v - mx) rs with the forward's running maximum and reciprocal sum; rs is folded
+            // into du (dur = rs du), and sum_v p_v (v + pos)_v du = u du with the forward's u = sum_v p_v (v + pos)_v
+            V64 dur, sp, dqs;
+            const V64 mx = gm_load_smp(c, ls + SL_MX);
+            {
+                const V64 u = gm_load_smp(c, ls + SL_U), rs = gm_load_smp(c, ls + SL_RS);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sp.t[t][r] = u.t[t][r] * du.t[t][r];
+                    for (int r = 0; r < 16; ++r) {
+                        dur.t[t][r] = rs.t[t][r] * du.t[t][r];
+                        sp.t[t][r] = u.t[t][r] * dur.t[t][r];
+                    }
             }
             dqs.t[0] = dqs.t[1] = gm_zero();
             // the view's saved activations are fetched one view ahead: issued in front of the LAST GEMM of the previous view (a
@@ -1133,8 +1142,9 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        dlg.t[t][r] = mk == 0.f ? 0.f : pr.t[t][r] * (vp.t[t][r] * du.t[t][r] - sp.t[t][r]);
-                        dvv.t[t][r] = pr.t[t][r] * du.t[t][r];
+                        const float e = __expf(pr.t[t][r] - mx.t[t][r]);          // (pr holds the logits)
+                        dlg.t[t][r] = mk == 0.f ? 0.f : e * (vp.t[t][r] * dur.t[t][r] - sp.t[t][r]);
+                        dvv.t[t][r] = e * dur.t[t][r];
                     }
                 float hsv[4];
 #pragma unroll
@@ -1188,7 +1198,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
         for (int v = 0; v < V; ++v) {
             const float* Sv = St + gm_opaque_zero();
             V64 dxv = gm_load_row(c, RW_DX, v);
-            const V64 r1 = gm_load_row(c, RW_R1, v);
+            const unsigned r1 = __float_as_uint(gm_row_at(c, RW_R1, v)[c.row_lane]);      // sign bits of the stem's hidden layer
             GM_PIN();
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -1199,7 +1209,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dr.t[t][r] = r1.t[t][r] > 0.f ? dr.t[t][r] : 0.f;
+                for (int r = 0; r < 16; ++r) dr.t[t][r] = (r1 >> (16 * t + r)) & 1u ? dr.t[t][r] : 0.f;
             const V64 df = gm_lin64_sj(w, lane, dr, nullptr, v + 1 < V ? Sv : nullptr);      // rgbfeat_fc.0^T: 35 <- 64
             float* o = d_rgb_feat + ((ray * S + c.s) * V + v) * 35;
 #pragma unroll

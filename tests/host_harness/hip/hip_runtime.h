@@ -134,6 +134,8 @@ static inline float atomicAdd(float* addr, float val) {
     }
 }
 
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 // device-scope fence (an acquire invalidates the non-coherent vector L1 on the device): a host fence here
 static inline void __builtin_amdgcn_fence(int order, const char*) { __atomic_thread_fence(order); }
 

@@ -1024,8 +1024,7 @@ def check_gnt_mfma_vs_generic(dev, shapes=((2, 32, 3, 2),)):
         assert float((al_a.sum(-1) - 1).abs().max()) < 1e-5
         d_rgb = torch.randn(R, 3, generator=gen).to(dev)
         ga = ops.gnt_bwd(blob, args[1], args[2], d_rgb, ws_a, (R, S, V), depth)
-        gb = ops.gnt_bwd(blob, args[1], args[2], d_rgb, ws_b, (R, S, V), depth)
-        assert_close(gb, ga, 1e-3, 2e-4 * float(ga.abs().max()), 'GNT d rgb_feat from the activations saved by either forward')
+        # (the matrix-core forward saves logits + softmax statistics and sign words: only its own backward reads that workspace)
         gc = ops.gnt_bwd_mfma(mblob, args[2], d_rgb, ws_b, (R, S, V), depth)
         assert_close(gc, ga, 1e-3, 2e-4 * float(ga.abs().max()), 'GNT d rgb_feat (matrix-core backward vs generic backward)')
 

@@ -46,12 +46,10 @@ def main():
     t_gen, (rgb_a, ws_a) = timed(lambda: ops.gnt_fwd(blob, *args, save=True))
     t_mf, (rgb_b, ws_b) = timed(lambda: ops.gnt_fwd_mfma(mblob, *args, save=True))
     t_mf0, (rgb_c, _) = timed(lambda: ops.gnt_fwd_mfma(mblob, *args, save=False))
-    t_bwd, g_b = timed(lambda: ops.gnt_bwd(blob, rd, mask, d_rgb, ws_b, (R, S, V), depth))
+    t_bwd, g_b = timed(lambda: ops.gnt_bwd(blob, rd, mask, d_rgb, ws_a, (R, S, V), depth))
     t_bmf, g_c = timed(lambda: ops.gnt_bwd_mfma(mblob, mask, d_rgb, ws_b, (R, S, V), depth))
-    g_a = ops.gnt_bwd(blob, rd, mask, d_rgb, ws_a, (R, S, V), depth)
     F = GNT_FWD_FLOPS_PER_RAY * R
-    print('rgb max diff %.2e (no-save %.2e), grad rel diff %.2e' % (float((rgb_a - rgb_b).abs().max()), float((rgb_a - rgb_c).abs().max()),
-                                                                      float((g_a - g_b).abs().max() / g_a.abs().max())))
+    print('rgb max diff %.2e (no-save %.2e)' % (float((rgb_a - rgb_b).abs().max()), float((rgb_a - rgb_c).abs().max())))
     print('backward: generic %.2f ms, matrix cores %.2f ms (%.1f TFLOP/s algorithmic), rel diff %.2e rel-L2 %.2e' %
           (t_bwd, t_bmf, F / t_bmf / 1e9, float((g_c - g_b).abs().max() / g_b.abs().max()), float((g_c - g_b).norm() / g_b.norm())))
     print('forward generic %.2f ms (%.1f TFLOP/s) | matrix cores %.2f ms (%.1f TFLOP/s), no save %.2f ms | backward %.2f ms' %
