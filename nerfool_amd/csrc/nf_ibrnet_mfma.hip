@@ -383,7 +383,25 @@ extern "C" int nf_ibrnet_pack_mfma_bf16(const float* mfma_blob, float* out) {
 // v_exp_f32-based exponentials (2 instructions, ~2 ulp) instead of the ~20-30 instruction libm forms: on the row kernels
 // the ~140 ELUs per lane per tile would otherwise cost more VALU cycles than the tile's 217 MFMAs take
 __device__ __forceinline__ float mf_exp(float x) { return __expf(x); }
-__device__ __forceinline__ float mf_elu(float x) { return x > 0.f ? x : mf_exp(x) - 1.f; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 nf_exp2x2(f32x2 x) {      // 2^x per element
+#if defined(__HIP_DEVICE_COMPILE__)
+    return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+#else
+    return f32x2{exp2f(x.x), exp2f(x.y)};
+#endif
+}
+__device__ __forceinline__ float nf_med3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+#endif
+}
+// ELU as the median of (x, e^x - 1, 0): x above zero (e^x - 1 >= x > 0), e^x - 1 below (x <= e^x - 1 <= 0) -- one v_med3_f32 in
+// place of a compare and a select.  (For 0 < x < ~3e-4 the rounded e^x - 1 can fall below x and is returned instead: within 1.2e-7.)
+// The ELUs are 40 % of the row kernels' vector instructions.
+__device__ __forceinline__ float mf_elu(float x) { return nf_med3(x, mf_exp(x) - 1.f, 0.f); }
 __device__ __forceinline__ float mf_sigmoid(float x) { return 1.f / (1.f + mf_exp(-x)); }
 
 // cross-view reductions of a sample: butterflies over its V adjacent lanes, as DPP modifiers of the combining instruction
@@ -470,9 +488,18 @@ __device__ __forceinline__ f32x16 gemm_small(const float* lds, int rec, int lane
     return acc;
 }
 
+// ... and over a fragment the scaling by log2(e) and the "- 1" are packed (v_pk_mul_f32 / v_pk_add_f32: two elements per
+// instruction), the same arithmetic per element as mf_elu
 __device__ __forceinline__ f32x16 elu16(f32x16 a) {
+    const f32x2 log2e = {1.44269502f, 1.44269502f};          // 0x3fb8aa3b: the constant __expf multiplies by
+    const f32x2 one = {1.f, 1.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = mf_elu(a[r]);
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = {a[r], a[r + 1]};
+        const f32x2 em = nf_exp2x2(x * log2e) - one;
+        a[r] = nf_med3(x.x, em.x, 0.f);
+        a[r + 1] = nf_med3(x.y, em.y, 0.f);
+    }
     return a;
 }
 
@@ -640,9 +667,9 @@ __device__ __forceinline__ void rows_forward_early(const float* lds, int lane, i
 #pragma unroll
     for (int r = 0; r < 8; ++r) d1[r] = mf_elu(d1[r]);
     {
-        f32x16 df = gemm_frag<BF, 8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h));
+        const f32x16 df = elu16(gemm_frag<BF, 8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h)));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a.F[r] = in.feat[r] + mf_elu(df[r]);
+        for (int r = 0; r < 16; ++r) a.F[r] = in.feat[r] + df[r];
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -1612,15 +1639,7 @@ __device__ __forceinline__ void ray_attention(const float* Ks, const float* Vs, 
 // position 8 h + 2 d + j for head h + 2 j, dimension d (ray_kv_slot), so that one 16-byte read delivers (d0: both heads, d1: both heads).
 // Element for element the arithmetic of ray_attention (same fma chains, same block-wise running maximum, v_exp_f32 of the same
 // argument), except that a head whose maximum did not move is rescaled by exp(0) = 1 instead of being skipped.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int ray_kv_slot(int r, int h) { return 8 * h + 2 * (r & 3) + (r >> 2); }       // fragment register r of lane half h
-__device__ __forceinline__ f32x2 nf_exp2x2(f32x2 x) {      // 2^x per element
-#if defined(__HIP_DEVICE_COMPILE__)
-    return f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-#else
-    return f32x2{exp2f(x.x), exp2f(x.y)};
-#endif
-}
 __device__ __forceinline__ void ray_attention_pk(const float* Kp, const float* Vp, int S, int h, RayActs& a) {
     const bool row_on = a.nval > 1.f;
     const f32x2 log2e = {1.44269502f, 1.44269502f};          // 0x3fb8aa3b: the constant __expf multiplies by

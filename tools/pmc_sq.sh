@@ -1,27 +1,28 @@
-# Issue / stall counters of the GNT network kernels at BASELINE config 4 (tools/bench_gnt_kernels.py), one rocprofv3 --pmc pass per
-# counter group.  Writes gpurun_out/pmc_gnt.txt.
+# Issue / stall counters (SQ block) of the kernels a program launches, one rocprofv3 --pmc pass per counter group.
+# usage: bash tools/pmc_sq.sh <tag> <kernel-name substring> <python script> [args...]   -> gpurun_out/pmc_sq_<tag>.txt
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=$1; FILTER=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
-OUT=$REPO/gpurun_out/pmc_gnt
+OUT=$REPO/gpurun_out/pmc_sq_$TAG
 mkdir -p $OUT
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
-           "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
            "SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
-           "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC"; do
+           "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o c -- python3 $REPO/tools/bench_gnt_kernels.py 2 > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -o c -- python3 "$@" > $OUT/p$i.log 2>&1
 done
-python3 - <<'PY' > $REPO/gpurun_out/pmc_gnt.txt
+FILTER="$FILTER" OUTDIR=$OUT python3 - <<'PY' > $REPO/gpurun_out/pmc_sq_$TAG.txt
 import csv, glob, collections, os
-out = os.environ.get('GRAFT_REPO_ROOT', '/root/repo') + '/gpurun_out/pmc_gnt'
+out = os.environ['OUTDIR']
+flt = os.environ['FILTER']
 tab = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True)):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'].split('(')[0]
-        if 'gnt' not in k:
+        if flt not in k:
             continue
         tab[k][row['Counter_Name']].append(float(row['Counter_Value']))
 for k, cs in tab.items():
@@ -29,4 +30,5 @@ for k, cs in tab.items():
     for c, v in sorted(cs.items()):
         print('   %-28s mean/launch %16.0f  (%d launches)' % (c, sum(v) / len(v), len(v)))
 PY
-cat $REPO/gpurun_out/pmc_gnt.txt
+cat $REPO/gpurun_out/pmc_sq_$TAG.txt
+rm -rf $OUT
