@@ -313,9 +313,11 @@ int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, 
 int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
                int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 
-/* GNT forward on the matrix cores (S in {32, 64, 96, 128}): same contract and workspace as nf_gnt_fwd -- nf_gnt_bwd consumes
- * what it saves -- with the weights re-ordered by nf_gnt_pack_mfma (HOST pointers: natural blob -> MFMA-order blob of
- * nf_gnt_mfma_blob_floats(depth) floats).                                    ref: gnt/transformer_network.py:270-309 */
+/* GNT forward on the matrix cores (S in {32, 64, 96, 128}): same arguments and workspace size as nf_gnt_fwd, with the weights
+ * re-ordered by nf_gnt_pack_mfma (HOST pointers: natural blob -> MFMA-order blob of nf_gnt_mfma_blob_floats(depth) floats).
+ * What it saves is for nf_gnt_bwd_mfma ONLY: the view softmax as masked logits + per-channel maximum / reciprocal sum, the ReLU
+ * layers as sign words, the view-attention output (nf_gnt.h); nf_gnt_bwd reads the workspace of nf_gnt_fwd.
+ *                                                                             ref: gnt/transformer_network.py:270-309 */
 int64_t nf_gnt_mfma_blob_floats(int depth);
 int nf_gnt_pack_mfma(int depth, const float* natural_blob_host, float* mfma_blob_host);
 int nf_gnt_mfma_supported(int n_samples, int n_views);

@@ -10,8 +10,14 @@
 //     weighted sum per channel in registers), any V; X_v comes back from the workspace the stem wrote.
 //   * ray transformer: K and V^T of the ray are laid out in LDS as MFMA A-operand records by the lanes that produced them;
 //     scores^T = K Q^T (keys on rows => the softmax over keys is in-lane + one cross-half shuffle), O^T = V^T P^T.
-// With save != 0 every activation nf_gnt_bwd reads is written to the workspace in the layout of nf_gnt.h, so the existing
-// backward consumes this forward unchanged.
+// One wave per SIMD (512 rays x 2 waves fill the chip exactly once): nothing hides a memory latency but the code itself.  So
+//   * the layer's small records and bias / LayerNorm tables live in LDS, q and v + pos of the view loop are parked in LDS,
+//   * the inputs of view v + 1 are fetched in front of the softmax arithmetic of view v,
+//   * the weight stream's chunk loads are pinned (GM_PIN_CHAIN) where they are written -- the scheduler otherwise sinks them to
+//     their use -- and the stream pointer keeps its address space (no flat_load: gm_opaque_zero).
+// With save != 0 the workspace (slots of nf_gnt.h) receives what k_gnt_bwd_mfma below reads -- NOT what the shape-generic
+// nf_gnt_bwd reads: the view softmax is saved as masked logits + running maximum + reciprocal sum (no normalisation pass over
+// the views), ReLU layers as sign words (gm_sign_word), plus the view-attention output u.
 #include "nf_gnt.h"
 
 #include <string.h>
@@ -852,7 +858,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// backward on the matrix cores: d rgb [R,3] -> d rgb_feat [R,S,V,35], from the activations a forward with save != 0 left in
+// backward on the matrix cores: d rgb [R,3] -> d rgb_feat [R,S,V,35], from the activations k_gnt_fwd_mfma with save != 0 left in
 // the workspace.  Same decomposition as the forward (one workgroup per ray, one wave per 32 samples, register-chained
 // transposed GEMMs dX^T = W^T dY^T, weight stream).  The ray attention is differentiated head by head with seven record
 // sets in LDS: scores are formed in BOTH orientations -- keys on rows (lane = query) for dQ, queries on rows (lane = key)
@@ -1254,8 +1260,8 @@ static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray
     return 0;
 }
 
-/* Same contract as nf_gnt_fwd (workspace of nf_gnt_workspace_floats, consumed by nf_gnt_bwd when save != 0); weights in the
- * layout of nf_gnt_pack_mfma.  S must satisfy nf_gnt_mfma_supported. */
+/* Same arguments as nf_gnt_fwd (workspace of nf_gnt_workspace_floats, consumed by nf_gnt_bwd_mfma when save != 0); weights in
+ * the layout of nf_gnt_pack_mfma.  S must satisfy nf_gnt_mfma_supported. */
 extern "C" int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
                                const float* pts, const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save,
                                float* rgb, float* alpha, float* workspace, nf_stream_t stream) {
@@ -1290,7 +1296,7 @@ static int gm_launch_bwd(const float* mblob, const float* mask, const float* d_r
     return 0;
 }
 
-/* Same contract as nf_gnt_bwd: `workspace` is the buffer a forward (either one) with save != 0 filled. */
+/* Same arguments as nf_gnt_bwd; `workspace` is the buffer nf_gnt_fwd_mfma with save != 0 filled (not nf_gnt_fwd's). */
 extern "C" int nf_gnt_bwd_mfma(const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
                                int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream) {
     NF_REQUIRE(nf_gnt_mfma_supported(n_samples, n_views) && depth >= 1 && depth <= 16 && n_rays >= 0,

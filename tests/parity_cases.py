@@ -992,8 +992,8 @@ def check_gnt_alpha(dev, kernel_path=None):
 
 
 def check_gnt_mfma_vs_generic(dev, shapes=((2, 32, 3, 2),)):
-    """Matrix-core GNT forward vs the shape-generic forward on random weights / inputs: the colour, and the gradient the
-    (shared) backward kernel derives from the activations each forward saved -- which checks every saved slot."""
+    """Matrix-core GNT kernels vs the shape-generic ones on random weights / inputs: the colour (with and without saving),
+    the ret_alpha weights, and the gradient each backward derives from the activations its own forward saved."""
     from nerfool_amd.gnt.transformer_network import GNT
     for (R, S, V, depth) in shapes:
         torch.manual_seed(7 + S)
