@@ -8,5 +8,6 @@ cp $F/pmc_traffic.json $P/${ROUND}_pmc_traffic.json; cp $F/pmc_render_traffic.tx
 for c in c2 c4 c5; do
   cp $F/steady_state_kernels_$c.txt $P/${ROUND}_steady_state_kernels_$c.txt; cp $F/step_timeline_$c.txt $P/${ROUND}_step_timeline_$c.txt
   cp $F/pmc_traffic_$c.txt $P/${ROUND}_pmc_traffic_$c.txt; cp $F/rocprofv3_kernel_stats_$c.csv $P/${ROUND}_rocprofv3_kernel_stats_$c.csv
+  cp $F/sq_pipe_$c.txt $P/${ROUND}_sq_pipe_$c.txt
 done
 python tools/make_profile_summary.py $ROUND

@@ -75,6 +75,10 @@ def main():
                  rs['seconds'], rs['rays_per_s'] / 1e6, r8['rays_per_s'] / 1e6, r8['mfma_frac_of_peak'], r88['rays_per_s'] / 1e6,
                  r88['mfma_frac_of_peak']))
     md.append('Steady-state kernel table (rocprofv3 kernel trace, timed steps only):\n\n```\n' + text(rnd + '_steady_state_kernels_c2.txt', 40) + '\n```\n')
+    md.append('Issue counters of the same kernels (`tools/pmc_sq.sh`, one rocprofv3 --pmc pass per counter group; "mfma busy" =\n'
+              'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of the launch in which a SIMD\'s matrix pipe executes,\n'
+              'counting recomputed and padded products; "wait(cnt)" = SQ_WAIT_ANY / SQ_WAVE_CYCLES, the share of a wave\'s life spent in s_waitcnt):\n\n```\n'
+              + text(rnd + '_sq_pipe_c2.txt', 26) + '\n```\n')
     md.append('PMC HBM traffic per launch of the C-ABI entry points (`%s_pmc_traffic.json`):\n' % rnd)
     md.append('| entry point | calls / step | HBM MB / launch (PMC) | algorithmic MB |\n|---|---|---|---|')
     for name, v in pmc['abi_kernels'].items():
@@ -87,6 +91,7 @@ def main():
                                                     '' if tag == 'c4' else ' (fp32 rows: %.2f ms/step)' % c5f['ms_per_step']))
         md.append(table(bj['extra']['kernels']) + '\n')
         md.append('Steady-state kernel table:\n\n```\n' + text('%s_steady_state_kernels_%s.txt' % (rnd, tag), 24) + '\n```\n')
+        md.append('Issue counters:\n\n```\n' + text('%s_sq_pipe_%s.txt' % (rnd, tag), 14) + '\n```\n')
         md.append('PMC HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, separate passes):\n\n```\n' + text('%s_pmc_traffic_%s.txt' % (rnd, tag), 14) + '\n```\n')
     md.append('## MFMA / VALU overlap probe (`tools/experimental/probe_overlap.hip`)\n\n```\n' + text(rnd + '_probe_mfma_valu_overlap.txt') + '\n```\n')
     md.append('fp32 and bf16 matrix instructions and fp32 vector instructions of the waves of one SIMD do not overlap: the times add (DESIGN.md section 4).\n')

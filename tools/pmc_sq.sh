@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_sq_$TAG
 mkdir -p $OUT
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
            "SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
@@ -25,6 +25,17 @@ for f in sorted(glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True
         if flt not in k:
             continue
         tab[k][row['Counter_Name']].append(float(row['Counter_Value']))
+def mean(cs, c):
+    return sum(cs[c]) / len(cs[c]) if cs.get(c) else float('nan')
+# GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_*_CYCLES of waves are in units of 4 clocks, SQ_VALU_MFMA_BUSY_CYCLES in clocks
+print('%-44s %9s %10s %10s %10s %10s %9s' % ('kernel', 'launches', 'clocks', 'mfma busy', 'waves/SIMD', 'wait(cnt)', 'VALU:MFMA'))
+for k, cs in sorted(tab.items(), key=lambda kv: -mean(kv[1], 'GRBM_GUI_ACTIVE') * len(kv[1].get('GRBM_GUI_ACTIVE', []))):
+    clk = mean(cs, 'GRBM_GUI_ACTIVE') / 8.0
+    print('%-44s %9d %10.0f %10.3f %10.2f %10.3f %9.1f' % (k[:44], len(cs.get('GRBM_GUI_ACTIVE', [])), clk,
+          mean(cs, 'SQ_VALU_MFMA_BUSY_CYCLES') / (clk * 1024), 4 * mean(cs, 'SQ_WAVE_CYCLES') / (clk * 1024),
+          mean(cs, 'SQ_WAIT_ANY') / mean(cs, 'SQ_WAVE_CYCLES'),
+          (mean(cs, 'SQ_INSTS_VALU') - mean(cs, 'SQ_INSTS_MFMA')) / max(mean(cs, 'SQ_INSTS_MFMA'), 1.0)))
+print()
 for k, cs in tab.items():
     print(k)
     for c, v in sorted(cs.items()):

@@ -27,6 +27,12 @@ profile() {   # $1 tag, $2.. bench flags
 profile c2
 profile c4 --config c4
 profile c5 --config c5
+# issue / stall counters of the same steps (matrix-pipe busy fraction, waves per SIMD, s_waitcnt share, vector : matrix instructions)
+sq() { tag=$1; shift; bash $REPO/tools/pmc_sq.sh $tag k_ $REPO/bench.py "$@" --steps 3 --warmup 2 --extras 0 --event-every 0 --cpu-iters 0 > /dev/null 2>&1; head -34 $REPO/gpurun_out/pmc_sq_$tag.txt > $OUT/sq_pipe_$tag.txt; }
+sq c2
+sq c4 --config c4
+sq c5 --config c5
+cd /tmp
 python3 $REPO/bench.py --config c4 --steps 5 --warmup 2 --render-chunks 4 > $OUT/bench_gnt.json 2> $OUT/bench_gnt.err
 python3 $REPO/bench.py --config c5 --steps 10 --warmup 3 > $OUT/bench_c5_bf16.json 2> $OUT/bench_c5.err
 python3 $REPO/bench.py --config c5 --precision fp32 --steps 10 --warmup 3 > $OUT/bench_c5_fp32.json 2> $OUT/bench_c5_fp32.err
