@@ -25,8 +25,9 @@ for f in sorted(glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True
         if flt not in k:
             continue
         tab[k][row['Counter_Name']].append(float(row['Counter_Value']))
-def mean(cs, c):
-    return sum(cs[c]) / len(cs[c]) if cs.get(c) else float('nan')
+def mean(cs, c):          # the median launch: a first launch that also sets up scratch / LDS limits does not skew the row
+    v = sorted(cs.get(c, []))
+    return v[len(v) // 2] if v else float('nan')
 # GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_*_CYCLES of waves are in units of 4 clocks, SQ_VALU_MFMA_BUSY_CYCLES in clocks
 print('%-44s %9s %10s %10s %10s %10s %9s' % ('kernel', 'launches', 'clocks', 'mfma busy', 'waves/SIMD', 'wait(cnt)', 'VALU:MFMA'))
 for k, cs in sorted(tab.items(), key=lambda kv: -mean(kv[1], 'GRBM_GUI_ACTIVE') * len(kv[1].get('GRBM_GUI_ACTIVE', []))):
