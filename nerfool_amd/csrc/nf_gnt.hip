@@ -94,8 +94,9 @@ struct GntCtx {
 #define STAGE_BEGIN if (act) {
 #define STAGE_END } __syncthreads();
 
-#define ROWP(slot) (c.ws_row + ((size_t)(slot) * c.V + v) * c.S + c.s)
-#define ROWSTRIDE ((size_t)c.V * c.S)
+// per-(sample, view) slots: [view][slot][sample] -- all slots of one view within one base + compile-time offsets (nf_gnt.h)
+#define ROWP(slot) (c.ws_row + ((size_t)v * row_floats + (slot)) * c.S + c.s)
+#define ROWSTRIDE ((size_t)c.S)
 #define ROW(slot, j) ROWP(slot)[(size_t)(j) * ROWSTRIDE]
 #define SMPP(slot) (c.ws_smp + (size_t)(slot) * c.S + c.s)
 #define SMP(slot, j) SMPP(slot)[(size_t)(j) * c.S]

@@ -291,12 +291,8 @@ __device__ __forceinline__ int gm_opaque_zero() {
     return z;
 }
 // acc += sum over NSTEPS k-steps: records at rec (L2 or LDS), B operand = x[r]
-#ifndef GM_FENCE
-#define GM_FENCE 0
-#endif
 template <int NSTEPS>
 __device__ __forceinline__ g16 gm_gemm(const float* __restrict__ rec, int lane, const g16& x, g16 acc) {
-    if (GM_FENCE) asm volatile("" ::: "memory");      // keeps the record loads of LATER k-blocks from being hoisted up here
 #pragma unroll
     for (int r = 0; r < NSTEPS; ++r) acc = GM_MFMA(rec[r * 64 + lane], x[r], acc);
     return acc;
@@ -372,18 +368,19 @@ __device__ __forceinline__ V64 gm_lin64_s(GmW& w, const float* __restrict__ tb, 
 }
 
 // Workspace addressing: feature 32 t + n(r, h) = [32 t + n(r, 0)] + 4 h, so every access is a WAVE-UNIFORM base (scalar
-// registers, scalar arithmetic) plus one of two per-lane 32-bit offsets computed once: 4 h S + s for the per-sample slots,
-// 4 h V S + s for the per-(sample, view) slots.  (Per-element 64-bit vector address arithmetic, hoisted out of the view loop
+// registers, scalar arithmetic) plus ONE per-lane 32-bit offset computed once, 4 h S + s, plus a compile-time multiple of S:
+// the per-(sample, view) slots are laid out [view][slot][sample], so one base per view serves all of a view's slots.  (Per-element 64-bit vector address arithmetic, hoisted out of the view loop
 // by the optimiser, was worth ~450 spilled registers.)
 struct GmCtx {
-    float* ws_row;      // [slot][V][S], uniform
+    float* ws_row;      // [V][slot][S], uniform
     float* ws_smp;      // [slot][S], uniform
+    int64_t view_floats;        // floats of one view's slots = row_floats * S
     int S, V, s, h;
     unsigned row_lane, smp_lane;
 };
 __device__ __forceinline__ float* gm_smp_at(const GmCtx& c, int slot_feature) { return c.ws_smp + (size_t)slot_feature * c.S; }
 __device__ __forceinline__ float* gm_row_at(const GmCtx& c, int slot_feature, int v) {
-    return c.ws_row + ((size_t)slot_feature * c.V + v) * c.S;
+    return c.ws_row + (size_t)v * c.view_floats + (size_t)slot_feature * c.S;
 }
 __device__ __forceinline__ void gm_store_smp(const GmCtx& c, int slot, const V64& x) {
 #pragma unroll
@@ -512,7 +509,8 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
     GmCtx c;
     c.S = S; c.V = V; c.s = wave * 32 + m; c.h = h;
     c.smp_lane = (unsigned)(4 * h * S + c.s);
-    c.row_lane = (unsigned)(4 * h * V * S + c.s);
+    c.row_lane = (unsigned)(4 * h * S + c.s);
+    c.view_floats = row_floats * S;
     const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;
     c.ws_row = ws + ray * per_ray;
     c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
@@ -950,7 +948,8 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
     GmCtx c;
     c.S = S; c.V = V; c.s = wave * 32 + m; c.h = h;
     c.smp_lane = (unsigned)(4 * h * S + c.s);
-    c.row_lane = (unsigned)(4 * h * V * S + c.s);
+    c.row_lane = (unsigned)(4 * h * S + c.s);
+    c.view_floats = row_floats * S;
     const size_t per_ray = (size_t)S * V * row_floats + (size_t)S * smp_floats;
     c.ws_row = ws + ray * per_ray;
     c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
