@@ -1094,6 +1094,40 @@ def check_gnt_attack_step(dev):
     assert_close(atk_state.delta.detach(), want, 0, 2e-7, 'GNT delta after the fused Adam step')
 
 
+def check_gnt_attack_gradient_kernel_paths(dev, shapes=((10, 32, 3, 2), (6, 64, 5, 2))):
+    """d loss / d delta of a GNT attack gradient at sample counts the matrix-core kernels take (the reference captures use 8 / 12
+    samples, which run on the shape-generic kernels): matrix-core forward + backward against the shape-generic pair, whose
+    parity with the reference check_gnt / check_gnt_attack_step pin."""
+    from nerfool_amd.gnt import eval_adv as GEA
+    from nerfool_amd.gnt import transformer_network as gnt_tn
+    from nerfool_amd.gnt.model import GNTModel
+    from nerfool_amd.synthetic import make_scene
+    for (R, S, V, depth) in shapes:
+        torch.manual_seed(3)
+        H, W = 48, 64
+        args = SimpleNamespace(netwidth=64, trans_depth=depth, single_net=True, ret_alpha=False, coarse_feat_dim=32, fine_feat_dim=32,
+                               N_rand=R, N_samples=S, N_importance=0, inv_uniform=True, det=True, white_bkgd=False, epsilon=8, adv_lr=2,
+                               use_adam=True, adam_lr=1e-3, lr_step_size=100, lr_gamma=0.5, adv_iters=1, sample_mode='uniform',
+                               center_ratio=0.8, ckpt_path=None)
+        model = GNTModel(args, device=dev)
+        model.switch_to_eval()
+        data = make_scene(H, W, V, seed=23, tilt=0.3)
+        src = RaySamplerSingleImage(data, dev).get_all()
+        picks = np.random.RandomState(6).choice(H * W, size=(R,), replace=False)
+        grads = {}
+        for path in ('mfma', 'generic'):
+            saved, gnt_tn.KERNEL_PATH = gnt_tn.KERNEL_PATH, path
+            try:
+                torch.manual_seed(11)              # the same random start delta in both variants
+                atk_state = GEA.PGDAttack(args, model, Projector(dev), src)
+                grads[path] = atk_state.gradient(data, select_inds=picks).detach().cpu().double().clone()
+            finally:
+                gnt_tn.KERNEL_PATH = saved
+        err = float((grads['mfma'] - grads['generic']).norm() / grads['generic'].norm())
+        print('[grad parity] GNT S %d V %d: d loss / d delta, matrix-core vs generic kernels rel-L2 %.3e' % (S, V, err))
+        assert grads['generic'].abs().max() > 0 and err <= 1e-4
+
+
 def check_eval_views_gnt_and_frames(dev):
     """eval_views on the GNT flavour (eval/gnt/eval.py:140-236: its own render_single_image, PSNR of the rendered level) and
     the frame loop of render_llff_video.py:156-223 / eval/gnt/render.py:41-98 (`render_frames`): against render_single_image

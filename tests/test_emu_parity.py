@@ -195,6 +195,10 @@ def test_gnt_matrix_core_forward_matches_generic():
     pc.check_gnt_mfma_vs_generic('cpu', shapes=((2, 32, 3, 2),))
 
 
+def test_gnt_attack_gradient_on_the_matrix_core_kernels():
+    pc.check_gnt_attack_gradient_kernel_paths('cpu', shapes=((4, 32, 3, 2),))
+
+
 def test_gnt_ret_alpha_and_hierarchical_sampling():
     # shape-generic kernels here (4 s); the matrix-core kernels take 4 minutes to emulate on this case: their ret_alpha output
     # is compared with the generic one in test_gnt_matrix_core_forward_matches_generic, the full case runs on the GPU

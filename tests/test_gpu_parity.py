@@ -296,6 +296,10 @@ def test_gnt_matrix_core_forward_matches_generic(shape):
     pc.check_gnt_mfma_vs_generic('cuda', shapes=(shape,))
 
 
+def test_gnt_attack_gradient_on_the_matrix_core_kernels():
+    pc.check_gnt_attack_gradient_kernel_paths('cuda')
+
+
 def test_evaluate_view_metrics():
     pc.check_evaluate_view('cuda')
 
