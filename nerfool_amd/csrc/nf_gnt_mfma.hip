@@ -489,11 +489,14 @@ template <int NW> struct GmLds {
 };
 
 
-template <int NW>
+// SAVE (write what the backward reads) is a template flag, not an argument: inside the view loop the count of stores that follow the
+// next view's loads then is a compile-time fact, and the wait in front of the loop's back edge is vmcnt(32) instead of a vmcnt(0) that
+// sits out the acknowledgements of the stores
+template <int NW, bool SAVE>
 __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restrict__ wb, const float* __restrict__ rgb_feat_all,
                                                           const float* __restrict__ ray_diff_all, const float* __restrict__ mask_all,
                                                           const float* __restrict__ pts, const float* __restrict__ ray_d, int V,
-                                                          int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
+                                                          int depth, float* __restrict__ rgb_out, float* __restrict__ ws,
                                                           int64_t row_floats, int64_t smp_floats, float* __restrict__ alpha_out) {
     HIP_DYNAMIC_SHARED(float, lds)
     constexpr int S = 32 * NW;
@@ -517,7 +520,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
     const float* rgb_feat = rgb_feat_all + ray * S * V * 35;
     const float* ray_diff = ray_diff_all + ray * S * V * 4;
     const float* mask = mask_all + ray * S * V;
-    const bool sv = save != 0;
+    constexpr bool sv = SAVE;
 
     // ---- stem: X_v = W2 relu(W1 rgb_feat_v + b1) + b2 (kept in the workspace), q = max over the views (first maximum wins)
     V64 cur, amax;
@@ -1121,6 +1124,13 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
             // the view softmax: p_v = exp(logit_v - mx) rs with the forward's running maximum and reciprocal sum; rs is folded
             // into du (dur = rs du), and sum_v p_v (v + pos)_v du = u du with the forward's u = sum_v p_v (v + pos)_v
             V64 dur, sp, dqs;
+            // the view's saved activations are fetched one view ahead: issued in front of the LAST GEMM of the previous view (a
+            // 64-MFMA window, and the point of the body with the fewest live registers).  View 0's are requested HERE, in front of
+            // the statistics loads below: every path into the loop then has the 32 d X_v atomics / the statistics loads behind
+            // them in the memory counter, and the wait at the loop top is vmcnt(32), not vmcnt(0) -- it does not sit out the atomics
+            V64 pr = gm_load_row(c, lr + RWL_PROB, 0), vp = gm_load_row(c, lr + RWL_VP, 0);
+            float mk = mask[(size_t)c.s * V];
+            GM_PIN();
             const V64 mx = gm_load_smp(c, ls + SL_MX);
             {
                 const V64 u = gm_load_smp(c, ls + SL_U), rs = gm_load_smp(c, ls + SL_RS);
@@ -1133,11 +1143,6 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
                     }
             }
             dqs.t[0] = dqs.t[1] = gm_zero();
-            // the view's saved activations are fetched one view ahead: issued in front of the LAST GEMM of the previous view (a
-            // 64-MFMA window, and the point of the body with the fewest live registers)
-            V64 pr = gm_load_row(c, lr + RWL_PROB, 0), vp = gm_load_row(c, lr + RWL_VP, 0);
-            float mk = mask[(size_t)c.s * V];
-            GM_PIN();
             for (int v = 0; v < V; ++v) {
                 const int oz = gm_opaque_zero();
                 const float* Bs = Bst + oz;
@@ -1240,7 +1245,8 @@ static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray
     bool& configured = configured_on[nf_current_device()];
     const size_t smem = GmLds<NW>::FLOATS * sizeof(float);
     if (!configured && smem > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
             nf_set_error("nf_gnt_fwd_mfma: cannot reserve %zu bytes of LDS", smem);
             return 1;
         }
@@ -1251,9 +1257,14 @@ static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray
     const int64_t step = save ? n_rays : GNT_RAYS_PER_LAUNCH;
     for (int64_t r0 = 0; r0 < n_rays; r0 += step) {
         const int64_t nr = n_rays - r0 < step ? n_rays - r0 : step;
-        hipLaunchKernelGGL(k_gnt_fwd_mfma<NW>, dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
-                           ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, V, depth, save ? 1 : 0,
-                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf, alpha ? alpha + r0 * S : nullptr);
+        if (save)
+            hipLaunchKernelGGL((k_gnt_fwd_mfma<NW, true>), dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
+                               ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, V, depth, rgb + r0 * 3,
+                               workspace + r0 * per_ray, rf, sf, alpha ? alpha + r0 * S : nullptr);
+        else
+            hipLaunchKernelGGL((k_gnt_fwd_mfma<NW, false>), dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
+                               ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, V, depth, rgb + r0 * 3,
+                               workspace, rf, sf, alpha ? alpha + r0 * S : nullptr);
         NF_LAUNCH_CHECK("nf_gnt_fwd_mfma");
     }
     return 0;
