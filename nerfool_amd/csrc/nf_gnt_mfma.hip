@@ -52,7 +52,7 @@ enum { MS_L1 = 0, MS_L2 = 36, MS_RECORDS = 100, MS_B1 = MS_RECORDS * 64, MS_B2 =
 // final: norm weight, bias (fragment order), rgb_fc weight [3] x fragment order, bias 3 (+1 pad)
 enum { MF_LNW = 0, MF_LNB = 64, MF_W = 128, MF_B = 320, GM_FINAL_FLOATS = 324 };
 
-NF_HD inline int64_t gm_layer_base(int i) { return GM_STEM_FLOATS + (int64_t)i * GM_LAYER_FLOATS; }
+NF_HD int64_t gm_layer_base(int i) { return GM_STEM_FLOATS + (int64_t)i * GM_LAYER_FLOATS; }
 
 // ---- backward section (behind the forward section): transposed records (dX^T = W^T dY^T) in the order the backward
 //      consumes them, layers stored in forward order but walked from the last to the first
@@ -65,9 +65,9 @@ enum {
     BSTEM_RECORDS = 128                // rgbfeat_fc.2^T (64 <- 64), rgbfeat_fc.0^T (35 <- 64: two tiles)
 };
 static constexpr int64_t GM_BWD_LAYER_FLOATS = (int64_t)BG_LAYER_RECORDS * 64;
-NF_HD inline int64_t gm_fwd_floats(int depth) { return GM_STEM_FLOATS + (int64_t)depth * GM_LAYER_FLOATS + GM_FINAL_FLOATS + GM_BLOB_PAD; }
-NF_HD inline int64_t gm_bwd_layer_base(int depth, int i) { return gm_fwd_floats(depth) + (int64_t)i * GM_BWD_LAYER_FLOATS; }
-NF_HD inline int64_t gm_bwd_stem_base(int depth) { return gm_bwd_layer_base(depth, depth); }
+NF_HD int64_t gm_fwd_floats(int depth) { return GM_STEM_FLOATS + (int64_t)depth * GM_LAYER_FLOATS + GM_FINAL_FLOATS + GM_BLOB_PAD; }
+NF_HD int64_t gm_bwd_layer_base(int depth, int i) { return gm_fwd_floats(depth) + (int64_t)i * GM_BWD_LAYER_FLOATS; }
+NF_HD int64_t gm_bwd_stem_base(int depth) { return gm_bwd_layer_base(depth, depth); }
 
 extern "C" int64_t nf_gnt_mfma_blob_floats(int depth) { return gm_bwd_stem_base(depth) + BSTEM_RECORDS * 64 + GM_BLOB_PAD; }
 
