@@ -53,7 +53,7 @@ class _GNTFunction(torch.autograd.Function):
     def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, mfma_blob, depth, ret_alpha):
         need_grad = rgb_feat.requires_grad
         if mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2]):
-            # same workspace layout as the generic forward: the backward below consumes either
+            # (each backward reads what ITS forward saved: ctx.use_mfma picks the matching one below)
             out = ops.gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha)
         else:
             out = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha)
