@@ -166,11 +166,12 @@ int nf_debug_mfma32(const float* a, const float* b, const float* c, float* d, nf
 /* ------------------------------------------------------------------------------------------------------------------
  * a6  raw2outputs                          ref: ibrnet/render_ray.py:123-170
  * raw [R,S,4], z_vals [R,S], pixel_mask [R,S] bytes (0/1) -> rgb [R,3], depth [R], weights [R,S], alpha [R,S],
- * ray_mask [R] bytes (sum_s pixel_mask > 8).
+ * ray_mask [R] bytes (sum_s pixel_mask > 8).  Exactly one of pixel_mask and view_mask is given: view_mask [R,S,n_views] are the
+ * projector's per-view validity flags, from which the kernel forms pixel_mask = (sum_v view_mask > 1) itself (:210).
  * ---------------------------------------------------------------------------------------------------------------- */
-int nf_composite_fwd(const float* raw, const float* z_vals, const uint8_t* pixel_mask, int64_t n_rays, int n_samples,
-                     int white_bkgd, float* rgb, float* depth, float* weights, float* alpha, uint8_t* ray_mask,
-                     nf_stream_t stream);
+int nf_composite_fwd(const float* raw, const float* z_vals, const uint8_t* pixel_mask, const float* view_mask, int n_views,
+                     int64_t n_rays, int n_samples, int white_bkgd, float* rgb, float* depth, float* weights, float* alpha,
+                     uint8_t* ray_mask, nf_stream_t stream);
 /* upstream gradients (each nullable): d_rgb [R,3], d_depth [R], d_weights [R,S], d_alpha [R,S] -> d_raw [R,S,4] */
 int nf_composite_bwd(const float* raw, const float* z_vals, int64_t n_rays, int n_samples, int white_bkgd,
                      const float* d_rgb, const float* d_depth, const float* d_weights, const float* d_alpha,

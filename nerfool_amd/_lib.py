@@ -53,7 +53,7 @@ _PROTOTYPES = {
     'nf_ibrnet_fwd_mfma_bf16': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_ibrnet_bwd_mfma_bf16': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_debug_mfma32': (c_int, [_P, _P, _P, _P, _P]),
-    'nf_composite_fwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'nf_composite_fwd': (c_int, [_P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'nf_composite_bwd': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'nf_sample_fine': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_sample_pdf': (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P]),

@@ -31,8 +31,12 @@ __device__ __forceinline__ float nf_wave_excl_suffix_sum(float v, int lane) {
 // ---------------------------------------------------------------------------------------------------------------
 // a6 forward.  alpha = 1-exp(-sigma); T = exclusive cumprod(1-alpha+1e-10); w = alpha*T   (render_ray.py:139-153)
 // ---------------------------------------------------------------------------------------------------------------
+// The per-sample mask "at least two valid observations" (render_ray.py:210) comes either ready (pixel_mask) or as the V per-view
+// validity flags of every sample (view_mask [R,S,V], what the projector / the gather-fused row kernel write): counting them here
+// saves the launch that used to turn one into the other.
 __global__ void __launch_bounds__(256) k_composite_fwd(const float* __restrict__ raw, const float* __restrict__ z_vals,
-                                                       const uint8_t* __restrict__ pixel_mask, int64_t n_rays, int S,
+                                                       const uint8_t* __restrict__ pixel_mask, const float* __restrict__ view_mask,
+                                                       int V, int64_t n_rays, int S,
                                                        int white_bkgd, float* __restrict__ rgb, float* __restrict__ depth,
                                                        float* __restrict__ weights, float* __restrict__ alpha_out,
                                                        uint8_t* __restrict__ ray_mask) {
@@ -59,7 +63,14 @@ __global__ void __launch_bounds__(256) k_composite_fwd(const float* __restrict__
         sb += w * rw[s * 4 + 2];
         sd += w * z_vals[rr * S + s];
         sw += w;
-        cnt += pixel_mask[rr * S + s] ? 1.f : 0.f;
+        if (pixel_mask) {
+            cnt += pixel_mask[rr * S + s] ? 1.f : 0.f;
+        } else {
+            const float* vm = view_mask + (rr * S + s) * V;
+            float seen = 0.f;
+            for (int v = 0; v < V; ++v) seen += vm[v];
+            cnt += seen > 1.f ? 1.f : 0.f;
+        }
         if (live) {
             weights[r * S + s] = w;
             alpha_out[r * S + s] = a;
@@ -77,14 +88,16 @@ __global__ void __launch_bounds__(256) k_composite_fwd(const float* __restrict__
     }
 }
 
-extern "C" int nf_composite_fwd(const float* raw, const float* z_vals, const uint8_t* pixel_mask, int64_t n_rays,
-                                int n_samples, int white_bkgd, float* rgb, float* depth, float* weights, float* alpha,
-                                uint8_t* ray_mask, nf_stream_t stream) {
+extern "C" int nf_composite_fwd(const float* raw, const float* z_vals, const uint8_t* pixel_mask, const float* view_mask,
+                                int n_views, int64_t n_rays, int n_samples, int white_bkgd, float* rgb, float* depth,
+                                float* weights, float* alpha, uint8_t* ray_mask, nf_stream_t stream) {
     NF_REQUIRE(n_rays >= 0 && n_samples >= 1 && n_samples <= 4096, "nf_composite_fwd: bad sizes (R %lld, S %d)",
                (long long)n_rays, n_samples);
     if (n_rays == 0) return 0;
+    NF_REQUIRE((pixel_mask != nullptr) != (view_mask != nullptr && n_views >= 1),
+               "nf_composite_fwd: exactly one of pixel_mask / view_mask (with n_views >= 1) must be given");
     hipLaunchKernelGGL(k_composite_fwd, dim3(nf_blocks(n_rays, NF_RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, raw,
-                       z_vals, pixel_mask, n_rays, n_samples, white_bkgd, rgb, depth, weights, alpha, ray_mask);
+                       z_vals, pixel_mask, view_mask, n_views, n_rays, n_samples, white_bkgd, rgb, depth, weights, alpha, ray_mask);
     NF_LAUNCH_CHECK("nf_composite_fwd");
     return 0;
 }

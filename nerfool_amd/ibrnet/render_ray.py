@@ -45,7 +45,8 @@ class _Composite(torch.autograd.Function):
 
 def raw2outputs(raw, z_vals, mask, white_bkgd=False, geo_noise=None):
     """ref: ibrnet/render_ray.py:123-170.  raw [N_rays, N_samples, 4], z_vals [N_rays, N_samples], mask (bool per sample:
-    at least two valid observations).  geo_noise is a training-only option of the reference and is rejected here."""
+    at least two valid observations -- or the per-view validity flags [N_rays, N_samples, V], from which the kernel forms it).
+    geo_noise is a training-only option of the reference and is rejected here."""
     if geo_noise is not None and geo_noise > 0:
         raise NotImplementedError('geo_noise is a training-time option outside the attack path')
     rgb, depth, weights, alpha, ray_mask = _Composite.apply(raw, z_vals, mask, bool(white_bkgd))
@@ -86,13 +87,14 @@ def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo
     if can is not None and ours and can(featmap, pts.shape[1], src['src_cameras'].shape[1]):
         # projection + bilinear gather run inside the network's row kernel (and their adjoint inside its backward)
         raw, mask = net.forward_gathered(pts, cams[0], src['src_rgbs'][0], featmap)
-        pixel_mask = ops.pixel_mask(mask)                    # at least 2 observations (:210)
+        views = mask                                    # [n_rays, n_samples, n_views]
     else:
         rgb_feat, ray_diff, mask = projector.compute(pts, ray_batch['camera'], src['src_rgbs'], src['src_cameras'],
                                                      featmaps=featmap, **({'cam_ws': cams[0]} if ours else {}))
-        pixel_mask = ops.pixel_mask(mask[..., 0])            # at least 2 observations (:210)
+        views = mask[..., 0]
         raw = net(rgb_feat, ray_diff, mask)
-    return raw2outputs(raw, z_vals, pixel_mask, white_bkgd=white_bkgd, geo_noise=geo_noise)
+    # "at least 2 observations" (:210) is counted by the compositing kernel from the per-view flags
+    return raw2outputs(raw, z_vals, views, white_bkgd=white_bkgd, geo_noise=geo_noise)
 
 
 def render_rays(ray_batch, model, featmaps, projector, N_samples, inv_uniform=False, N_importance=0, det=False,

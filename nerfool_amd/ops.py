@@ -341,19 +341,25 @@ def ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, anti_alias):
     return d_rgb_feat
 
 
-def composite_fwd(raw, z_vals, pixel_mask_b, white_bkgd):
+def composite_fwd(raw, z_vals, mask, white_bkgd):
+    """mask: the per-sample pixel mask [R,S] (bool) or the per-view validity flags [R,S,V] (float: the kernel counts them itself)"""
     raw, z_vals = _c(raw, 'raw'), _c(z_vals, 'z_vals')
-    pm = pixel_mask_b.contiguous()
-    if pm.dtype != torch.bool:
-        pm = pm != 0
     R, S, _ = raw.shape
+    if mask.dim() == 3:
+        pm, vm, V = None, _c(mask, 'view mask'), mask.shape[2]
+        if tuple(mask.shape[:2]) != (R, S):
+            raise ValueError('view mask %s does not match raw %s' % (tuple(mask.shape), tuple(raw.shape)))
+    else:
+        pm, vm, V = mask.contiguous(), None, 0
+        if pm.dtype != torch.bool:
+            pm = pm != 0
     dev = raw.device
     rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
     depth = torch.empty(R, dtype=torch.float32, device=dev)
     weights = torch.empty(R, S, dtype=torch.float32, device=dev)
     alpha = torch.empty(R, S, dtype=torch.float32, device=dev)
     ray_mask = torch.empty(R, dtype=torch.bool, device=dev)
-    _done(_lib.lib().nf_composite_fwd(_ptr(raw), _ptr(z_vals), _ptr(pm), R, S, int(bool(white_bkgd)), _ptr(rgb),
+    _done(_lib.lib().nf_composite_fwd(_ptr(raw), _ptr(z_vals), _ptr(pm), _ptr(vm), V, R, S, int(bool(white_bkgd)), _ptr(rgb),
                                            _ptr(depth), _ptr(weights), _ptr(alpha), _ptr(ray_mask), _stream(raw)),
                'nf_composite_fwd')
     return rgb, depth, weights, alpha, ray_mask
