@@ -7,6 +7,7 @@ eps 8/255): ray picking, ResUNet on the perturbed sources, coarse+fine render, m
 Adam/eps-ball/[0,1] update.  `value` = rays rendered-and-differentiated per second over all ranks.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W            # starts its own N rank processes (see spawn_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -102,6 +103,9 @@ def parse():
                     help='N > 1: --n-rand rays per rank (weak) or split over the ranks (strong)')
     ap.add_argument('--cpu-iters', type=int, default=10, help='timed CPU-oracle PGD iterations for cpu_baseline after 2 warm-ups (0 = skip)')
     ap.add_argument('--extras', type=int, default=1, help='0 = only the headline timed region (profiling runs)')
+    ap.add_argument('--device', choices=('gpu', 'cpu-standin'), default='gpu',
+                    help="'cpu-standin': FUNCTIONAL check of the launcher / sharding on a box without a GPU -- the kernels' CPU stand-in "
+                         "build (tests/host_harness), gloo, shape-generic kernels; tiny sizes only, never a measurement")
     ap.add_argument('--event-every', type=int, default=5,
                     help='HIP-event brackets around the roofline kernels on every N-th timed step (1 = every step, 0 = never)')
     return ap.parse_args()
@@ -246,7 +250,7 @@ def render_leg(model, projector, sampler, src_ray_batch, featmaps, n_chunks, sam
     """forward-only throughput on 4096-ray chunks with resident feature maps: 1 warm-up chunk + n_chunks timed PER RANK -- rank r
     renders the contiguous chunk block [r (n_chunks + 1), (r + 1)(n_chunks + 1)) of the image, nothing is exchanged; the rate is
     all ranks' rays over the slowest rank's time between barriers.  par = (rank, world, barrier, max_over_ranks)."""
-    rank, world, barrier, max_over_ranks = par if par is not None else (0, 1, torch.cuda.synchronize, lambda x: x)
+    rank, world, barrier, max_over_ranks = par if par is not None else (0, 1, SYNC, lambda x: x)
     if gnt:
         from nerfool_amd.gnt.render_ray import render_rays as gnt_render_rays
 
@@ -302,19 +306,67 @@ def exchange_microbench(shard, V, C, Hf, Wf, H, W, dev, view_sharded, reps=10):
     saved = (shard.collectives, shard.bytes, shard.shard_views)
     shard.shard_views = view_sharded
     once()
-    torch.cuda.synchronize()
+    SYNC()
     shard.dist.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         once()
-    torch.cuda.synchronize()
+    SYNC()
     dt = (time.perf_counter() - t0) / reps
     shard.collectives, shard.bytes, shard.shard_views = saved
     return 1e3 * dt
 
 
+def SYNC():
+    torch.cuda.synchronize()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process becomes a pure parent -- it has not touched the GPU (importing
+    torch does not) and never will -- and starts N fresh rank processes of this same script with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, one per GPU (the reference's multi-process scripts initialise themselves the same way, from LOCAL_RANK:
+    eval/gnt/eval_adv.py:1211-1214).  Rank 0's stdout (the ONE JSON line) is relayed; the other ranks' stdout goes to stderr.  If a
+    rank fails, the others are stopped (exact PIDs) and the parent exits with that rank's code."""
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC only on this pool (RCCL needs it)
+    base.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    out0 = tempfile.TemporaryFile(mode='w+')
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:         # a dead rank leaves the others waiting in a collective: stop them, by PID
+                    q.terminate()
+    out0.seek(0)
+    for line in out0:            # the JSON line to stdout; anything else a library printed on rank 0's stdout (gloo does) to stderr
+        (sys.stdout if line.lstrip().startswith('{') else sys.stderr).write(line)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     if a.config == 'c4':
         a.model = 'gnt'
     if a.config == 'c5':          # config 5 defaults unless the user overrode the sizes
@@ -328,25 +380,42 @@ def main():
         a.importance, a.cpu_iters = 0, 0
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if os.environ.get('NERFOOL_BENCH_FAIL_RANK') == str(rank):        # test hook of the launcher (tests/test_distributed_gloo.py)
+        sys.exit(3)
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == a.gpus, '--gpus %d but WORLD_SIZE %d (launch with torch.distributed.run for N > 1)' % (a.gpus, world)
-    # one rank per GPU; the modulo only matters for the 1-GPU debugging set-up below (several ranks on one device)
-    local_dev = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_dev)
-    dev = torch.device('cuda', local_dev)
+    standin = a.device == 'cpu-standin'
+    if standin:
+        a.extras, a.cpu_iters = 0, 0
+        # functional check without a GPU (tests/test_distributed_gloo.py): the CPU stand-in build of the kernel sources, bound from
+        # the test tree; the product package itself has no CPU path
+        global SYNC
+        SYNC = lambda: None          # noqa: E731
+        sys.path.insert(0, os.path.join(ROOT, 'tests', 'host_harness'))
+        import standin as _standin
+        _standin.install_emulated()
+        from nerfool_amd.ibrnet import feature_network as _fn, mlp_network as _mn
+        _mn.KERNEL_PATH, _fn.CNN_PATH = 'generic', 'torch'        # the matrix-core kernels / fused executor emulate ~30x slower
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(world, 1)))
+        dev = torch.device('cpu')
+    else:
+        # one rank per GPU; the modulo only matters for the 1-GPU debugging set-up below (several ranks on one device)
+        local_dev = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_dev)
+        dev = torch.device('cuda', local_dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # 'nccl' is RCCL.  NERFOOL_DIST_BACKEND=gloo lets several ranks share ONE GPU to exercise the sharded path on a
         # single-GPU box (RCCL refuses duplicate devices); it is a functional check, never a measurement.
-        backend = os.environ.get('NERFOOL_DIST_BACKEND', 'nccl')
+        backend = 'gloo' if standin else os.environ.get('NERFOOL_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
     # the library is built by ONE rank (a no-op when it is fresh, as on the GPU box where the built .so travels in the tree)
     import __graft_entry__ as entry
-    if rank == 0 and not os.path.exists(entry.LIB):
+    if rank == 0 and not standin and not os.path.exists(entry.LIB):
         entry.build()
     if world > 1:
         torch.distributed.barrier()
@@ -365,7 +434,7 @@ def main():
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        SYNC()
 
     def max_over_ranks(seconds):
         if world > 1:
@@ -377,10 +446,10 @@ def main():
     attack = make_attack(a.cnn_shard, a.scaling)
     # HIP events only around the kernels the roofline table prices (~10 of the ~250 launches of a step): bracketing every
     # launch costs ~1.5 ms of host time per step, which is visible now that the step is close to launch-bound
-    timer = prof.KernelTimer(only=ROOFLINE_KERNELS)
+    timer = None if standin else prof.KernelTimer(only=ROOFLINE_KERNELS)
     elapsed = max_over_ranks(time_steps(attack, data, a.steps, a.warmup, barrier, timer, a.event_every))
-    timed_steps = len(range(0, a.steps, a.event_every)) if a.event_every > 0 else 0
-    kernels = timer.summary()
+    timed_steps = len(range(0, a.steps, a.event_every)) if (a.event_every > 0 and timer is not None) else 0
+    kernels = {} if timer is None else timer.summary()
     final_loss = float(attack.last_loss)
     rays_per_step = a.n_rand * (world if a.scaling == 'weak' else 1)
     collectives_per_step = payload_per_step = None
@@ -580,6 +649,7 @@ def main():
         # the arithmetic type of the path: c5 runs the IBRNet row network on bf16 matrix-core operands (fp32 accumulate; CNN, per-ray
         # part, compositing and update in fp32)
         'dtype': 'bf16' if (a.precision == 'bf16') else 'f32', 'data': 'synthetic',
+        'device': 'MI355X (gfx950)' if not standin else 'cpu-standin: FUNCTIONAL check of the launcher / sharding, not a measurement',
         'config': {'workload': workload,
                    'rays_per_step_all_ranks': rays_per_step, 'parallelism': par,
                    'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step},

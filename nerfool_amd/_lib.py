@@ -2,8 +2,8 @@
 
 The product path has exactly one backend: the gfx950 library built in-tree by `__graft_entry__.build()`.
 If it is missing, or a tensor is not on a GPU, the call raises -- there is no CPU or PyTorch fallback.
-`use_library_for_tests` exists only so that the test-suite can point the same bindings at the CPU stand-in build of
-the kernel sources (tests/host_harness); nothing in this package calls it.
+The test-suite points the same bindings at the CPU stand-in build of the kernel sources from OUTSIDE the package
+(tests/host_harness/standin.py sets `_lib` / `_emulated`); nothing in this package does.
 """
 import ctypes
 import os
@@ -130,15 +130,6 @@ def lib():
         if handle.nf_abi_version() != ABI_VERSION:
             raise RuntimeError('nerfool_amd: ABI mismatch (library %d, binding %d)' % (handle.nf_abi_version(), ABI_VERSION))
         _lib = handle
-    return _lib
-
-
-def use_library_for_tests(path, emulated=True):
-    """TEST HOOK: bind a CPU stand-in build of the kernel sources (tests/host_harness); emulated=False binds another GPU
-    build of the same sources (tuning variants, tools/build_variant.sh)."""
-    global _lib, _emulated
-    _lib = bind(ctypes.CDLL(path))
-    _emulated = bool(emulated)
     return _lib
 
 

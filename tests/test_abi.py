@@ -80,7 +80,8 @@ def test_legacy_choice_matches_numpy(built_library):
     from nerfool_amd import _lib
     from nerfool_amd.ibrnet import sample_ray
     if _lib._lib is None:
-        _lib.use_library_for_tests(built_library, emulated=False)
+        from host_harness import standin
+        standin.use_library(built_library, emulated=False)
     gen = np.random.RandomState(234)
     for pop, size in ((756 * 1008, 512), (1, 1), (2, 2), (97, 0), (4096, 4096), (604 * 806, 4096), (65537, 300)):
         for _ in range(3):
@@ -106,7 +107,8 @@ def test_pixel_lookahead_keeps_the_stream(built_library):
     from nerfool_amd import _lib
     from nerfool_amd.ibrnet import sample_ray
     if _lib._lib is None:
-        _lib.use_library_for_tests(built_library, emulated=False)
+        from host_harness import standin
+        standin.use_library(built_library, emulated=False)
     plain = np.random.RandomState(234)
     sample_ray.rng.seed(234)
     for pop, size, ahead in ((5000, 64, True), (5000, 64, True), (5000, 64, True), (7000, 64, True), (7000, 32, False),

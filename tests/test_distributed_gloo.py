@@ -19,8 +19,9 @@ import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
 import numpy as np, torch
 import torch.distributed as dist
-from nerfool_amd import _lib
-_lib.use_library_for_tests(os.path.join(%(harness)r, 'libnerfool_emu.so'))
+sys.path.insert(0, %(harness)r)
+import standin
+standin.use_library(os.path.join(%(harness)r, 'libnerfool_emu.so'))
 from nerfool_amd.ibrnet import mlp_network, feature_network
 mlp_network.KERNEL_PATH = 'generic'          # the shape-generic kernels emulate ~30x faster than the MFMA ones; the sharding
 feature_network.CNN_PATH = 'torch'           # logic under test is the same
@@ -219,8 +220,9 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests')
 from types import SimpleNamespace
 import numpy as np, torch
 import torch.distributed as dist
-from nerfool_amd import _lib
-_lib.use_library_for_tests(os.path.join(%(harness)r, 'libnerfool_emu.so'))
+sys.path.insert(0, %(harness)r)
+import standin
+standin.use_library(os.path.join(%(harness)r, 'libnerfool_emu.so'))
 from nerfool_amd.ibrnet import mlp_network, feature_network
 mlp_network.KERNEL_PATH = 'generic'          # the matrix-core kernels emulate ~30x slower; the sharding under test is the same
 feature_network.CNN_PATH = 'torch'
@@ -335,3 +337,65 @@ def test_sharded_render_equals_single_process_bit_for_bit(tmp_path):
         assert keys and set(other.files) == set(keys)
         for k in keys:
             assert np.array_equal(other[k], ref[k]), k
+
+
+BENCH_TINY = ['--device', 'cpu-standin', '--height', '48', '--width', '64', '--n-rand', '24', '--samples', '8', '--importance', '8',
+              '--steps', '2', '--warmup', '1']
+
+
+def _bench(extra_args, env=None):
+    import json
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/clang++'):
+        pytest.skip('clang++ of the ROCm toolchain is needed to build the CPU stand-in')
+    subprocess.run([os.path.join(HARNESS, 'build.sh')], check=True, capture_output=True)
+    clean = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    clean.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + extra_args + BENCH_TINY, env=clean, capture_output=True,
+                       text=True, timeout=900)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    return p.returncode, [json.loads(l) for l in lines], p.stderr
+
+
+@pytest.mark.timeout(1200)
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus N` (the driver's command shape, no torch.distributed.run in front): the parent starts N fresh rank
+    processes itself and relays rank 0's ONE JSON line (reference precedent for self-initialising ranks:
+    eval/gnt/eval_adv.py:1211-1214).  Here on the kernels' CPU stand-in over gloo -- a functional check of launcher + sharding."""
+    rc, out, err = _bench(['--gpus', '2'])
+    assert rc == 0, err[-2000:]
+    assert len(out) == 1, 'exactly ONE JSON line on stdout'
+    line = out[0]
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
+    assert line['config']['collectives_per_step'] == 2          # north-star form: 16-byte all-reduce + ONE d delta all-reduce
+    assert line['config']['rays_per_step_all_ranks'] == 48 and line['scaling'] == 'weak'
+    assert line['value'] > 0 and abs(line['value'] - 48 * 2 / (line['ms_per_step'] * 2e-3)) <= 1e-6 * line['value']
+    assert 'cpu-standin' in line['device']
+    # N = 1 keeps its shape (no spawn, no collectives)
+    rc1, out1, err1 = _bench(['--gpus', '1'])
+    assert rc1 == 0, err1[-2000:]
+    assert len(out1) == 1 and out1[0]['n_gpus'] == 1 and out1[0]['config']['collectives_per_step'] is None
+    assert set(out1[0]) == set(line)
+    # the same final loss on the union of the rays is NOT expected (weak scaling doubles the batch); strong scaling reproduces N = 1
+    rc2, out2, err2 = _bench(['--gpus', '2', '--scaling', 'strong'])
+    assert rc2 == 0, err2[-2000:]
+    assert abs(out2[0]['extra']['final_loss'] - out1[0]['extra']['final_loss']) <= 1e-4 * abs(out1[0]['extra']['final_loss'])
+
+
+@pytest.mark.timeout(600)
+def test_bench_parent_fails_when_a_rank_fails():
+    """a rank that dies takes the whole run down with a non-zero exit code instead of leaving its peers in a collective"""
+    rc, out, err = _bench(['--gpus', '2'], env={'NERFOOL_BENCH_FAIL_RANK': '1'})
+    assert rc != 0 and out == []
+
+
+@pytest.mark.timeout(600)
+def test_bench_under_torch_distributed_run_still_works():
+    import json
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/clang++'):
+        pytest.skip('clang++ of the ROCm toolchain is needed to build the CPU stand-in')
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29577', os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + BENCH_TINY,
+                       capture_output=True, text=True, timeout=580)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.lstrip().startswith('{')]
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['config']['collectives_per_step'] == 2

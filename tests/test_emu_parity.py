@@ -23,7 +23,8 @@ def emulated_library():
     from nerfool_amd import _lib
     from nerfool_amd.ibrnet import mlp_network
     saved = (_lib._lib, _lib._emulated, mlp_network.KERNEL_PATH)
-    _lib.use_library_for_tests(os.path.join(HARNESS, 'libnerfool_emu.so'))
+    from host_harness import standin
+    standin.use_library(os.path.join(HARNESS, 'libnerfool_emu.so'))
     # the product's default dispatch: matrix-core kernels (emulated MFMA) and the fused CNN executor, exactly what runs on the GPU
     yield
     _lib._lib, _lib._emulated, mlp_network.KERNEL_PATH = saved

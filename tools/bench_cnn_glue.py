@@ -25,7 +25,9 @@ def timed(fn, iters):
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     if len(sys.argv) > 2:
-        _lib.use_library_for_tests(sys.argv[2], emulated=False)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'host_harness'))
+        import standin          # test hook: bind a tuning build of the kernel sources
+        standin.use_library(sys.argv[2], emulated=False)
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
     tot = 0.0

@@ -16,7 +16,9 @@ GNT_FWD_FLOPS_PER_RAY = 217.0e6       # V = 10, S = 64, depth 8
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     if len(sys.argv) > 2:
-        _lib.use_library_for_tests(sys.argv[2], emulated=False)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'host_harness'))
+        import standin          # test hook: bind a tuning build of the kernel sources
+        standin.use_library(sys.argv[2], emulated=False)
     dev = torch.device('cuda', 0)
     R, S, V, depth = 512, 64, 10, 8
     torch.manual_seed(0)

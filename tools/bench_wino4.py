@@ -9,7 +9,9 @@ import torch
 import torch.nn.functional as F
 from nerfool_amd import _lib, ops
 if os.environ.get('NF_VARIANT_LIB'):
-    _lib.use_library_for_tests(os.environ['NF_VARIANT_LIB'], emulated=False)
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'host_harness'))
+    import standin          # test hook: bind a tuning build of the kernel sources
+    standin.use_library(os.environ['NF_VARIANT_LIB'], emulated=False)
 
 EXP = os.path.join(ROOT, 'tools', 'experimental')
 SO = os.path.join(EXP, 'libnf_wino4.so')
