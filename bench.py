@@ -258,7 +258,12 @@ def render_leg(model, projector, sampler, src_ray_batch, featmaps, n_chunks, sam
             kw.pop('N_importance', None)
             return gnt_render_rays(rb, model, featmaps, projector, n_samples, N_importance=0, **kw)
     else:
-        from nerfool_amd.ibrnet.render_ray import render_rays
+        from nerfool_amd.ibrnet.render_ray import camera_workspace, render_rays as ibr_render_rays
+        # a chunk loop over ONE view builds the cameras' projection workspace once, as render_single_image does
+        ws = camera_workspace(sampler.get_all(), src_ray_batch)
+
+        def render_rays(rb, model, featmaps, projector, n_samples, **kw):
+            return ibr_render_rays(rb, model, featmaps, projector, n_samples, cam_ws=ws, **kw)
     rays = sampler.get_all()
     total = rays['ray_o'].shape[0] // 4096          # whole chunks of the image; a rank's block wraps around when the image is short
     first = rank * (n_chunks + 1)

@@ -1,7 +1,12 @@
 """GNT as an nn.Module whose forward and backward are HIP kernels.  The module tree reproduces the parameter names of
 gnt/transformer_network.py:205-268 (rgbfeat_fc, view_crosstrans.N.{attn_norm, ff_norm, ff.fc1/fc2, attn.{q_fc,k_fc,v_fc,
 pos_fc.0/2, attn_fc.0/2, out_fc}}, view_selftrans.N.{...}, q_fcs.N.0/2 on even N, norm, rgb_fc) so that the public GNT
-checkpoints load by key.  Eval-mode semantics (Dropout = identity); the parameters are constants of the attack."""
+checkpoints load by key.  Eval-mode semantics (Dropout = identity); the parameters are constants of the attack.
+
+Train mode is REJECTED, loudly: the reference's universal GNT loop runs before `model.switch_to_eval()` (eval/gnt/eval_adv.py:739-878
+vs :959), i.e. with the `Dropout(0.1)` of every attention / feed-forward block active (gnt/transformer_network.py:45,72,136) -- a
+stochastic forward whose masks come from torch's global generator.  The kernels implement no dropout, so a module left in training
+mode raises instead of silently computing something else than the reference would."""
 import torch
 import torch.nn as nn
 
@@ -115,6 +120,10 @@ class GNT(nn.Module):
 
     def forward(self, rgb_feat, ray_diff, mask, pts, ray_d):
         """rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V,1], pts [R,S,3], ray_d [R,3] -> rgb [R,3] (or [R,3+S])"""
+        if self.training:
+            raise RuntimeError('nerfool_amd GNT runs eval-mode semantics only (Dropout = identity): call model.switch_to_eval() / '
+                               '.eval() first.  The reference leaves Dropout(0.1) active in its universal GNT loop '
+                               '(eval/gnt/eval_adv.py:739-878 runs before switch_to_eval at :959); that stochastic variant is not built.')
         blob, mfma_blob = self._packed(rgb_feat.device)
         rgb, alpha = _GNTFunction.apply(rgb_feat, ray_diff, mask[..., 0], pts.detach(), ray_d.detach(), blob, mfma_blob,
                                         self.trans_depth, bool(self.ret_alpha))

@@ -16,7 +16,8 @@ from collections import OrderedDict
 
 import torch
 
-from .render_ray import render_rays, render_rays_hybrid
+from .projection import Projector
+from .render_ray import camera_workspace, render_rays, render_rays_hybrid
 
 _WHOLE = ('camera', 'depth_range', 'src_rgbs', 'src_cameras')
 _LEVELS = ('outputs_coarse', 'outputs_fine')
@@ -102,7 +103,9 @@ class ShardCollector:
     """This rank's chunk outputs stay in HBM as ONE packed fp32 record per ray (all fields of both levels side by side, in
     schema order; bool / integer fields travel as 0.0 / 1.0 resp. their exact float value), padded to the longest block, so
     that a single collective assembles the image.  The schema -- (level, key, trailing shape, dtype) of every field --
-    follows from the first chunk; a rank without any chunk learns it from rank 0."""
+    follows from the first chunk; a rank without any chunk (fewer chunks than ranks) learns it by rendering the image's first ray
+    itself (`run_chunks`), so the ONE gather stays the only collective of an image.  Fields must be float32 or bool: the records
+    travel as fp32 (an integer field above 2^24 or a float64 field would be rounded silently -- rejected instead)."""
 
     def __init__(self, n_rays, chunk_size, shard, device):
         self.n_rays, self.chunk_size, self.shard, self.device = n_rays, chunk_size, shard, device
@@ -123,8 +126,17 @@ class ShardCollector:
                 schema.append((level, None, None, None))
                 continue
             for k, v in ret[level].items():
+                if v is not None and v.dtype not in (torch.float32, torch.bool):
+                    raise TypeError('sharded render: field %s/%s is %s; the packed per-ray records carry float32 and bool fields only'
+                                    % (level, k, v.dtype))
                 schema.append((level, k, None, None) if v is None else (level, k, tuple(v.shape[1:]), str(v.dtype)))
         return schema
+
+    def learn_schema(self, ret):
+        """record layout from the outputs of any chunk (their leading dimension is not part of it)"""
+        if self.schema is None:
+            self.schema = self._schema_of(ret)
+            self._alloc()
 
     @staticmethod
     def _width(shape):
@@ -135,13 +147,11 @@ class ShardCollector:
 
     def _alloc(self):
         width = sum(self._width(s) for _, k, s, _ in self.schema if k is not None and s is not None)
-        # (no fill here: chunks arrive on alternating streams, a fill enqueued with the first one could land on top of the second's rows)
+        # (no fill: every row of this rank's block is written by `add`, the padding rows behind it are zeroed in `finish`)
         self.buf = torch.empty(self.rows, width, dtype=torch.float32, device=self.device)
 
     def add(self, i, ret):
-        if self.schema is None:
-            self.schema = self._schema_of(ret)
-            self._alloc()
+        self.learn_schema(ret)
         r0 = i - self.lo * self.chunk_size
         col = 0
         for level, k, shape, _ in self.schema:
@@ -156,13 +166,7 @@ class ShardCollector:
         """-> the reference's return schema on the gathering rank (host tensors), None on the others"""
         shard = self.shard
         dist = shard.dist
-        if self.n_chunks < shard.world:       # some rank rendered nothing and has no schema yet (the same test on every rank)
-            box = [self.schema if shard.rank == 0 else None]
-            dist.broadcast_object_list(box, src=shard.global_rank(0), group=shard.group)
-            if self.schema is None and box[0] is not None:
-                self.schema = box[0]
-                self._alloc()
-        if self.schema is None:               # an image without rays: nothing to assemble
+        if self.schema is None:               # an image without rays (on every rank alike): nothing to assemble, no collective
             return OrderedDict([('outputs_coarse', OrderedDict()), ('outputs_fine', OrderedDict())])
         n_mine = max(0, min(self.hi * self.chunk_size, self.n_rays) - self.lo * self.chunk_size)
         if n_mine < self.rows:
@@ -219,6 +223,10 @@ def run_chunks(ray_batch, chunk_size, render_chunk, hs, ws, shard=None):
             for k, v in ray_batch.items():
                 chunk[k] = v if (k in _WHOLE or v is None) else v[i:i + chunk_size]
             out.add(i, render_chunk(chunk))
+        if n_rays > 0 and getattr(out, 'schema', True) is None:
+            # a rank without a chunk of its own: the record layout from the image's first ray (deterministic on every rank, no
+            # exchange -- the image's one collective stays the gather)
+            out.learn_schema(render_chunk(OrderedDict((k, v if (k in _WHOLE or v is None) else v[0:1]) for k, v in ray_batch.items())))
     return out.finish(hs, ws)
 
 
@@ -235,11 +243,15 @@ def render_single_image(ray_sampler, ray_batch, model, projector, chunk_size, N_
     if hybrid:
         render_chunk = lambda chunk: render_rays_hybrid(chunk, model, featmaps, featmaps_clean=featmaps_clean, **kw)
     else:
+        # every chunk sees the same cameras: their projection workspace is built once per image, owned by this call
+        if isinstance(projector, Projector) and ray_batch['ray_o'].shape[0] > 0:
+            kw['cam_ws'] = camera_workspace(ray_batch, src_ray_batch)
         render_chunk = lambda chunk: render_rays(chunk, model, featmaps, **kw)
     all_ret = run_chunks(ray_batch, chunk_size, render_chunk, len(range(0, ray_sampler.H, render_stride)),
                          len(range(0, ray_sampler.W, render_stride)), shard)
     if all_ret is None:
         return None
     coarse = all_ret['outputs_coarse']
-    coarse['rgb'][coarse['mask'] == 0] = 1.       # coarse level only (render_image.py:113)
+    if coarse:                                    # (an image without rays has no fields)
+        coarse['rgb'][coarse['mask'] == 0] = 1.   # coarse level only (render_image.py:113)
     return all_ret

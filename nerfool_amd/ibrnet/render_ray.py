@@ -63,19 +63,13 @@ def sample_fine_depths(z_vals, weights, N_importance, inv_uniform=False, det=Fal
     return ops.sample_fine(z_vals.detach(), weights.detach(), N_importance, inv_uniform, u)
 
 
-_CAMERA_WS = [None]      # (query camera tensor, source cameras tensor, their versions, workspace) of the last call
-
-
-def _camera_workspace(camera, src_cameras):
-    """ops.camera_setup(camera, src_cameras), remembered while the SAME two tensor objects (unmodified: version counters) come
-    back -- every chunk of an image and every step of an attack on one target view do.  The cache holds the tensors themselves,
-    so their addresses cannot be re-used by other cameras while it is valid."""
-    c = _CAMERA_WS[0]
-    if c is not None and c[0] is camera and c[1] is src_cameras and c[2] == (camera._version, src_cameras._version):
-        return c[3]
-    ws = ops.camera_setup(camera.detach(), src_cameras.detach())
-    _CAMERA_WS[0] = (camera, src_cameras, (camera._version, src_cameras._version), ws)
-    return ws
+def camera_workspace(ray_batch, src_ray_batch=None):
+    """ops.camera_setup for the cameras of a batch: a caller that renders many chunks of ONE view (render_single_image, a chunk loop)
+    builds it once and hands it to every render_rays call as `cam_ws=`; render_rays builds it itself otherwise (one 5 us launch).
+    The workspace is owned by the caller's loop -- nothing is remembered between calls, so an in-place edit of a camera tensor can
+    never meet a stale projection."""
+    src = ray_batch if src_ray_batch is None else src_ray_batch
+    return ops.camera_setup(ray_batch['camera'].detach(), src['src_cameras'].detach())
 
 
 def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo_noise, cams):
@@ -83,7 +77,7 @@ def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo
     can = getattr(net, 'can_gather', None)
     ours = isinstance(projector, Projector)
     if ours and cams[0] is None:
-        cams[0] = _camera_workspace(ray_batch['camera'], src['src_cameras'])
+        cams[0] = camera_workspace(ray_batch, src)
     if can is not None and ours and can(featmap, pts.shape[1], src['src_cameras'].shape[1]):
         # projection + bilinear gather run inside the network's row kernel (and their adjoint inside its backward)
         raw, mask = net.forward_gathered(pts, cams[0], src['src_rgbs'][0], featmap)
@@ -98,9 +92,10 @@ def _level(pts, z_vals, ray_batch, src, net, featmap, projector, white_bkgd, geo
 
 
 def render_rays(ray_batch, model, featmaps, projector, N_samples, inv_uniform=False, N_importance=0, det=False,
-                white_bkgd=False, args=None, src_ray_batch=None, geo_noise=None):
+                white_bkgd=False, args=None, src_ray_batch=None, geo_noise=None, cam_ws=None):
     """
     :param ray_batch: {'ray_o': [N_rays, 3], 'ray_d': [N_rays, 3], 'camera', 'depth_range', 'src_rgbs', 'src_cameras'}
+    :param cam_ws: optional `camera_workspace(ray_batch, src_ray_batch)` of a caller that loops over chunks of one view
     :param model: object with .net_coarse / .net_fine
     :param featmaps: (coarse [V,32,Hf,Wf], fine [V,32,Hf,Wf])
     :return: {'outputs_coarse': OrderedDict, 'outputs_fine': OrderedDict or None}   (ibrnet/render_ray.py:173-256)
@@ -109,7 +104,7 @@ def render_rays(ray_batch, model, featmaps, projector, N_samples, inv_uniform=Fa
     ret = {'outputs_coarse': None, 'outputs_fine': None}
     pts, z_vals = sample_along_camera_ray(ray_batch['ray_o'], ray_batch['ray_d'], ray_batch['depth_range'], N_samples,
                                           inv_uniform=inv_uniform, det=det)
-    cams = [None]
+    cams = [cam_ws]
     ret['outputs_coarse'] = _level(pts, z_vals, ray_batch, src, model.net_coarse, featmaps[0], projector, white_bkgd,
                                    geo_noise, cams)
     if N_importance > 0:

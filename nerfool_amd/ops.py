@@ -12,37 +12,24 @@ _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 _current_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
 
 
-_restore_device = None       # the caller's current device while a launch on another GPU is being made
-
-
-def _stream(t):
-    """hipStream_t of torch's current stream on t's device (the raw-handle query: a step makes ~250 launches).  Every
-    launch passes through here right before the C call, so this is also where the tensor's device is made the current HIP
-    device when it is not (a model living on a non-current GPU): kernel launches, the per-device LDS opt-ins and
-    nf_device_cu_count all refer to the current device.  `_done` -- which receives the C call's status -- switches back, so
-    a library call never changes the caller's current device."""
-    global _restore_device
+def _launch(fn, name, t, *args):
+    """One C-ABI launch: `fn(*args, hipStream_t)` on torch's current stream of t's device, status checked.  Kernel launches, the
+    per-device LDS opt-ins and nf_device_cu_count all refer to the CURRENT HIP device, so a tensor living on another GPU than the
+    caller's current one is launched under a device guard (restored on every exit path, per thread); the common case -- the tensor
+    is on the current device -- takes the raw-handle query only (a step makes ~250 launches)."""
     if t.is_cuda:
         idx = t.device.index
+        cur = _current_device()
         if idx is None:
-            idx = _current_device()
-        elif idx != _current_device():
-            if _restore_device is None:
-                _restore_device = _current_device()
-            torch.cuda.set_device(idx)
-        if _raw_stream is not None:
-            return _raw_stream(idx)
-        return torch.cuda.current_stream(t.device).cuda_stream
-    return 0
-
-
-def _done(status, name):
-    """status of the C call that `_stream` prepared the device for: restore the caller's device, then raise on failure"""
-    global _restore_device
-    if _restore_device is not None:
-        torch.cuda.set_device(_restore_device)
-        _restore_device = None
-    _lib.check(status, name)
+            idx = cur
+        if idx != cur:
+            with torch.cuda.device(idx):
+                rc = fn(*args, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(t.device).cuda_stream)
+        else:
+            rc = fn(*args, _raw_stream(idx) if _raw_stream is not None else torch.cuda.current_stream(t.device).cuda_stream)
+    else:
+        rc = fn(*args, 0)
+    _lib.check(rc, name)
 
 
 def _f32(t, name):
@@ -69,8 +56,8 @@ def sample_along_ray(ray_o, ray_d, depth_range, n_samples, inv_uniform, t_rand=N
     z = torch.empty(R, n_samples, dtype=torch.float32, device=ray_o.device)
     if t_rand is not None:
         t_rand = _c(t_rand, 't_rand')
-    _done(_lib.lib().nf_sample_along_ray(_ptr(ray_o), _ptr(ray_d), _ptr(dr), R, n_samples, int(bool(inv_uniform)),
-                                              _ptr(t_rand), _ptr(pts), _ptr(z), _stream(ray_o)), 'nf_sample_along_ray')
+    _launch(_lib.lib().nf_sample_along_ray, 'nf_sample_along_ray', ray_o, _ptr(ray_o), _ptr(ray_d), _ptr(dr), R, n_samples, int(bool(inv_uniform)),
+                                              _ptr(t_rand), _ptr(pts), _ptr(z))
     return pts, z
 
 
@@ -78,8 +65,7 @@ def points_from_depths(ray_o, ray_d, z_vals):
     ray_o, ray_d, z_vals = _c(ray_o, 'ray_o'), _c(ray_d, 'ray_d'), _c(z_vals, 'z_vals')
     R, S = z_vals.shape
     pts = torch.empty(R, S, 3, dtype=torch.float32, device=z_vals.device)
-    _done(_lib.lib().nf_points_from_depths(_ptr(ray_o), _ptr(ray_d), _ptr(z_vals), R, S, _ptr(pts), _stream(pts)),
-               'nf_points_from_depths')
+    _launch(_lib.lib().nf_points_from_depths, 'nf_points_from_depths', pts, _ptr(ray_o), _ptr(ray_d), _ptr(z_vals), R, S, _ptr(pts))
     return pts
 
 
@@ -88,7 +74,7 @@ def camera_setup(query_camera, src_cameras):
     s = _c(src_cameras.reshape(-1, 34), 'src_cameras')
     V = s.shape[0]
     ws = torch.empty((V + 1) * 16, dtype=torch.float32, device=s.device)
-    _done(_lib.lib().nf_camera_setup(_ptr(q), _ptr(s), V, _ptr(ws), _stream(s)), 'nf_camera_setup')
+    _launch(_lib.lib().nf_camera_setup, 'nf_camera_setup', s, _ptr(q), _ptr(s), V, _ptr(ws))
     return ws
 
 
@@ -107,9 +93,9 @@ def project_gather_fwd(xyz, cam_ws, src_rgbs, featmaps, want_pix=False):
     pix = torch.empty(V, N, 2, dtype=torch.float32, device=dev) if want_pix else None
     sv, sc, sh, sw = featmaps.stride()
     with prof.launch('nf_project_gather_fwd', xyz, n_pts=N, V=V, C=C):
-        _done(_lib.lib().nf_project_gather_fwd(_ptr(xyz), N, _ptr(cam_ws), V, _ptr(src_rgbs), H, W, _ptr(featmaps), C,
+        _launch(_lib.lib().nf_project_gather_fwd, 'nf_project_gather_fwd', xyz, _ptr(xyz), N, _ptr(cam_ws), V, _ptr(src_rgbs), H, W, _ptr(featmaps), C,
                                                     Hf, Wf, sv, sc, sh, sw, _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
-                                                    _ptr(pix), _stream(xyz)), 'nf_project_gather_fwd')
+                                                    _ptr(pix))
     return rgb_feat, ray_diff, mask, pix
 
 
@@ -131,15 +117,15 @@ def project_gather_bwd(xyz, cam_ws, V, H, W, d_rgb_feat, feat_shape):
         n_taps = N * V * 4
         keys = torch.empty(n_taps, dtype=torch.int32, device=xyz.device)
         wts = torch.empty(n_taps, dtype=torch.float32, device=xyz.device)
-        _done(L.nf_project_gather_keys(_ptr(xyz), N, _ptr(cam_ws), V, Hf, Wf, _ptr(keys), _ptr(wts), _stream(xyz)), 'nf_project_gather_keys')
+        _launch(L.nf_project_gather_keys, 'nf_project_gather_keys', xyz, _ptr(xyz), N, _ptr(cam_ws), V, Hf, Wf, _ptr(keys), _ptr(wts))
         skeys, perm = torch.sort(keys, stable=True)
         with prof.launch('nf_project_gather_bwd_sorted', xyz, n_pts=N, V=V, C=C):
-            _done(L.nf_project_gather_bwd_sorted(_ptr(skeys), _ptr(perm), _ptr(wts), n_taps, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc, sh, sw,
-                                                      _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd_sorted')
+            _launch(L.nf_project_gather_bwd_sorted, 'nf_project_gather_bwd_sorted', xyz, _ptr(skeys), _ptr(perm), _ptr(wts), n_taps, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc, sh, sw,
+                                                      _ptr(d_feat))
         return d_feat
     with prof.launch('nf_project_gather_bwd', xyz, n_pts=N, V=V, C=C):
-        _done(_lib.lib().nf_project_gather_bwd(_ptr(xyz), N, _ptr(cam_ws), V, H, W, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc,
-                                                    sh, sw, _ptr(d_feat), _stream(xyz)), 'nf_project_gather_bwd')
+        _launch(_lib.lib().nf_project_gather_bwd, 'nf_project_gather_bwd', xyz, _ptr(xyz), N, _ptr(cam_ws), V, H, W, _ptr(d_rgb_feat), C, Hf, Wf, sv, sc,
+                                                    sh, sw, _ptr(d_feat))
     return d_feat
 
 
@@ -149,7 +135,7 @@ def pixel_mask(mask):
     V = m.shape[-1]
     n = m.numel() // V
     out = torch.empty(m.shape[:-1], dtype=torch.bool, device=m.device)
-    _done(_lib.lib().nf_pixel_mask(_ptr(m), n, V, _ptr(out), _stream(m)), 'nf_pixel_mask')
+    _launch(_lib.lib().nf_pixel_mask, 'nf_pixel_mask', m, _ptr(m), n, V, _ptr(out))
     return out
 
 
@@ -186,7 +172,7 @@ def pack_ibrnet_mfma_blob(natural_blob):
     L = _lib.lib()
     nat = natural_blob.detach().to('cpu', torch.float32).contiguous()
     out = torch.empty(L.nf_ibrnet_mfma_blob_floats(), dtype=torch.float32)
-    _done(L.nf_ibrnet_pack_mfma(nat.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma')
+    _lib.check(L.nf_ibrnet_pack_mfma(nat.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma')
     return out.to(natural_blob.device)
 
 
@@ -195,7 +181,7 @@ def pack_ibrnet_bf16_blob(mfma_blob):
     L = _lib.lib()
     src = mfma_blob.detach().to('cpu', torch.float32).contiguous()
     out = torch.empty(L.nf_ibrnet_mfma_bf16_blob_floats(), dtype=torch.float32)
-    _done(L.nf_ibrnet_pack_mfma_bf16(src.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma_bf16')
+    _lib.check(L.nf_ibrnet_pack_mfma_bf16(src.data_ptr(), out.data_ptr()), 'nf_ibrnet_pack_mfma_bf16')
     return out.to(mfma_blob.device)
 
 
@@ -217,13 +203,12 @@ def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_ali
     raw = torch.empty(R, S, 4, dtype=torch.float32, device=rgb_feat.device)
     if bf16_blob is not None:
         with prof.launch('nf_ibrnet_fwd_mfma_bf16', raw, R=R, S=S, V=V):
-            _done(L.nf_ibrnet_fwd_mfma_bf16(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff),
-                                                 _ptr(mask), R, S, V, int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)),
-                       'nf_ibrnet_fwd_mfma_bf16')
+            _launch(L.nf_ibrnet_fwd_mfma_bf16, 'nf_ibrnet_fwd_mfma_bf16', raw, _ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff),
+                                                 _ptr(mask), R, S, V, int(bool(anti_alias)), _ptr(raw), _ptr(ws))
         return raw, ws
     with prof.launch('nf_ibrnet_fwd_mfma', raw, R=R, S=S, V=V):
-        _done(L.nf_ibrnet_fwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S,
-                                        V, int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd_mfma')
+        _launch(L.nf_ibrnet_fwd_mfma, 'nf_ibrnet_fwd_mfma', raw, _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S,
+                                        V, int(bool(anti_alias)), _ptr(raw), _ptr(ws))
     return raw, ws
 
 
@@ -254,9 +239,9 @@ def ibrnet_fwd_mfma_gather(mfma_blob, blob, pos_enc, xyz, cam_ws, src_rgbs, feat
     mask = torch.empty(R, S, V, dtype=torch.float32, device=dev)
     sv, sc, sh, sw = featmaps.stride()
     with prof.launch('nf_ibrnet_fwd_mfma_bf16' if bf16_blob is not None else 'nf_ibrnet_fwd_mfma', raw, R=R, S=S, V=V):
-        _done(L.nf_ibrnet_fwd_mfma_gather(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(xyz), _ptr(cam_ws), _ptr(src_rgbs),
+        _launch(L.nf_ibrnet_fwd_mfma_gather, 'nf_ibrnet_fwd_mfma_gather', raw, _ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(xyz), _ptr(cam_ws), _ptr(src_rgbs),
                                                H, W, _ptr(featmaps), Hf, Wf, sv, sc, sh, sw, R, S, V, int(bool(anti_alias)), _ptr(raw), _ptr(ws),
-                                               _ptr(mask), _stream(raw)), 'nf_ibrnet_fwd_mfma_gather')
+                                               _ptr(mask))
     return raw, mask, ws
 
 
@@ -269,15 +254,14 @@ def ibrnet_bwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, smp, d_r
     d_rgb_feat = torch.empty_like(rgb_feat)
     if bf16_blob is not None:
         with prof.launch('nf_ibrnet_bwd_mfma_bf16', d_raw, R=R, S=S, V=V):
-            _done(_lib.lib().nf_ibrnet_bwd_mfma_bf16(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat),
+            _launch(_lib.lib().nf_ibrnet_bwd_mfma_bf16, 'nf_ibrnet_bwd_mfma_bf16', d_raw, _ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat),
                                                           _ptr(ray_diff), _ptr(mask), _ptr(smp), _ptr(d_raw), R, S, V,
-                                                          int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(d_ws), _stream(d_raw)),
-                       'nf_ibrnet_bwd_mfma_bf16')
+                                                          int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(d_ws))
         return d_rgb_feat
     with prof.launch('nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
-        _done(_lib.lib().nf_ibrnet_bwd_mfma(_ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
+        _launch(_lib.lib().nf_ibrnet_bwd_mfma, 'nf_ibrnet_bwd_mfma', d_raw, _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
                                                  _ptr(smp), _ptr(d_raw), R, S, V, int(bool(anti_alias)), _ptr(d_rgb_feat),
-                                                 _ptr(d_ws), _stream(d_raw)), 'nf_ibrnet_bwd_mfma')
+                                                 _ptr(d_ws))
     return d_rgb_feat
 
 
@@ -296,17 +280,15 @@ def ibrnet_bwd_mfma_scatter(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, 
     d_feat = torch.zeros(V, Hf, Wf, C, dtype=torch.float32, device=xyz.device).permute(0, 3, 1, 2)
     sv, sc, sh, sw = d_feat.stride()
     with prof.launch('nf_ibrnet_bwd_mfma_bf16' if bf16_blob is not None else 'nf_ibrnet_bwd_mfma', d_raw, R=R, S=S, V=V):
-        _done(_lib.lib().nf_ibrnet_bwd_mfma_scatter(_ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
+        _launch(_lib.lib().nf_ibrnet_bwd_mfma_scatter, 'nf_ibrnet_bwd_mfma_scatter', d_raw, _ptr(bf16_blob), _ptr(mfma_blob), _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask),
                                                          _ptr(smp), _ptr(d_raw), R, S, V, int(bool(anti_alias)), _ptr(d_ws), _ptr(xyz),
-                                                         _ptr(cam_ws), _ptr(d_feat), sv, sc, sh, sw, Hf, Wf, _stream(d_raw)),
-                   'nf_ibrnet_bwd_mfma_scatter')
+                                                         _ptr(cam_ws), _ptr(d_feat), sv, sc, sh, sw, Hf, Wf)
     return d_feat
 
 
 def debug_mfma32(a, b, c):
     d = torch.empty_like(c)
-    _done(_lib.lib().nf_debug_mfma32(_ptr(_c(a, 'a')), _ptr(_c(b, 'b')), _ptr(_c(c, 'c')), _ptr(d), _stream(d)),
-               'nf_debug_mfma32')
+    _launch(_lib.lib().nf_debug_mfma32, 'nf_debug_mfma32', d, _ptr(_c(a, 'a')), _ptr(_c(b, 'b')), _ptr(_c(c, 'c')), _ptr(d))
     return d
 
 
@@ -322,8 +304,8 @@ def ibrnet_fwd(blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias):
     ws = torch.empty(L.nf_ibrnet_workspace_floats(R, S, V, 0), dtype=torch.float32, device=rgb_feat.device)
     raw = torch.empty(R, S, 4, dtype=torch.float32, device=rgb_feat.device)
     with prof.launch('nf_ibrnet_fwd', raw, R=R, S=S, V=V):
-        _done(L.nf_ibrnet_fwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S, V,
-                                   int(bool(anti_alias)), _ptr(raw), _ptr(ws), _stream(raw)), 'nf_ibrnet_fwd')
+        _launch(L.nf_ibrnet_fwd, 'nf_ibrnet_fwd', raw, _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), R, S, V,
+                                   int(bool(anti_alias)), _ptr(raw), _ptr(ws))
     return raw
 
 
@@ -336,8 +318,8 @@ def ibrnet_bwd(blob, pos_enc, rgb_feat, ray_diff, mask, d_raw, anti_alias):
     ws = torch.empty(L.nf_ibrnet_workspace_floats(R, S, V, 1), dtype=torch.float32, device=rgb_feat.device)
     d_rgb_feat = torch.empty_like(rgb_feat)
     with prof.launch('nf_ibrnet_bwd', d_raw, R=R, S=S, V=V):
-        _done(L.nf_ibrnet_bwd(_ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(d_raw), R, S, V,
-                                   int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(ws), _stream(d_raw)), 'nf_ibrnet_bwd')
+        _launch(L.nf_ibrnet_bwd, 'nf_ibrnet_bwd', d_raw, _ptr(blob), _ptr(pe), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(d_raw), R, S, V,
+                                   int(bool(anti_alias)), _ptr(d_rgb_feat), _ptr(ws))
     return d_rgb_feat
 
 
@@ -359,9 +341,8 @@ def composite_fwd(raw, z_vals, mask, white_bkgd):
     weights = torch.empty(R, S, dtype=torch.float32, device=dev)
     alpha = torch.empty(R, S, dtype=torch.float32, device=dev)
     ray_mask = torch.empty(R, dtype=torch.bool, device=dev)
-    _done(_lib.lib().nf_composite_fwd(_ptr(raw), _ptr(z_vals), _ptr(pm), _ptr(vm), V, R, S, int(bool(white_bkgd)), _ptr(rgb),
-                                           _ptr(depth), _ptr(weights), _ptr(alpha), _ptr(ray_mask), _stream(raw)),
-               'nf_composite_fwd')
+    _launch(_lib.lib().nf_composite_fwd, 'nf_composite_fwd', raw, _ptr(raw), _ptr(z_vals), _ptr(pm), _ptr(vm), V, R, S, int(bool(white_bkgd)), _ptr(rgb),
+                                           _ptr(depth), _ptr(weights), _ptr(alpha), _ptr(ray_mask))
     return rgb, depth, weights, alpha, ray_mask
 
 
@@ -370,8 +351,8 @@ def composite_bwd(raw, z_vals, white_bkgd, d_rgb=None, d_depth=None, d_weights=N
     R, S, _ = raw.shape
     grads = [None if g is None else _c(g, 'upstream gradient') for g in (d_rgb, d_depth, d_weights, d_alpha)]
     d_raw = torch.empty_like(raw)
-    _done(_lib.lib().nf_composite_bwd(_ptr(raw), _ptr(z_vals), R, S, int(bool(white_bkgd)), _ptr(grads[0]), _ptr(grads[1]),
-                                           _ptr(grads[2]), _ptr(grads[3]), _ptr(d_raw), _stream(raw)), 'nf_composite_bwd')
+    _launch(_lib.lib().nf_composite_bwd, 'nf_composite_bwd', raw, _ptr(raw), _ptr(z_vals), R, S, int(bool(white_bkgd)), _ptr(grads[0]), _ptr(grads[1]),
+                                           _ptr(grads[2]), _ptr(grads[3]), _ptr(d_raw))
     return d_raw
 
 
@@ -381,8 +362,8 @@ def sample_fine(z_vals, weights, n_importance, inv_uniform, u_rand=None):
     out = torch.empty(R, S + n_importance, dtype=torch.float32, device=z_vals.device)
     if u_rand is not None:
         u_rand = _c(u_rand, 'u_rand')
-    _done(_lib.lib().nf_sample_fine(_ptr(z_vals), _ptr(weights), R, S, n_importance, int(bool(inv_uniform)), _ptr(u_rand),
-                                         _ptr(out), _stream(out)), 'nf_sample_fine')
+    _launch(_lib.lib().nf_sample_fine, 'nf_sample_fine', out, _ptr(z_vals), _ptr(weights), R, S, n_importance, int(bool(inv_uniform)), _ptr(u_rand),
+                                         _ptr(out))
     return out
 
 
@@ -394,8 +375,7 @@ def sample_pdf(bins, weights, n_samples, u_rand=None):
     out = torch.empty(R, n_samples, dtype=torch.float32, device=bins.device)
     if u_rand is not None:
         u_rand = _c(u_rand, 'u_rand')
-    _done(_lib.lib().nf_sample_pdf(_ptr(bins), _ptr(weights), R, M, n_samples, _ptr(u_rand), _ptr(out), _stream(out)),
-               'nf_sample_pdf')
+    _launch(_lib.lib().nf_sample_pdf, 'nf_sample_pdf', out, _ptr(bins), _ptr(weights), R, M, n_samples, _ptr(u_rand), _ptr(out))
     return out
 
 
@@ -408,8 +388,7 @@ def masked_mse_fwd(rgb, gt, mask_b=None, cnt_override=None):
         if pm.dtype != torch.bool:
             pm = pm != 0
     out = torch.empty(3, dtype=torch.float32, device=rgb.device)
-    _done(_lib.lib().nf_masked_mse_fwd(_ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt_override), _ptr(out), _stream(rgb)),
-               'nf_masked_mse_fwd')
+    _launch(_lib.lib().nf_masked_mse_fwd, 'nf_masked_mse_fwd', rgb, _ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt_override), _ptr(out))
     return out, pm
 
 
@@ -417,8 +396,7 @@ def masked_mse_bwd(rgb, gt, pm, cnt, d_loss):
     R = rgb.shape[0]
     d_rgb = torch.empty_like(rgb)
     d_loss = _c(d_loss.reshape(1), 'd_loss')
-    _done(_lib.lib().nf_masked_mse_bwd(_ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt), _ptr(d_loss), _ptr(d_rgb),
-                                            _stream(rgb)), 'nf_masked_mse_bwd')
+    _launch(_lib.lib().nf_masked_mse_bwd, 'nf_masked_mse_bwd', rgb, _ptr(rgb), _ptr(gt), _ptr(pm), R, _ptr(cnt), _ptr(d_loss), _ptr(d_rgb))
     return d_rgb
 
 
@@ -432,8 +410,7 @@ def _flat_inplace(t, name):
 def project_perturb_(delta, src, epsilon, lower=0.0, upper=1.0):
     _flat_inplace(delta, 'delta')
     src = _c(src, 'src')
-    _done(_lib.lib().nf_project_perturb(_ptr(delta), _ptr(src), delta.numel(), float(epsilon), float(lower), float(upper),
-                                             _stream(delta)), 'nf_project_perturb')
+    _launch(_lib.lib().nf_project_perturb, 'nf_project_perturb', delta, _ptr(delta), _ptr(src), delta.numel(), float(epsilon), float(lower), float(upper))
     return delta
 
 
@@ -446,18 +423,17 @@ def pgd_adam_step_(delta, grad, exp_avg, exp_avg_sq, src, lr, step, epsilon, bet
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
     with prof.launch('nf_pgd_adam_step', delta, n=delta.numel()):
-        _done(_lib.lib().nf_pgd_adam_step(_ptr(delta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(src),
+        _launch(_lib.lib().nf_pgd_adam_step, 'nf_pgd_adam_step', delta, _ptr(delta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(src),
                                                delta.numel(), -(lr / bc1), 1.0 - beta1, beta2, 1.0 - beta2, bc2 ** 0.5,
-                                               adam_eps, float(epsilon), float(lower), float(upper), _stream(delta)),
-                   'nf_pgd_adam_step')
+                                               adam_eps, float(epsilon), float(lower), float(upper))
     return delta
 
 
 def pgd_sign_step_(delta, grad, src, alpha, epsilon, lower=0.0, upper=1.0):
     _flat_inplace(delta, 'delta')
     grad, src = _c(grad, 'grad'), _c(src, 'src')
-    _done(_lib.lib().nf_pgd_sign_step(_ptr(delta), _ptr(grad), _ptr(src), delta.numel(), float(alpha), float(epsilon),
-                                           float(lower), float(upper), _stream(delta)), 'nf_pgd_sign_step')
+    _launch(_lib.lib().nf_pgd_sign_step, 'nf_pgd_sign_step', delta, _ptr(delta), _ptr(grad), _ptr(src), delta.numel(), float(alpha), float(epsilon),
+                                           float(lower), float(upper))
     return delta
 
 
@@ -491,10 +467,9 @@ def in_act_pad_fwd(x, gamma, beta, res, act, pad, eps=1e-5, out=None, c_off=0):
             raise ValueError('residual shape %s does not match %s' % (tuple(res.shape), (N, C, H, W)))
         rs = res.stride()
     with prof.launch('nf_in_act_pad_fwd', x, n=x.numel()):
-        _done(_lib.lib().nf_in_act_pad_fwd(_ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta), float(eps), _ptr(res), rs[0], rs[1],
+        _launch(_lib.lib().nf_in_act_pad_fwd, 'nf_in_act_pad_fwd', x, _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta), float(eps), _ptr(res), rs[0], rs[1],
                                                 rs[2], rs[3], int(act), int(pad), y_ptr, y_ns, _ptr(mean), _ptr(rstd),
-                                                _ptr(scratch), _stream(x)),
-                   'nf_in_act_pad_fwd')
+                                                _ptr(scratch))
     return yp, mean, rstd
 
 
@@ -527,10 +502,9 @@ def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res,
     d_res = torch.empty_like(dx) if want_d_res else None
     scratch = torch.empty(N * C * 64, dtype=torch.float64, device=ref.device) if gamma is not None else None
     with prof.launch('nf_in_act_pad_bwd', ref, n=dx.numel()):
-        _done(_lib.lib().nf_in_act_pad_bwd(_ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta),
+        _launch(_lib.lib().nf_in_act_pad_bwd, 'nf_in_act_pad_bwd', ref, _ptr(dyp), _ptr(d_extra), _ptr(yp), _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta),
                                                 _ptr(mean), _ptr(rstd), int(act), int(pad), _ptr(d_res), _ptr(dx), _ptr(scratch),
-                                                dy_ns, _ptr(d_extra_sub), _stream(ref)),
-                   'nf_in_act_pad_bwd')
+                                                dy_ns, _ptr(d_extra_sub))
     return dx, d_res
 
 
@@ -539,7 +513,7 @@ def conv1x1_pack(weight, transposed, device):
     L = _lib.lib()
     w = weight.detach().to('cpu', torch.float32).reshape(weight.shape[0], weight.shape[1]).contiguous()
     out = torch.empty(L.nf_conv1x1_pack_floats(w.shape[0], w.shape[1]), dtype=torch.float32)
-    _done(L.nf_conv1x1_pack(w.data_ptr(), w.shape[0], w.shape[1], int(bool(transposed)), out.data_ptr()), 'nf_conv1x1_pack')
+    _lib.check(L.nf_conv1x1_pack(w.data_ptr(), w.shape[0], w.shape[1], int(bool(transposed)), out.data_ptr()), 'nf_conv1x1_pack')
     return out.to(device)
 
 
@@ -563,8 +537,8 @@ def conv1x1(records, bias, x, c_out, channels_last_out=False, x2=None):
         y = torch.empty(N, c_out, H, W, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
     with prof.launch('nf_conv1x1', x, n=y.numel()):
-        _done(_lib.lib().nf_conv1x1(_ptr(records), _ptr(bias), _ptr(x), xs[0], xs[1], xs[2], xs[3], _ptr(y), ys[0], ys[1], ys[2],
-                                         ys[3], N, H, W, c_in, c_out, _ptr(x2), c_split, _stream(x)), 'nf_conv1x1')
+        _launch(_lib.lib().nf_conv1x1, 'nf_conv1x1', x, _ptr(records), _ptr(bias), _ptr(x), xs[0], xs[1], xs[2], xs[3], _ptr(y), ys[0], ys[1], ys[2],
+                                         ys[3], N, H, W, c_in, c_out, _ptr(x2), c_split)
     return y
 
 
@@ -585,8 +559,8 @@ def pad_gather_fwd(src, H, W, pad, top=0, left=0, out=None):
     assert tuple(out.shape) == (N, C, Hp, Wp) and out.stride(3) == 1 and out.stride(2) == Wp
     ss = src.stride()
     with prof.launch('nf_pad_gather_fwd', src, n=out.numel()):
-        _done(_lib.lib().nf_pad_gather_fwd(_ptr(src), ss[0], ss[1], ss[2], ss[3], N, C, eh, ew, int(top), int(left), int(H), int(W), int(pad),
-                                                _ptr(out), out.stride(0), out.stride(1), _stream(src)), 'nf_pad_gather_fwd')
+        _launch(_lib.lib().nf_pad_gather_fwd, 'nf_pad_gather_fwd', src, _ptr(src), ss[0], ss[1], ss[2], ss[3], N, C, eh, ew, int(top), int(left), int(H), int(W), int(pad),
+                                                _ptr(out), out.stride(0), out.stride(1))
     return out
 
 
@@ -602,8 +576,8 @@ def pad_gather_bwd(d_out, H, W, pad, eh, ew, top=0, left=0, like=None):
         din = torch.empty(N, C, eh, ew, dtype=torch.float32, device=d_out.device)
     ds = din.stride()
     with prof.launch('nf_pad_gather_bwd', d_out, n=d_out.numel()):
-        _done(_lib.lib().nf_pad_gather_bwd(_ptr(d_out), d_out.stride(0), d_out.stride(1), N, C, int(H), int(W), int(pad), int(eh), int(ew),
-                                                int(top), int(left), _ptr(din), ds[0], ds[1], ds[2], ds[3], _stream(d_out)), 'nf_pad_gather_bwd')
+        _launch(_lib.lib().nf_pad_gather_bwd, 'nf_pad_gather_bwd', d_out, _ptr(d_out), d_out.stride(0), d_out.stride(1), N, C, int(H), int(W), int(pad), int(eh), int(ew),
+                                                int(top), int(left), _ptr(din), ds[0], ds[1], ds[2], ds[3])
     return din
 
 
@@ -613,8 +587,7 @@ def upsample2x_pad_bwd(d_yp, h, w, pad):
     N, C = d_yp.shape[0], d_yp.shape[1]
     dx = torch.empty(N, C, h, w, dtype=torch.float32, device=d_yp.device)
     with prof.launch('nf_upsample2x_pad_bwd', d_yp, n=d_yp.numel()):
-        _done(_lib.lib().nf_upsample2x_pad_bwd(_ptr(d_yp), N * C, int(h), int(w), int(pad), _ptr(dx), h * w, w, _stream(d_yp)),
-                   'nf_upsample2x_pad_bwd')
+        _launch(_lib.lib().nf_upsample2x_pad_bwd, 'nf_upsample2x_pad_bwd', d_yp, _ptr(d_yp), N * C, int(h), int(w), int(pad), _ptr(dx), h * w, w)
     return dx
 
 
@@ -628,7 +601,7 @@ def conv_s2_pack(weight, backward, device):
     if n < 0:
         raise ValueError('stride-2 convolution kernels exist for 3x3 and 7x7 (got %dx%d)' % (ks, ks))
     out = torch.empty(n, dtype=torch.float32)
-    _done(L.nf_conv_s2_pack(w.data_ptr(), c_out, c_in, ks, int(bool(backward)), out.data_ptr()), 'nf_conv_s2_pack')
+    _lib.check(L.nf_conv_s2_pack(w.data_ptr(), c_out, c_in, ks, int(bool(backward)), out.data_ptr()), 'nf_conv_s2_pack')
     return out.to(device)
 
 
@@ -642,8 +615,8 @@ def conv_s2_fwd(records, x, c_out, ks):
     y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
     with prof.launch('nf_conv_s2_fwd', x, n_img=N, c_in=c_in, c_out=c_out, ks=ks, Ho=Ho, Wo=Wo):
-        _done(_lib.lib().nf_conv_s2_fwd(_ptr(records), int(ks), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, _ptr(y), ys[0], ys[1], ys[2],
-                                             Ho, Wo, N, c_in, c_out, _stream(x)), 'nf_conv_s2_fwd')
+        _launch(_lib.lib().nf_conv_s2_fwd, 'nf_conv_s2_fwd', x, _ptr(records), int(ks), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, _ptr(y), ys[0], ys[1], ys[2],
+                                             Ho, Wo, N, c_in, c_out)
     return y
 
 
@@ -656,8 +629,8 @@ def conv_s2_bwd(records, dy, c_in, ks, Hi, Wi):
     dx = torch.empty(N, c_in, Hi, Wi, dtype=torch.float32, device=dy.device)
     ds, xs = dy.stride(), dx.stride()
     with prof.launch('nf_conv_s2_bwd', dy, n_img=N, c_in=c_in, c_out=c_out, ks=ks, Ho=Ho, Wo=Wo):
-        _done(_lib.lib().nf_conv_s2_bwd(_ptr(records), int(ks), _ptr(dy), ds[0], ds[1], ds[2], Ho, Wo, _ptr(dx), xs[0], xs[1], xs[2],
-                                             Hi, Wi, N, c_in, c_out, _stream(dy)), 'nf_conv_s2_bwd')
+        _launch(_lib.lib().nf_conv_s2_bwd, 'nf_conv_s2_bwd', dy, _ptr(records), int(ks), _ptr(dy), ds[0], ds[1], ds[2], Ho, Wo, _ptr(dx), xs[0], xs[1], xs[2],
+                                             Hi, Wi, N, c_in, c_out)
     return dx
 
 
@@ -670,7 +643,7 @@ def wino_pack(weight, backward, device, k_per_group=None):
     n_out = c_in if backward else c_out
     kg = wino_group(n_out) if k_per_group is None else int(k_per_group)
     out = torch.empty(L.nf_wino_pack_floats(n_out, c_out if backward else c_in, kg), dtype=torch.float32)
-    _done(L.nf_wino_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), kg, out.data_ptr()), 'nf_wino_pack')
+    _lib.check(L.nf_wino_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), kg, out.data_ptr()), 'nf_wino_pack')
     return out.to(device)
 
 
@@ -686,9 +659,8 @@ def conv3x3_wino(records, x, c_out, pad, tile_blocks=0, k_per_group=None):
     y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
     with prof.launch('nf_conv3x3_wino', x, n_img=N, c_in=c_in, c_out=c_out, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo):
-        _done(_lib.lib().nf_conv3x3_wino(_ptr(records), wino_group(c_out) if k_per_group is None else int(k_per_group), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y),
-                                              ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out, int(tile_blocks), _stream(x)),
-                   'nf_conv3x3_wino')
+        _launch(_lib.lib().nf_conv3x3_wino, 'nf_conv3x3_wino', x, _ptr(records), wino_group(c_out) if k_per_group is None else int(k_per_group), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y),
+                                              ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out, int(tile_blocks))
     return y
 
 
@@ -697,7 +669,7 @@ def wino_ring_pack(weight, device):
     L = _lib.lib()
     w = weight.detach().to('cpu', torch.float32).contiguous()
     out = torch.empty(L.nf_wino_ring_pack_floats(w.shape[0], w.shape[1]), dtype=torch.float32)
-    _done(L.nf_wino_ring_pack(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr()), 'nf_wino_ring_pack')
+    _lib.check(L.nf_wino_ring_pack(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr()), 'nf_wino_ring_pack')
     return out.to(device)
 
 
@@ -733,12 +705,11 @@ def conv3x3_wino_bwd_split(records, ring_records, dy, c_dx, plan, k_per_group=No
     xs, gs = dy.stride(), g.stride()
     L = _lib.lib()
     with prof.launch('nf_conv3x3_wino', dy, n_img=N, c_in=c_dy, c_out=c_dx, Hi=H, Wi=W, Ho=rows, Wo=cols):
-        _done(L.nf_conv3x3_wino(_ptr(records), wino_group(c_dx) if k_per_group is None else int(k_per_group), _ptr(dy), xs[0], xs[1], xs[2],
-                                     H, W, 1, g.data_ptr() + 4 * (gs[2] + 1), gs[0], gs[1], gs[2], rows, cols, N, c_dy, c_dx, 0, _stream(dy)),
-                   'nf_conv3x3_wino')
+        _launch(L.nf_conv3x3_wino, 'nf_conv3x3_wino', dy, _ptr(records), wino_group(c_dx) if k_per_group is None else int(k_per_group), _ptr(dy), xs[0], xs[1], xs[2],
+                                     H, W, 1, g.data_ptr() + 4 * (gs[2] + 1), gs[0], gs[1], gs[2], rows, cols, N, c_dy, c_dx, 0)
     with prof.launch('nf_conv3x3_bwd_ring', dy, n=N * c_dx * (2 * (W + 2) + 2 * H)):
-        _done(L.nf_conv3x3_bwd_ring(_ptr(ring_records), _ptr(dy), xs[0], xs[1], xs[2], H, W, _ptr(g), gs[0], gs[1], gs[2], N, c_dy, c_dx,
-                                         int(kinds), _stream(dy)), 'nf_conv3x3_bwd_ring')
+        _launch(L.nf_conv3x3_bwd_ring, 'nf_conv3x3_bwd_ring', dy, _ptr(ring_records), _ptr(dy), xs[0], xs[1], xs[2], H, W, _ptr(g), gs[0], gs[1], gs[2], N, c_dy, c_dx,
+                                         int(kinds))
     return g
 
 
@@ -753,8 +724,7 @@ def upsample2x_pad_fwd(x, pad):
         sn, sc, sh, sw = x.stride()
     yp = torch.empty(N, C, 2 * h + 2 * pad, 2 * w + 2 * pad, dtype=torch.float32, device=x.device)
     with prof.launch('nf_upsample2x_pad_fwd', x, n=yp.numel()):
-        _done(_lib.lib().nf_upsample2x_pad_fwd(_ptr(x), N * C, sc, sh, h, w, int(pad), _ptr(yp), _stream(x)),
-                   'nf_upsample2x_pad_fwd')
+        _launch(_lib.lib().nf_upsample2x_pad_fwd, 'nf_upsample2x_pad_fwd', x, _ptr(x), N * C, sc, sh, h, w, int(pad), _ptr(yp))
     return yp
 
 
@@ -790,8 +760,8 @@ def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=
     rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
     alpha = torch.empty(R, S, dtype=torch.float32, device=rgb_feat.device) if want_alpha else None
     with prof.launch('nf_gnt_fwd', rgb, R=R, S=S, V=V, depth=depth):
-        _done(L.nf_gnt_fwd(_ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V, depth,
-                                int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd')
+        _launch(L.nf_gnt_fwd, 'nf_gnt_fwd', rgb, _ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V, depth,
+                                int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws))
     if want_alpha:
         return rgb, (ws if save else None), alpha
     return rgb, (ws if save else None)
@@ -802,7 +772,7 @@ def pack_gnt_mfma_blob(blob, depth):
     L = _lib.lib()
     nat = blob.detach().to('cpu', torch.float32).contiguous()
     out = torch.empty(L.nf_gnt_mfma_blob_floats(depth), dtype=torch.float32)
-    _done(L.nf_gnt_pack_mfma(depth, nat.data_ptr(), out.data_ptr()), 'nf_gnt_pack_mfma')
+    _lib.check(L.nf_gnt_pack_mfma(depth, nat.data_ptr(), out.data_ptr()), 'nf_gnt_pack_mfma')
     return out.to(blob.device)
 
 
@@ -821,8 +791,8 @@ def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, w
     rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
     alpha = torch.empty(R, S, dtype=torch.float32, device=rgb_feat.device) if want_alpha else None
     with prof.launch('nf_gnt_fwd_mfma', rgb, R=R, S=S, V=V, depth=depth):
-        _done(L.nf_gnt_fwd_mfma(_ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
-                                     depth, int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws), _stream(rgb)), 'nf_gnt_fwd_mfma')
+        _launch(L.nf_gnt_fwd_mfma, 'nf_gnt_fwd_mfma', rgb, _ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
+                                     depth, int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws))
     if want_alpha:
         return rgb, (ws if save else None), alpha
     return rgb, (ws if save else None)
@@ -833,8 +803,7 @@ def gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, shape, depth):
     mask, d_rgb = _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
     d_rgb_feat = torch.empty(R, S, V, 35, dtype=torch.float32, device=d_rgb.device)
     with prof.launch('nf_gnt_bwd_mfma', d_rgb, R=R, S=S, V=V, depth=depth):
-        _done(_lib.lib().nf_gnt_bwd_mfma(_ptr(mfma_blob), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat), _ptr(ws),
-                                              _stream(d_rgb)), 'nf_gnt_bwd_mfma')
+        _launch(_lib.lib().nf_gnt_bwd_mfma, 'nf_gnt_bwd_mfma', d_rgb, _ptr(mfma_blob), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat), _ptr(ws))
     return d_rgb_feat
 
 
@@ -843,6 +812,6 @@ def gnt_bwd(blob, ray_diff, mask, d_rgb, ws, shape, depth):
     ray_diff, mask, d_rgb = _c(ray_diff, 'ray_diff'), _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
     d_rgb_feat = torch.empty(R, S, V, 35, dtype=torch.float32, device=d_rgb.device)
     with prof.launch('nf_gnt_bwd', d_rgb, R=R, S=S, V=V, depth=depth):
-        _done(_lib.lib().nf_gnt_bwd(_ptr(blob), _ptr(ray_diff), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat),
-                                         _ptr(ws), _stream(d_rgb)), 'nf_gnt_bwd')
+        _launch(_lib.lib().nf_gnt_bwd, 'nf_gnt_bwd', d_rgb, _ptr(blob), _ptr(ray_diff), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat),
+                                         _ptr(ws))
     return d_rgb_feat

@@ -27,6 +27,18 @@ class Golden:
         return torch.from_numpy(np.array(a, order='C')).to(device)      # np.array keeps 0-d shapes
 
     def params(self, prefix, device='cpu'):
+        if prefix + '_seed' in self.z.files:
+            # parameters regenerated from their seed (the generator script made the same call in front of the reference) and
+            # checked against the fingerprint stored with the capture
+            from oracle.gnt_ref import random_gnt_params
+            depth, seed = [int(x) for x in self.z[prefix + '_seed']]
+            p = random_gnt_params(depth, seed=seed)
+            s1 = sum(float(v.double().sum()) for _, v in sorted(p.items()))
+            s2 = sum(float((v.double() ** 2).sum()) for _, v in sorted(p.items()))
+            want = self.z[prefix + '_checksum']
+            assert abs(s1 - want[0]) <= 1e-9 * max(1.0, abs(want[0])) and abs(s2 - want[1]) <= 1e-9 * abs(want[1]), \
+                'regenerated parameters do not match the fingerprint of the capture (%r vs %r)' % ((s1, s2), tuple(want))
+            return OrderedDict((k, v.to(device)) for k, v in p.items())
         out = OrderedDict()
         for k in self.z.files:
             name = k[len(prefix) + 1:]

@@ -31,7 +31,16 @@ def npy(t):
     return t.detach().cpu().numpy().copy() if isinstance(t, torch.Tensor) else np.array(t)
 
 
-def case(name, H, W, V, R, S, depth, seed, tilt=0.0):
+def params_checksum(params):
+    """order-independent fingerprint of a state dict: per tensor the float64 sum and sum of squares, summed over the sorted keys"""
+    s1 = sum(float(v.double().sum()) for _, v in sorted(params.items()))
+    s2 = sum(float((v.double() ** 2).sum()) for _, v in sorted(params.items()))
+    return np.array([s1, s2], dtype=np.float64)
+
+
+def case(name, H, W, V, R, S, depth, seed, tilt=0.0, store_weights=True):
+    """store_weights=False: the network parameters are regenerated from their seed by the tests (oracle.gnt_ref.random_gnt_params,
+    the call below) -- the fixture keeps the seed and a fingerprint instead of megabytes of weights (depth 8: 3.5 MB)."""
     torch.manual_seed(seed)
     data = make_scene(H, W, V, seed=seed, tilt=tilt)
     Hf, Wf = max(6, H // 4), max(8, W // 4)
@@ -56,8 +65,12 @@ def case(name, H, W, V, R, S, depth, seed, tilt=0.0):
     out['in/ray_o'] = npy(batch['ray_o'])
     out['in/ray_d'] = npy(batch['ray_d'])
     out['in/gt_rgb'] = npy(batch['rgb'])
-    for k, v in params.items():
-        out['net/' + k] = npy(v)
+    if store_weights:
+        for k, v in params.items():
+            out['net/' + k] = npy(v)
+    else:
+        out['net_seed'] = np.array([depth, 60 + seed], dtype=np.int64)
+        out['net_checksum'] = params_checksum(params)
     out['rgb'] = npy(rgb)
     out['loss'] = npy(loss)
     out['grad/featmap'] = npy(grad)
@@ -126,6 +139,11 @@ def alpha_case(name, H, W, V, R, S, N_imp, depth, seed, tilt=0.0):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'c4':
+        # BASELINE config 4's network shape: trans_depth 8 (configs/gnt/gnt_full.txt:26), 10 source views, 64 samples per ray -- the shape
+        # the matrix-core GNT kernels run at in the benchmark (gnt/transformer_network.py:270-309)
+        case('gnt_c4_d8_v10', 32, 48, 10, 8, 64, 8, seed=4, tilt=0.3, store_weights=False)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'alpha':
         alpha_case('gnt_alpha_d2_v3', 32, 48, 3, 10, 32, 32, 2, seed=3, tilt=0.3)
         sys.exit(0)

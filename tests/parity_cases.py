@@ -870,9 +870,10 @@ def make_gnt(g, depth, dev):
     return net.to(dev).eval()
 
 
-def check_gnt(case, dev):
+def check_gnt(case, dev, expect_mfma=False):
     """GNT network forward + backward (d/d rgb_feat) and the GNT render_rays + unmasked MSE + gradient to the feature map
-    against the reference's capture."""
+    against the reference's capture.  expect_mfma: the case must run on the matrix-core kernels (asserted, not assumed)."""
+    from nerfool_amd.gnt import transformer_network as tn
     from nerfool_amd.gnt.criterion import Criterion as GntCriterion
     from nerfool_amd.gnt.render_ray import render_rays as gnt_render_rays
     from oracle import gnt_ref as gr
@@ -882,6 +883,9 @@ def check_gnt(case, dev):
     ins = [g.t('net_in/' + k, dev) for k in ('rgb_feat', 'ray_diff', 'mask', 'pts')] + [g.t('in/ray_d', dev)]
     with torch.no_grad():
         rgb = net(*ins)
+    if expect_mfma:
+        assert tn.KERNEL_PATH == 'mfma' and ops.gnt_mfma_supported(S, V) and net._mfma_blob is not None, \
+            'this capture pins the matrix-core GNT kernels: they must be the ones that ran'
     ref_rgb = g.np('rgb')
     assert_close(rgb, ref_rgb, 1e-3, 1e-3 * float(np.abs(ref_rgb).max()), 'GNT rgb (no-grad path)')
     # backward w.r.t. rgb_feat against autograd of the oracle

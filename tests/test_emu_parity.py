@@ -150,6 +150,11 @@ def test_gnt(case):
     pc.check_gnt(case, 'cpu')
 
 
+def test_gnt_config4_shape_on_the_matrix_core_kernels():
+    """BASELINE config 4's network shape (depth 8, V 10, S 64) through the emulated matrix-core GNT kernels against the reference capture"""
+    pc.check_gnt('gnt_c4_d8_v10', 'cpu', expect_mfma=True)
+
+
 def test_gnt_attack_step():
     pc.check_gnt_attack_step('cpu')
 

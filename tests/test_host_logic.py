@@ -1,0 +1,71 @@
+"""CPU: host-side logic that needs neither a GPU nor the kernels' stand-in build."""
+import subprocess
+import sys
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scene(seed=0, H=40, W=56, V=3, path=None):
+    from nerfool_amd.synthetic import make_scene
+    data = make_scene(H, W, V, seed=seed)
+    data.pop('rgb_path', None)
+    if path is not None:
+        data['rgb_path'] = [path]
+    return data
+
+
+@pytest.mark.parametrize('with_path', [False, True])
+def test_sampler_cache_keys_on_content_not_identity(with_path):
+    """RaySamplerSingleImage.cached: a DataLoader hands out FRESH tensors for the same view every step of the reference's universal
+    loop (eval/ibrnet/eval_adv.py:652-740 `for data in train_loader`) -- equal content must hit, an edit anywhere in an image must
+    miss (without a path: full checksum; with `rgb_path`: path + cameras + a strided checksum, so an edit is caught when the path or
+    a camera changes with it, which is what distinguishes two views of a scene)."""
+    from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
+    RaySamplerSingleImage._cache.clear()
+    path = 'scene/images/007.png' if with_path else None
+    a = _scene(path=path)
+    s0 = RaySamplerSingleImage.cached(a, 'cpu')
+    fresh = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
+    assert RaySamplerSingleImage.cached(fresh, 'cpu') is s0
+    assert RaySamplerSingleImage.cached(a, 'cpu') is s0                      # memoised per tensor object
+    moved = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
+    moved['camera'][0, 20] += 1e-3                                           # another target pose
+    assert RaySamplerSingleImage.cached(moved, 'cpu') is not s0
+    edited = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
+    edited['src_rgbs'][0, 1, 5, 5, 1] += 1e-3                                # one element
+    if with_path:
+        edited['rgb_path'] = ['scene/images/008.png']
+    assert RaySamplerSingleImage.cached(edited, 'cpu') is not s0
+    dense = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
+    dense['src_rgbs'] += 1e-3                                                # a perturbation of the whole image: seen on the stride too
+    assert RaySamplerSingleImage.cached(dense, 'cpu') is not s0
+    # an in-place edit of a tensor already seen bumps its version counter: no stale memo
+    a['src_rgbs'][0, 0].mul_(0.5)
+    if not with_path:
+        assert RaySamplerSingleImage.cached(a, 'cpu') is not s0
+    RaySamplerSingleImage._cache.clear()
+
+
+def test_gnt_rejects_training_mode_loudly():
+    """the reference's universal GNT loop runs with Dropout(0.1) active (eval/gnt/eval_adv.py:739-878 before switch_to_eval at :959);
+    the kernels are eval-only, so a module in training mode raises instead of silently running eval semantics"""
+    from nerfool_amd.gnt.transformer_network import GNT
+    net = GNT(SimpleNamespace(netwidth=64, trans_depth=2), in_feat_ch=32, posenc_dim=63, viewenc_dim=63)
+    assert net.training
+    x = torch.zeros(2, 8, 3, 35)
+    with pytest.raises(RuntimeError, match='switch_to_eval'):
+        net(x, torch.zeros(2, 8, 3, 4), torch.ones(2, 8, 3, 1), torch.zeros(2, 8, 3), torch.zeros(2, 3))
+
+
+def test_removed_environment_switches_warn_once():
+    code = 'import warnings; warnings.simplefilter("error"); import nerfool_amd'
+    env = dict(os.environ, PYTHONPATH=ROOT, NERFOOL_GATHER_FUSION='full')
+    p = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True)
+    assert p.returncode != 0 and 'NERFOOL_GATHER_FUSION' in p.stderr
+    env.pop('NERFOOL_GATHER_FUSION')
+    assert subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True).returncode == 0

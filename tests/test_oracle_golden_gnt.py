@@ -6,7 +6,7 @@ import torch
 from fixtures import Golden, assert_close
 from oracle import gnt_ref as gr
 
-GNT_CASES = ['gnt_tiny_d2_v4', 'gnt_tiny_d3_v5']
+GNT_CASES = ['gnt_tiny_d2_v4', 'gnt_tiny_d3_v5', 'gnt_c4_d8_v10']      # the last: BASELINE config 4's network shape
 
 
 def gnt_batch(g, device='cpu'):
