@@ -41,6 +41,8 @@ _PROTOTYPES = {
     'nf_ibrnet_mfma_blob_floats': (c_int64, []),
     'nf_ibrnet_pack_mfma': (c_int, [_P, _P]),
     'nf_ibrnet_mfma_supported': (c_int, [c_int, c_int]),
+    'nf_ibrnet_rows_form': (c_int, [c_int]),
+    'nf_ibrnet_sol_selected': (c_int, [c_int, c_int]),
     'nf_ibrnet_mfma_workspace_floats': (c_int64, [c_int64, c_int]),
     'nf_ibrnet_fwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
     'nf_ibrnet_bwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),

@@ -43,6 +43,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define NF_ROWS_BWD_OCC 1
 #endif
 
+// makes a value opaque to the optimiser (the two-phase backward RECOMPUTES the early activations from the laundered inputs: without
+// it the compiler proves them equal to the first evaluation and keeps those registers alive instead)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NF_LAUNDER_F(x) asm volatile("" : "+v"(x))
+#define NF_PIN_FRAG(x) asm volatile("" : "+v"(x))        // a 16-register fragment: "computed by here" (no instruction)
+#else
+#define NF_LAUNDER_F(x) asm volatile("" : "+x"(x))
+#define NF_PIN_FRAG(x) asm volatile("" ::: "memory")
+#endif
+
 __host__ __device__ constexpr int nf_nidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---- record layout of the MFMA-order weight blob (units: records of 64 floats) -------------------------------------
@@ -829,6 +839,353 @@ __global__ void __launch_bounds__(64 * NF_ROWS_FWD_WAVES, NF_ROWS_FWD_OCC) k_ibr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// kernel A, SAMPLE-ON-THE-LANE form ("sol"): a wave owns 32 SAMPLES -- the MFMA column is the sample, lane (m, h) holds half of
+// sample m's 32 features -- and walks the V views of its samples IN TIME.  Against the row form above (column = (sample, view) row):
+//   * the view-invariant part of base_fc.0 -- W[:, mean | var] . [mean | var], 70 of its 105 inputs (mlp_network.py:245-247: the
+//     global feature is expanded over the views) -- is multiplied ONCE per sample instead of once per view: 72 of the row form's
+//     217 matrix instructions per 32 rows become 72 per 32 SAMPLES (V = 4: 868 -> 652 per 128 rows);
+//   * every cross-view reduction (pooling mean / variance, normalisations, the blending softmax) is in-lane accumulation over the
+//     view loop: the ~170 DPP butterflies of a row tile are gone;
+//   * any view count runs without padding lanes (the row form pads V to a power of two: 10 views on 16 lanes).
+// What it costs: the views' features F_v stay in registers from the pooling to their base_fc.0 product (16 V registers), so the
+// kernel runs at two waves per SIMD (V <= 4) or one (V <= 10) instead of four.  Same weight records as the row form.
+// The variance of the SECOND pooling needs its mean first, and keeping x2_v of every view would cost another 16 V registers: it is
+// accumulated around a pivot (x2 of view 0) instead,  var = sum w (d - mu)^2 = sum w d^2 - 2 mu sum w d + mu^2 sum w  with
+// d = x2_v - pivot, mu = mean - pivot: all three terms are of the size of the view-to-view spread squared (no cancellation
+// against the features' magnitude); the backward uses the exact deviations, it knows the mean when it re-walks the views.
+// ---------------------------------------------------------------------------------------------------------------
+// OCC = waves per SIMD the kernel is built for: 2 (eight-wave workgroups, <= 256 registers: V <= 4) or 1 (four-wave workgroups, <= 512)
+__host__ __device__ constexpr int sol_fwd_waves(int occ) { return 4 * occ; }
+#define NF_SOL_MAX_V 10
+
+// direction MLP 4 -> 16 -> 35 and f = rgb_feat + dir_feat of one (sample, view)   (mlp_network.py:231-233)
+template <bool BF>
+__device__ __forceinline__ void sol_direction(const float* lds, int lane, int h, const RowIn& in, f32x16& F, float (&fc)[3]) {
+    f32x16 d1 = bias_tile(lds, BT_DIR0, h);
+    {
+        const float v2[2] = {h ? in.rd[1] : in.rd[0], h ? in.rd[3] : in.rd[2]};
+        d1 = gemm_small<BF, 2>(lds, MR_DIR0, lane, v2, d1);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d1[r] = mf_elu(d1[r]);
+    {
+        const f32x16 df = elu16(gemm_frag<BF, 8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h)));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) F[r] = in.feat[r] + df[r];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* wv = lds + MS_DIR1C + c * 16 + h * 8;
+        const float4 wa = *reinterpret_cast<const float4*>(wv), wb = *reinterpret_cast<const float4*>(wv + 4);
+        const float wr[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        float d = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d = fmaf(wr[r], d1[r], d);
+        d = half_sum(d) + lds[MS_DIR1C + 48 + c];
+        fc[c] = in.c[c] + mf_elu(d);
+    }
+}
+
+// the view-invariant part of base_fc.0, output tile NT: bias + W[:, mean] . mean + W[:, var] . var   (once per sample)
+template <bool BF, int NT>
+__device__ __forceinline__ f32x16 sol_base0_global(const float* lds, int lane, int h, const f32x16& MEAN, const float (&mc)[3],
+                                                   const f32x16& VAR, const float (&vc)[3]) {
+    constexpr int rec = MR_BASE0 + NT * 54;
+    f32x16 acc = bias_tile(lds, BT_BASE0A + NT, h);
+    acc = gemm_frag<BF, 16>(lds, rec, lane, MEAN, acc);
+    const float m2[2] = {h ? mc[1] : mc[0], h ? 0.f : mc[2]};
+    acc = gemm_small<BF, 2>(lds, rec + 16, lane, m2, acc);
+    acc = gemm_frag<BF, 16>(lds, rec + 18, lane, VAR, acc);
+    const float v2[2] = {h ? vc[1] : vc[0], h ? 0.f : vc[2]};
+    acc = gemm_small<BF, 2>(lds, rec + 34, lane, v2, acc);
+    return acc;
+}
+// ... and the per-view part on top of it: G + W[:, f] . f_v
+template <bool BF, int NT>
+__device__ __forceinline__ f32x16 sol_base0_view(const float* lds, int lane, int h, const f32x16& G, const f32x16& F, const float (&fc)[3]) {
+    constexpr int rec = MR_BASE0 + NT * 54;
+    f32x16 acc = gemm_frag<BF, 16>(lds, rec + 36, lane, F, G);
+    const float f2[2] = {h ? fc[1] : fc[0], h ? 0.f : fc[2]};
+    return gemm_small<BF, 2>(lds, rec + 52, lane, f2, acc);
+}
+
+// everything of one (sample, view) behind base_fc.0 that does not look at the other views: base_fc.2, vis_fc, vis_fc2 and the
+// colour head's logit (mlp_network.py:248-254, 268-270).  The backward re-walks the views through the same function.
+struct SolViewActs {
+    f32x16 H, V1, XV, X2, U;
+    float r1[8], r2[8];
+    float logit, sig1, vis1, sig2, vis2, y;
+};
+template <bool BF>
+__device__ __forceinline__ void sol_view_chain(const float* lds, int lane, int h, const f32x16& H1a, const f32x16& H1b, float w, float mk,
+                                               const float (&rd)[4], SolViewActs& a) {
+    {
+        f32x16 acc = bias_tile(lds, BT_BASE1, h);
+        acc = gemm_frag<BF, 16>(lds, MR_BASE1, lane, H1a, acc);
+        acc = gemm_frag<BF, 16>(lds, MR_BASE1 + 16, lane, H1b, acc);
+        a.H = elu16(acc);
+    }
+    {
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = a.H[r] * w;
+        a.V1 = elu16(gemm_frag<BF, 16>(lds, MR_VIS0, lane, t, bias_tile(lds, BT_VIS0, h)));
+        a.XV = elu16(gemm_frag<BF, 16>(lds, MR_VIS1, lane, a.V1, bias_tile(lds, BT_VIS1, h)));
+        a.logit = mf_elu(dot_frag16(lds + MS_VIS1L + h * 16, a.V1) + lds[MS_VIS1L + 32]);
+        a.sig1 = mf_sigmoid(a.logit);
+        a.vis1 = a.sig1 * mk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            a.X2[r] = a.H[r] + a.XV[r];
+            t[r] = a.X2[r] * a.vis1;
+        }
+        a.U = elu16(gemm_frag<BF, 16>(lds, MR_VISB0, lane, t, bias_tile(lds, BT_VISB0, h)));
+        const float z2 = dot_frag16(lds + MS_VISB1 + h * 16, a.U) + lds[MS_VISB1 + 32];
+        a.sig2 = mf_sigmoid(z2);
+        a.vis2 = a.sig2 * mk;
+    }
+    // colour head: rgb_fc 37 -> 16 -> 8 -> 1
+    {
+        f32x16 acc = gemm_frag<BF, 16>(lds, MR_RGB0, lane, a.X2, bias_tile(lds, BT_RGB0, h));
+        const float v3[3] = {h ? rd[0] : a.vis2, h ? rd[2] : rd[1], h ? 0.f : rd[3]};
+        acc = gemm_small<BF, 3>(lds, MR_RGB0 + 16, lane, v3, acc);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a.r1[r] = mf_elu(acc[r]);
+        float y = lds[MS_RGB2 + 8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* wv = lds + MS_RGB1 + j * 16 + h * 8;
+            const float4 wa = *reinterpret_cast<const float4*>(wv), wb = *reinterpret_cast<const float4*>(wv + 4);
+            const float wr[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t = fmaf(wr[r], a.r1[r], t);
+            a.r2[j] = mf_elu(half_sum(t) + lds[MS_RGB1 + 128 + j]);
+            y = fmaf(lds[MS_RGB2 + j], a.r2[j], y);
+        }
+        a.y = mk == 0.f ? -1e9f : y;          // masked_fill(mask == 0, -1e9)  (:271)
+    }
+}
+
+// the per-view state that stays in registers across a tile.  KEEP (the gather-fused form, whose colour taps and ray differences are
+// computed, not loaded): also the clean colour and the ray difference; otherwise those are read again where they are used (L1 / L2
+// hits of lines the first read brought in) instead of holding 7 V registers across the view loops.
+template <bool KEEP>
+struct SolView {
+    f32x16 F;
+    float fc[3], mk, w, rd3;
+    float c[KEEP ? 3 : 1], rd[KEEP ? 3 : 1];
+};
+
+// first pooling of a tile: weights (:234-241), weighted mean / variance over the views (:144-149) -- all in-lane
+template <int V, bool KEEP>
+__device__ __forceinline__ void sol_pool_first(const float* lds, int aa, SolView<KEEP> (&vw)[V], f32x16& MEAN, f32x16& VAR, float (&mc)[3],
+                                               float (&vc)[3]) {
+    if (aa) {
+        const float s_abs = lds[MS_RGB2 + 9];
+        float e[V];
+        float mn = 3.0e38f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            e[v] = mf_exp(s_abs * (vw[v].rd3 - 1.f));
+            mn = fminf(mn, e[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) vw[v].w = (e[v] - mn) * vw[v].mk;
+    } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) vw[v].w = vw[v].mk;
+    }
+    float ws = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) ws += vw[v].w;
+    ws += 1e-8f;
+#pragma unroll
+    for (int v = 0; v < V; ++v) vw[v].w = vw[v].w / ws;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float mu = vw[0].F[r] * vw[0].w;
+#pragma unroll
+        for (int v = 1; v < V; ++v) mu = fmaf(vw[v].F[r], vw[v].w, mu);
+        float var = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float d = vw[v].F[r] - mu;
+            var = fmaf(vw[v].w * d, d, var);
+        }
+        MEAN[r] = mu;
+        VAR[r] = var;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float mu = vw[0].fc[c] * vw[0].w;
+#pragma unroll
+        for (int v = 1; v < V; ++v) mu = fmaf(vw[v].fc[c], vw[v].w, mu);
+        float var = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float d = vw[v].fc[c] - mu;
+            var = fmaf(vw[v].w * d, d, var);
+        }
+        mc[c] = mu;
+        vc[c] = var;
+    }
+}
+
+template <int V, bool BF, bool GATH, int OCC>
+__global__ void __launch_bounds__(64 * sol_fwd_waves(OCC), OCC) k_ibr_sol_fwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
+                                                         const float* __restrict__ ray_diff, const float* __restrict__ mask,
+                                                         int64_t n_samples, int aa, float* __restrict__ smp, RowGather gather) {
+    HIP_DYNAMIC_SHARED(float, lds)
+    for (int i = threadIdx.x; i < NF_MFMA_FWD_FLOATS; i += blockDim.x) lds[i] = wblob[i];      // BF: wblob is the bf16 image
+    __syncthreads();
+    constexpr int NWV = sol_fwd_waves(OCC);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n_samples + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * NWV + wave; tile < n_tiles; tile += (int64_t)gridDim.x * NWV) {
+        asm volatile("" ::: "memory");       // keeps the (tile-invariant) weight reads inside the loop
+        int64_t sample = tile * 32 + m;
+        const bool live = sample < n_samples;
+        if (!live) sample = n_samples - 1;   // lanes beyond the end recompute the last sample (nothing written)
+        // ---- per view: inputs, direction MLP, f_v.  (The memory clobber keeps the loads of view v + 1 behind the arithmetic of view
+        //      v: hoisted to the top of the tile, the V views' taps would hold 76 V registers at once.)
+        SolView<GATH> vw[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+#ifndef NF_SOL_NO_CLOB1
+            asm volatile("" ::: "memory");
+#endif
+            RowIn in;
+            in.pad = false;
+            const int64_t row = sample * V + v;
+            if (GATH) load_row_gather(gather, V, row, sample, v, h, live, in);
+            else load_row<1>(rgb_feat, ray_diff, mask, row, h, in);
+            sol_direction<BF>(lds, lane, h, in, vw[v].F, vw[v].fc);
+            if constexpr (GATH) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    vw[v].c[c] = in.c[c];
+                    vw[v].rd[c] = in.rd[c];
+                }
+            }
+            vw[v].rd3 = in.rd[3];
+            vw[v].mk = in.mk;
+            // (pins the view's taps and direction MLP inside its iteration: f_v is only consumed by the pooling behind the loop, and
+            //  the compiler otherwise keeps the raw taps of several views -- 64 registers each -- to do their arithmetic later)
+            NF_PIN_FRAG(vw[v].F);
+        }
+        // ---- first pooling, the view-invariant part of base_fc.0
+        f32x16 G0, G1;
+        {
+            f32x16 MEAN, VAR;
+            float mc[3], vc[3];
+            sol_pool_first<V, GATH>(lds, aa, vw, MEAN, VAR, mc, vc);
+            G0 = sol_base0_global<BF, 0>(lds, lane, h, MEAN, mc, VAR, vc);
+            G1 = sol_base0_global<BF, 1>(lds, lane, h, MEAN, mc, VAR, vc);
+        }
+        // ---- per view: the rest of the row network; second-pooling sums around the pivot x2 of view 0
+        f32x16 piv, S1, S2;
+        float vis2[V], y[V];
+        float vs = 0.f, nval = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+#ifndef NF_SOL_NO_CLOB2
+            // (without this clobber the compiler reads every weight record ONCE per tile and keeps it in a register for all V views:
+            //  145 registers of A operands)
+            asm volatile("" ::: "memory");
+#endif
+            SolViewActs a;
+            {
+                const f32x16 H1a = elu16(sol_base0_view<BF, 0>(lds, lane, h, G0, vw[v].F, vw[v].fc));
+                const f32x16 H1b = elu16(sol_base0_view<BF, 1>(lds, lane, h, G1, vw[v].F, vw[v].fc));
+                float rd[4];
+                if constexpr (GATH) {
+                    rd[0] = vw[v].rd[0]; rd[1] = vw[v].rd[1]; rd[2] = vw[v].rd[2];
+                } else {
+                    const float* p = ray_diff + (sample * V + v) * 4;
+                    rd[0] = p[0]; rd[1] = p[1]; rd[2] = p[2];
+                }
+                rd[3] = vw[v].rd3;
+                sol_view_chain<BF>(lds, lane, h, H1a, H1b, vw[v].w, vw[v].mk, rd, a);
+            }
+            vis2[v] = a.vis2;
+            y[v] = a.y;
+            // (pins the colour head of view v inside its iteration: its only consumer is the softmax behind the loop, and the compiler
+            //  otherwise parks the 19 weight records and x2 of every view in scratch and runs the V heads at the end)
+            NF_LAUNDER_F(y[v]);
+            vs += a.vis2;
+            nval += vw[v].mk;
+            if (v == 0) {
+                piv = a.X2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S1[r] = S2[r] = 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = a.X2[r] - piv[r];
+                    const float wd = a.vis2 * d;
+                    S1[r] += wd;
+                    S2[r] = fmaf(wd, d, S2[r]);
+                }
+            }
+        }
+        // ---- second pooling (:255-257): w2_v = vis2_v / (sum + 1e-8)
+        const float vsum = vs + 1e-8f;
+        const float inv_vsum = 1.f / vsum;
+        float W = 0.f;                        // sum of the normalised weights (1, or 0 when no view is valid)
+#pragma unroll
+        for (int v = 0; v < V; ++v) W += vis2[v] * inv_vsum;
+        const float wmean = W * (1.f / (float)V);
+        f32x16 MEAN2, VAR2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m1 = S1[r] * inv_vsum;                 // sum w2 d
+            const float mu = fmaf(piv[r], W - 1.f, m1);        // mean - pivot
+            MEAN2[r] = mu + piv[r];
+            VAR2[r] = fmaf(mu * mu, W, fmaf(-2.f * mu, m1, S2[r] * inv_vsum));
+        }
+        // ---- blending softmax over the views, blend of the clean colours (:271-273)
+        float rgb[3] = {0.f, 0.f, 0.f};
+        {
+            float mx = y[0];
+#pragma unroll
+            for (int v = 1; v < V; ++v) mx = fmaxf(mx, y[v]);
+            float p[V], ps = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                p[v] = mf_exp(y[v] - mx);
+                ps += p[v];
+            }
+            const float inv = 1.f / ps;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const float beta = p[v] * inv;
+                float col[3];
+                if constexpr (GATH) {
+                    col[0] = vw[v].c[0]; col[1] = vw[v].c[1]; col[2] = vw[v].c[2];
+                } else {
+                    const float* q = rgb_feat + (sample * V + v) * 35;
+                    col[0] = q[0]; col[1] = q[1]; col[2] = q[2];
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rgb[c] = fmaf(beta, col[c], rgb[c]);
+            }
+        }
+        if (live) {
+            float* out = smp + sample * NF_SMP_STRIDE;
+            frag_store32(out, h, MEAN2);
+            frag_store32(out + 32, h, VAR2);
+            if (h == 0) {
+                *reinterpret_cast<float4*>(out + 64) = make_float4(wmean, rgb[0], rgb[1], rgb[2]);
+                out[68] = nval;
+                out[69] = vsum;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // kernel A backward: d(per-sample record) -> d rgb_feat.  Follows oracle/ibrnet_manual_bwd.py; the backward-data GEMMs
 // dX^T = W^T . dY^T use the transposed records and chain through registers exactly like the forward.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1034,13 +1391,6 @@ __host__ __device__ constexpr int rows_bwd_waves(bool bf, bool scat) { return (r
 __host__ __device__ constexpr int rows_bwd_occ(bool bf, bool scat) { return (rows_bwd_two_phase(bf) || bf) ? 2 : NF_ROWS_BWD_OCC; }
 __host__ __device__ constexpr int rows_bwd_wgs_per_cu(bool bf, bool scat) { return (bf && !scat) ? 2 : 1; }
 
-// makes a value opaque to the optimiser (the two-phase backward RECOMPUTES the early activations from the laundered inputs: without
-// it the compiler proves them equal to the first evaluation and keeps those registers alive instead)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define NF_LAUNDER_F(x) asm volatile("" : "+v"(x))
-#else
-#define NF_LAUNDER_F(x) asm volatile("" : "+x"(x))
-#endif
 
 template <int V, bool BF, bool SCAT, bool GATH>
 __global__ void __launch_bounds__(64 * rows_bwd_waves(BF, SCAT), rows_bwd_occ(BF, SCAT)) k_ibr_rows_bwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
@@ -1967,6 +2317,57 @@ static void launch_rows_fwd(const float* wblob, const float* bf_blob, const floa
 #undef NF_ROWS_FWD_GO
 }
 
+// ---- which form of kernel A runs: the sample-on-the-lane form where it is built (fp32 operands, 2 <= V <= NF_SOL_MAX_V), the row
+// form otherwise.  nf_ibrnet_rows_form(1) pins the row form (TEST / DIAGNOSTIC hook: the tests run both forms on the same inputs).
+static int g_rows_form = 0;
+extern "C" int nf_ibrnet_rows_form(int form) {
+    const int old = g_rows_form;
+    if (form == 0 || form == 1) g_rows_form = form;
+    return old;
+}
+static bool sol_selected(int n_views, bool bf16) { return g_rows_form == 0 && !bf16 && n_views >= 2 && n_views <= NF_SOL_MAX_V; }
+/* does the sample-on-the-lane form run for this shape under the current setting? */
+extern "C" int nf_ibrnet_sol_selected(int n_views, int bf16_operands) { return sol_selected(n_views, bf16_operands != 0) ? 1 : 0; }
+
+template <int V, int OCC>
+static int launch_sol_fwd_vo(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_samples, int aa,
+                             float* smp, const RowGather& g, hipStream_t st) {
+    constexpr int NWV = sol_fwd_waves(OCC);
+    const int64_t tiles = (n_samples + 31) / 32;
+    int64_t blocks = (tiles + NWV - 1) / NWV;
+    const int64_t cap = 256;                // one resident workgroup per CU (MI355X: 256) stages the 58 KB weight image once and walks its tiles
+    if (blocks > cap) blocks = cap;
+    const size_t smem = (size_t)NF_MFMA_FWD_FLOATS * sizeof(float);
+    if (g.featmap)
+        hipLaunchKernelGGL((k_ibr_sol_fwd<V, false, true, OCC>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, wblob, rgb_feat, ray_diff, mask,
+                           n_samples, aa, smp, g);
+    else
+        hipLaunchKernelGGL((k_ibr_sol_fwd<V, false, false, OCC>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, wblob, rgb_feat, ray_diff, mask,
+                           n_samples, aa, smp, g);
+    return 0;
+}
+template <int V>
+static int launch_sol_fwd_v(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_samples, int aa,
+                            float* smp, const RowGather& g, hipStream_t st) {
+    // A tile is 32 samples x V views of serial work.  With no more tiles than the chip has SIMDs (1024) every tile gets a SIMD of its own
+    // in four-wave workgroups (the attack's coarse level: 512 rays x 64 samples = 1024 tiles); beyond that two waves per SIMD hide each
+    // other's LDS / memory latency where the registers allow it (V <= 4: measured 0.361 -> 0.311 ms at 4096 x 64 x 4).
+    if constexpr (V <= 4) {
+        if ((n_samples + 31) / 32 > 1024) return launch_sol_fwd_vo<V, 2>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st);
+    }
+    return launch_sol_fwd_vo<V, 1>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st);
+}
+static int launch_sol_fwd(int n_views, const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_samples,
+                          int aa, float* smp, const RowGather& g, hipStream_t st) {
+    switch (n_views) {
+#define NF_SOL_CASE(VV) case VV: return launch_sol_fwd_v<VV>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st);
+        NF_SOL_CASE(2) NF_SOL_CASE(3) NF_SOL_CASE(4) NF_SOL_CASE(5) NF_SOL_CASE(6) NF_SOL_CASE(7) NF_SOL_CASE(8) NF_SOL_CASE(9) NF_SOL_CASE(10)
+#undef NF_SOL_CASE
+    }
+    nf_set_error("nf_ibrnet_fwd_mfma: no sample-on-the-lane kernel for %d views", n_views);
+    return 1;
+}
+
 static int ibrnet_fwd_impl(const char* who, const float* bf_blob, const float* mfma_blob, const float* blob, const float* pos_enc,
                            const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_rays, int n_samples, int n_views,
                            int anti_alias_pooling, float* raw, float* workspace, nf_stream_t stream, const RowGather& gather = RowGather{}) {
@@ -1974,6 +2375,10 @@ static int ibrnet_fwd_impl(const char* who, const float* bf_blob, const float* m
     if (n_rays == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int64_t ns = n_rays * n_samples;
+    if (sol_selected(n_views, bf_blob != nullptr)) {
+        const int rc = launch_sol_fwd(n_views, mfma_blob, rgb_feat, ray_diff, mask, ns, anti_alias_pooling, workspace, gather, st);
+        if (rc) return rc;
+    } else
     switch (rows_lanes_per_sample(n_views)) {
         case 1: launch_rows_fwd<1>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, n_views, anti_alias_pooling, workspace, gather, st); break;
         case 2: launch_rows_fwd<2>(mfma_blob, bf_blob, rgb_feat, ray_diff, mask, ns, n_views, anti_alias_pooling, workspace, gather, st); break;

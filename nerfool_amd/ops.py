@@ -189,6 +189,17 @@ def ibrnet_mfma_supported(S, V):
     return bool(_lib.lib().nf_ibrnet_mfma_supported(int(S), int(V)))
 
 
+def ibrnet_rows_form(form):
+    """TEST / DIAGNOSTIC hook (nf_ibrnet_rows_form): 'auto' = the sample-on-the-lane kernels where they exist (fp32, 2 <= V <= 10),
+    'rows' = the row-form kernels always.  Returns the previous setting."""
+    names = ('auto', 'rows')
+    return names[_lib.lib().nf_ibrnet_rows_form(names.index(form))]
+
+
+def ibrnet_sol_selected(n_views, bf16=False):
+    return bool(_lib.lib().nf_ibrnet_sol_selected(int(n_views), int(bool(bf16))))
+
+
 def ibrnet_fwd_mfma(mfma_blob, blob, pos_enc, rgb_feat, ray_diff, mask, anti_alias, bf16_blob=None):
     """bf16_blob: run the per-(sample, view) row network on bf16 matrix-core operands (fp32 accumulate)"""
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')

@@ -81,6 +81,36 @@ def check_stage_kernels(case, dev):
         assert_close(zf, g.np('outputs_fine/z_vals'), 1e-4, 1e-5, 'fine depths')
 
 
+def check_row_kernel_forms(case, dev):
+    """kernel A exists in two forms (include/nerfool_hip.h: nf_ibrnet_rows_form): the sample-on-the-lane form must be the one that
+    runs by default at this view count, both forms must meet the reference's capture, and they must agree with each other far inside
+    that tolerance (same arithmetic up to the order of the cross-view sums and the pivot form of the second variance)."""
+    g = Golden(case)
+    cfg = g.stage_cfg()
+    S, V = cfg['S'], cfg['V']
+    net = make_net(g.params('coarse'), S, cfg['anti_alias_pooling'], dev)
+    ins = (g.t('coarse/rgb_feat', dev), g.t('coarse/ray_diff', dev), g.t('coarse/mask', dev))
+    ref_raw = g.np('coarse/raw')
+    scale = float(np.abs(ref_raw).max())
+    assert ops.ibrnet_rows_form('auto') in ('auto', 'rows')
+    try:
+        assert ops.ibrnet_sol_selected(V) == (2 <= V <= 10), 'the sample-on-the-lane form must run for V = %d' % V
+        with torch.no_grad():
+            raw_sol = net(*ins)
+        ops.ibrnet_rows_form('rows')
+        assert not ops.ibrnet_sol_selected(V)
+        with torch.no_grad():
+            raw_rows = net(*ins)
+    finally:
+        ops.ibrnet_rows_form('auto')
+    assert_close(raw_sol, ref_raw, 1e-3, 1e-3 * scale, 'IBRNet raw, sample-on-the-lane form')
+    assert_close(raw_rows, ref_raw, 1e-3, 1e-3 * scale, 'IBRNet raw, row form')
+    assert_close(raw_sol, raw_rows, 2e-5, 2e-5 * scale, 'the two forms of kernel A')
+    print('[row kernel forms] %s V %d: max |sol - rows| %.2e of scale, sol vs reference %.2e, rows vs reference %.2e'
+          % (case, V, float((raw_sol - raw_rows).abs().max()) / scale, float((raw_sol.cpu() - torch.from_numpy(ref_raw)).abs().max()) / scale,
+             float((raw_rows.cpu() - torch.from_numpy(ref_raw)).abs().max()) / scale))
+
+
 def check_ibrnet_backward(case, dev):
     """HIP IBRNet backward vs autograd of the oracle forward (CPU)."""
     g = Golden(case)

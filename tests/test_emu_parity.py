@@ -50,6 +50,11 @@ def test_stage_kernels(case):
 
 
 @pytest.mark.parametrize('case', TINY)
+def test_row_kernel_forms(case):
+    pc.check_row_kernel_forms(case, 'cpu')
+
+
+@pytest.mark.parametrize('case', TINY)
 def test_ibrnet_backward(case):
     pc.check_ibrnet_backward(case, 'cpu')
 

@@ -29,6 +29,11 @@ def test_stage_kernels(case):
 
 
 @pytest.mark.parametrize('case', TINY)
+def test_row_kernel_forms(case):
+    pc.check_row_kernel_forms(case, 'cuda')
+
+
+@pytest.mark.parametrize('case', TINY)
 def test_ibrnet_backward(case):
     pc.check_ibrnet_backward(case, 'cuda')
 
@@ -305,10 +310,12 @@ def test_c5_full_size_properties():
         err = float((b[k] - f[k]).abs().max())
         print('[config 5 full size] %s: bf16 rows vs fp32 rows max abs %.2e' % (k, err))
         assert err <= 2e-2, (k, err)
-    # same fine depths except where a bf16-moved coarse weight tips an inverse-CDF draw into the neighbouring bin
-    moved = float((b['z_f'] != f['z_f']).float().mean())
-    print('[config 5 full size] fine depths that differ between the precisions: %.2e of all' % moved)
-    assert moved <= 5e-2
+    # the fine depths are a continuous function of the coarse weights (inverse CDF), so they move a little everywhere and by a bin
+    # where a bf16-moved weight tips a draw across a cdf edge: most within 1e-3 of the depth range, few beyond 5 % of it
+    dz = (b['z_f'] - f['z_f']).abs() / (4.8 - 3.2)
+    med, far_frac = float(dz.median()), float((dz > 5e-2).float().mean())
+    print('[config 5 full size] fine depths, bf16 vs fp32 rows: median |dz| %.2e of the range, %.2e of them beyond 5 %% of it' % (med, far_frac))
+    assert med <= 1e-3 and far_frac <= 2e-2
     for k in ('g_c', 'g_f'):
         rel = float((b[k] - f[k]).norm() / f[k].norm())
         print('[config 5 full size] %s: bf16 rows vs fp32 rows rel-L2 %.2e' % (k, rel))
