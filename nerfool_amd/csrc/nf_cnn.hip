@@ -24,6 +24,11 @@
 #ifndef NF_BWD1_UNROLL
 #define NF_BWD1_UNROLL 2
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NF_OPAQUE_INT(x) asm volatile("" : "+v"(x))      // the optimiser forgets what it knows about x (no instruction)
+#else
+#define NF_OPAQUE_INT(x) asm volatile("" : "+r"(x))
+#endif
 #define NF_PRAGMA(x) _Pragma(#x)
 #define NF_UNROLL(n) NF_PRAGMA(unroll n)
 
@@ -493,8 +498,8 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-        // compiler barrier every 4 items: bounds how many items' loads are hoisted at once (12 at once spill ~90 VGPRs)
-        if (EPT > 4 && (k & 3) == 0 && k > 0) asm volatile("" ::: "memory");
+        // compiler barrier every 2 items: bounds how many items' loads (up to 6 x 16 bytes each) are hoisted at once
+        if (EPT > 4 && (k & 1) == 0 && k > 0) asm volatile("" ::: "memory");
         const int idx = threadIdx.x + k * NT;
         const int h = idx / G, w0 = (idx - h * G) << 2, nvalid = idx < total ? min(4, W - w0) : 0;
         nf_f4u xv;
@@ -521,7 +526,11 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
     float* drp = d_res ? d_res + p * HW : nullptr;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-        const int idx = threadIdx.x + k * NT;
+        if (EPT > 4 && (k & 3) == 0 && k > 0) asm volatile("" ::: "memory");       // (the x re-reads of at most 4 items in flight)
+        int idx = threadIdx.x + k * NT;
+        // (the item's row / column are derived AGAIN here: remembered from the first loop they cost 3 registers per item, which at
+        //  16 items is what spilled)
+        if (EPT > 4) NF_OPAQUE_INT(idx);
         if (idx >= total) continue;
         const int h = idx / G, w0 = (idx - h * G) << 2, nvalid = min(4, W - w0), i0 = h * W + w0;
         nf_f4u o, xh;
@@ -539,12 +548,14 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
     }
 }
 
-// which plane-resident instantiation holds an H x W plane: 0 none, 1 (256 threads x 3 items), 2 (1024 x 3), 3 (1024 x 12)
+// which plane-resident instantiation holds an H x W plane: 0 none, 1 (256 threads x 3 items), 2 (1024 x 3), 3 (768 x 16: 64 registers
+// of gradient per thread at three waves per SIMD -- 1024 x 12 at four waves per SIMD spilled 46 of its 48, two extra passes of the
+// tensor through scratch memory: 292 MB per launch where 195 MB are the tensors)
 static int nf_plane_variant(int H, int W) {
     const int64_t items = (int64_t)H * ((W + 3) / 4);
     if (items <= 256 * 3) return 1;
     if (items <= 1024 * 3) return 2;
-    if (items <= 1024 * 12) return 3;
+    if (items <= 768 * 16) return 3;
     return 0;
 }
 
@@ -616,14 +627,15 @@ extern "C" int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W,
     const int planes = n_img * C, HW = H * W, HWp = (H + 2 * pad) * (W + 2 * pad);
     if (y_n_stride == 0) y_n_stride = (int64_t)C * HWp;       // packed [N,C,Hp,Wp]
     int variant = gamma ? nf_plane_variant(H, W) : 0;
-    if (variant == 3) variant = 0;      // one 1024-thread workgroup per CU serialises load / reduce / store: two passes are faster
+    // (variant 3 was slower than the two-pass form as 1024 threads x 12 items -- one workgroup per CU serialising load / reduce / store;
+    //  as 768 x 16 it is faster: 189 x 252 planes 34.6 -> 22.2 us, one read of the convolution output instead of two)
     if (variant) {
 #define NF_PLANE_FWD(NT, EPT)                                                                                                   \
     hipLaunchKernelGGL((k_plane_fwd<NT, EPT>), dim3((unsigned)planes), dim3(NT), 0, st, x, C, H, W, gamma, beta, eps, res, rs_n, \
                        rs_c, rs_h, rs_w, act, pad, y_padded, mean, rstd, y_n_stride)
         if (variant == 1) NF_PLANE_FWD(256, 3);
         else if (variant == 2) NF_PLANE_FWD(1024, 3);
-        else NF_PLANE_FWD(1024, 12);
+        else NF_PLANE_FWD(768, 16);
 #undef NF_PLANE_FWD
         NF_LAUNCH_CHECK("nf_in_act_pad_fwd (plane)");
         return 0;
@@ -657,14 +669,16 @@ extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, c
     const int planes = n_img * C, HW = H * W;
     int variant = gamma ? nf_plane_variant(H, W) : 0;
     if (variant > NF_PLANE_BWD_MAX) variant = 0;
-    if (variant == 3 && d_res) variant = 0;      // measured: with the extra d_res stream the two-pass form is faster for big planes
+#ifdef NF_PLANE_BWD_NO_RES3
+    if (variant == 3 && d_res) variant = 0;      // (round 2, with the spilling 1024 x 12 form: the two-pass form was faster with a d_res stream)
+#endif
     if (variant) {
 #define NF_PLANE_BWD(NT, EPT, KEEP)                                                                                            \
     hipLaunchKernelGGL((k_plane_bwd<NT, EPT, KEEP>), dim3((unsigned)planes), dim3(NT), 0, st, dy_padded, d_extra, y_padded, x, C, H, W, \
                        gamma, mean, rstd, act, pad, d_res, dx, from_x ? beta : nullptr, dy_n_stride, d_extra_sub)
         if (variant == 1) NF_PLANE_BWD(256, 3, true);
         else if (variant == 2) NF_PLANE_BWD(1024, 3, true);
-        else NF_PLANE_BWD(1024, 12, false);
+        else NF_PLANE_BWD(768, 16, false);
 #undef NF_PLANE_BWD
         NF_LAUNCH_CHECK("nf_in_act_pad_bwd (plane)");
         return 0;

@@ -196,40 +196,35 @@ class _Act:
         self.gs = g if self.gs is None else self.gs + g
 
 
-# 3x3 stride-1 convolutions: 'auto' times the Winograd matrix-core kernel (csrc/nf_wino.hip) with 64 and with 32 output
-# channels per workgroup, once per (shape, direction) on first use, and keeps the faster -- both forms compute every output
-# with the same arithmetic in the same order, so the choice does not change a single bit of the result; 'wino' / 'wino32'
-# force one (test / diagnostic hook)
+# 3x3 stride-1 convolutions: the Winograd matrix-core kernel (csrc/nf_wino.hip) runs with 64 or with 32 output channels per
+# workgroup -- both forms compute every output with the same arithmetic in the same order, so the width does not change a single bit
+# of the result.  'auto' picks it by a RULE ON THE SHAPE (round 4; until round 3 a one-off timing per process, which made the trace,
+# counter and bench runs of one commit use different configurations): 32 exactly when the 64-wide grid would not fill one round of
+# the chip's 512 resident workgroups (two per CU) -- there the narrower form doubles the workgroups (256 -> 256 at 48 x 63: 79 -> 69
+# us); everywhere else the 64-wide form is faster or equal (tools/bench_conv3x3.py: 128 -> 128 at 95 x 126 67 vs 71 us, 256 -> 128
+# at 96 x 126 119 vs 136 us).  'wino' / 'wino32' force one (test / diagnostic hook).
 CONV3X3 = 'auto'
-_CONV_CHOICE = {}
+_CONV_CHOICE = {}          # (direction, c_in, c_out, input shape) -> chosen form: what bench.py reports
 
 
-def _time_us(fn, iters=3, batches=2):
-    """best mean over `batches` batches of `iters` calls after one warm-up call (first use happens on a cold device)"""
-    fn()
-    best = float('inf')
-    for _ in range(batches):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        e1.synchronize()
-        best = min(best, e0.elapsed_time(e1) / iters * 1e3)
-    return best
+def _wino_width(c_out, n_img, h_out, w_out):
+    """output channels per workgroup for a Winograd launch producing [n_img, c_out, h_out, w_out] (8 x 16 output blocks)"""
+    if c_out <= 64:
+        return ops.wino_group(c_out)
+    blocks64 = n_img * (-(-h_out // 8)) * (-(-w_out // 16)) * (c_out // 64)
+    return 32 if blocks64 < 512 else 64
 
 
-def _pick(key, candidates, timed):
-    """which implementation runs this convolution (candidates: name -> thunk): decided once per key"""
+def _pick(key, candidates, rule):
+    """which implementation runs this convolution (candidates: name -> thunk); rule = the name the shape rule selects"""
     if CONV3X3 in candidates:
-        return CONV3X3
-    if len(candidates) == 1:
-        return next(iter(candidates))
-    if not timed:                       # CPU stand-in build: no timing, the default Winograd form
-        return 'wino'
-    if key not in _CONV_CHOICE:
-        _CONV_CHOICE[key] = min(candidates, key=lambda name: _time_us(candidates[name]))
-    return _CONV_CHOICE[key]
+        name = CONV3X3
+    elif len(candidates) == 1:
+        name = next(iter(candidates))
+    else:
+        name = rule
+    _CONV_CHOICE[key] = name
+    return name
 
 
 def _wino_records(conv_w, k_per_group):
@@ -260,11 +255,12 @@ def _wino_ring_records(conv_w):
 def _conv3x3(tape, inp, w, sink):
     """3x3 stride-1 convolution on a pre-padded activation (padding 0) and its backward-data pass"""
     c_out, c_in = w.shape[0], w.shape[1]
-    timed = inp.is_cuda
+    N, Hi, Wi = inp.shape[0], inp.shape[2], inp.shape[3]
     fwd = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out))[0], inp, c_out, 0, k_per_group=ops.wino_group(c_out))}
     if c_out > 64:                      # narrower workgroups only matter when they add workgroups to a thin grid
         fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[0], inp, c_out, 0, k_per_group=32)
-    out = _Slot(fwd[_pick(('f', c_in, c_out) + tuple(inp.shape), fwd, timed)]())
+    rule = 'wino32' if _wino_width(c_out, N, Hi - 2, Wi - 2) == 32 and c_out > 64 else 'wino'
+    out = _Slot(fwd[_pick(('f', c_in, c_out) + tuple(inp.shape), fwd, rule)]())
 
     def bwd():
         g_out = out.g
@@ -281,7 +277,9 @@ def _conv3x3(tape, inp, w, sink):
         cand = {'wino': lambda: bwd_data(ops.wino_group(c_in))}
         if c_in > 64:
             cand['wino32'] = lambda: bwd_data(32)
-        sink(cand[_pick(('b', c_in, c_out) + tuple(inp.shape), cand, timed)]())
+        ho, wo = (g_out.shape[2] + 2, g_out.shape[3] + 2) if plan is None else (plan[0], plan[1])
+        rule_b = 'wino32' if _wino_width(c_in, N, ho, wo) == 32 and c_in > 64 else 'wino'
+        sink(cand[_pick(('b', c_in, c_out) + tuple(inp.shape), cand, rule_b)]())
         out.g = None
     tape.append(bwd)
     return out

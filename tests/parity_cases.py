@@ -161,6 +161,17 @@ def check_gather_and_composite_backward(case, dev):
     assert_close(mine, ref, 1e-4, 1e-5 * float(ref.abs().max()), 'd outputs / d raw')
 
 
+def moved_samples(a, b, tol):
+    """fraction of the entries of the sorted rows of `a` without an entry of the same row of `b` within tol (rows [R, S])"""
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a, dtype=np.float64))
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b, dtype=np.float64))
+    assert a.shape == b.shape
+    b = b.contiguous()
+    i = torch.searchsorted(b, a.contiguous()).clamp(1, b.shape[1] - 1)
+    near = torch.minimum((a - b.gather(1, i - 1)).abs(), (a - b.gather(1, i)).abs())
+    return float((near > tol * (1.0 + a.abs())).double().mean())
+
+
 def check_render_rays(case, dev):
     """The product render_rays (all kernels chained, autograd Functions) vs the reference's end-to-end capture."""
     g = Golden(case)
@@ -186,7 +197,10 @@ def check_render_rays(case, dev):
         # a re-sampled depth can flip bins where u_k ties a cdf edge or where the reference's `denom < 1e-5 -> 1`
         # rule makes the inverse CDF discontinuous (render_ray.py:62-64): tolerate isolated flips
         # (the reference's own fp32 run moves 3e-4 .. 5e-3 of the samples against its float64 run, make_golden_grad64.py)
-        assert_close(ret[level]['z_vals'], g.np(level + '/z_vals'), 1e-4, 1e-4, level + ' z_vals', frac_ok=2e-3)
+        # counted as MOVED SAMPLES (depths of this evaluation that have no partner in the reference's row): one flipped draw shifts a
+        # whole run of the sorted row by one slot, which an element-by-element comparison would count as many errors
+        moved = moved_samples(ret[level]['z_vals'], g.np(level + '/z_vals'), 1e-4)
+        assert moved <= 2e-3, '%s z_vals: %.2e of the samples have no partner in the reference row' % (level, moved)
         for k in ('weights', 'alpha'):
             assert_close(ret[level][k], g.np('%s/%s' % (level, k)), 2e-3, 5e-4, '%s %s' % (level, k), frac_ok=2e-3)
     assert_close(loss, g.np('loss'), 1e-3, 1e-6, 'loss')
