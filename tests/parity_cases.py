@@ -245,9 +245,12 @@ def check_render_rays(case, dev):
     for name, mine, want, nat, ref32 in zip(('coarse', 'fine'), grads, g64, g_nat, ('grad/featmap_coarse', 'grad/featmap_fine')):
         err = float((d64(mine) - want).norm() / want.norm())
         floor = float((torch.from_numpy(g.np(ref32)).double() - nat).norm() / nat.norm())
-        print('[grad parity] %s d loss / d featmap_%s: rel-L2 vs float64 (same fine depths) %.3e | reference fp32 vs float64: %.3e'
-              % (case, name, err, floor))
-        assert err <= max(1e-3, 3 * floor), 'd loss / d featmap_%s: rel-L2 %.3e vs float64 (reference fp32 floor %.3e)' % (name, err, floor)
+        print('[grad parity] %s d loss / d featmap_%s: rel-L2 vs float64 (same fine depths) %.3e | reference fp32 vs float64: %.3e | ratio %.2f'
+              % (case, name, err, floor, err / floor))
+        # the HIP path may be at most TWICE as far from float64 as the reference's own fp32 evaluation is (or 1e-4, where both are
+        # at rounding level): measured ratios 0.3 .. 1.6 (profiles/r04_parity_numbers.txt)
+        assert err <= max(1e-4, 2 * floor), 'd loss / d featmap_%s: rel-L2 %.3e vs float64, %.2f x the reference fp32 floor %.3e' % (
+            name, err, err / floor, floor)
         assert_close(mine, want, 0, 1e-3 * float(want.abs().max()), 'd loss / d featmap_' + name, frac_ok=1e-3)
     assert abs(float(loss.detach()) - float(loss64.detach())) <= 1e-4 * float(loss64.detach()), 'loss vs float64'
 
