@@ -103,6 +103,10 @@ def parse():
                     help='N > 1: --n-rand rays per rank (weak) or split over the ranks (strong)')
     ap.add_argument('--cpu-iters', type=int, default=10, help='timed CPU-oracle PGD iterations for cpu_baseline after 2 warm-ups (0 = skip)')
     ap.add_argument('--extras', type=int, default=1, help='0 = only the headline timed region (profiling runs)')
+    ap.add_argument('--conv-operands', choices=('bf16x3', 'fp32'), default='bf16x3',
+                    help="operand form of the 3x3 convolutions' Winograd products: 'bf16x3' (default of the package: every fp32 operand as "
+                         "three bf16 parts on the bf16 matrix cores, six cross terms, error at fp32 rounding level) or 'fp32' "
+                         "(v_mfma_f32_32x32x2_f32, the form of rounds 1-3)")
     ap.add_argument('--device', choices=('gpu', 'cpu-standin'), default='gpu',
                     help="'cpu-standin': FUNCTIONAL check of the launcher / sharding on a box without a GPU -- the kernels' CPU stand-in "
                          "build (tests/host_harness), gloo, shape-generic kernels; tiny sizes only, never a measurement")
@@ -427,6 +431,7 @@ def main():
     args, data, model, sampler, src_ray_batch, projector, EA = build_problem(a, dev)
     from nerfool_amd import prof
     from nerfool_amd.ibrnet import feature_network
+    feature_network.WINO_OPERANDS = a.conv_operands
 
     def make_attack(cnn_shard, scaling, n_rand=None):
         """a fresh PGDAttack (own delta / moments) in the given multi-GPU form; n_rand as on the command line: rays per rank
@@ -604,6 +609,13 @@ def main():
                            'total_ms': round(k['total_ms'], 3)}
     if 'nf_conv3x3_wino' in table:
         table['nf_conv3x3_wino']['direct_form_equivalent_tflops'] = round(float(np.mean(wino_direct)), 2)
+        table['nf_conv3x3_wino']['operands'] = a.conv_operands
+        if a.conv_operands == 'bf16x3':
+            # `achieved` counts every Winograd-domain product ONCE (an fp32-accurate product, priced against the fp32 matrix peak: what the
+            # hardware offers natively for that accuracy); the kernel executes it as six bf16 products on the bf16 matrix pipe
+            ex = 6.0 * table['nf_conv3x3_wino']['achieved']
+            table['nf_conv3x3_wino']['executed_bf16_tflops'] = round(ex, 2)
+            table['nf_conv3x3_wino']['executed_frac_of_bf16_peak'] = round(ex / PEAK_BF16_TFLOPS, 4)
     if 'nf_ibrnet_bwd_mfma' in table and 'nf_project_gather_bwd' not in table:
         table['nf_ibrnet_bwd_mfma']['includes'] = ('the scatter of d rgb_feat into the feature-map gradient (float atomics, formerly '
                                                    'nf_project_gather_bwd: 0.11 ms per launch) -- not counted in the FLOPs')
@@ -655,7 +667,7 @@ def main():
         # part, compositing and update in fp32)
         'dtype': 'bf16' if (a.precision == 'bf16') else 'f32', 'data': 'synthetic',
         'device': 'MI355X (gfx950)' if not standin else 'cpu-standin: FUNCTIONAL check of the launcher / sharding, not a measurement',
-        'config': {'workload': workload,
+        'config': {'workload': workload, 'conv_operands': a.conv_operands,
                    'rays_per_step_all_ranks': rays_per_step, 'parallelism': par,
                    'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step},
         'roofline': roofline,

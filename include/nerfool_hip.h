@@ -277,6 +277,17 @@ int nf_wino_pack(const float* weight_host, int c_out, int c_in, int backward, in
 int nf_conv3x3_wino(const float* records, int k_per_group, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi,
                     int pad, float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out,
                     int tile_blocks, nf_stream_t stream);
+/* The same convolutions with the Winograd-domain products on the BF16 matrix cores (csrc/nf_wino_bf.hip; ref: the same lines,
+ * ibrnet/feature_network.py:28-36, 38-78, 127-151).  n_split = 3: every fp32 operand is the sum of three bf16 parts (8 significant
+ * bits each) and the product is the six cross terms of order <= 2^-16 -- dropped terms <= 2^-24 of the product, i.e. fp32 rounding
+ * level: a drop-in for nf_conv3x3_wino at 6 / 16 of its matrix-pipe time.  n_split = 1: plain bf16 operands (BASELINE config 5's
+ * opt-in precision; 8 significant bits per operand, tolerance stated in DESIGN.md).  records = nf_wino_bf_pack(weight, ...,
+ * k_per_group in {32, 64}, n_split) (HOST pointers); tensors, geometry and strides as nf_conv3x3_wino. */
+int64_t nf_wino_bf_pack_floats(int c_out, int c_in, int k_per_group, int n_split);
+int nf_wino_bf_pack(const float* weight_host, int c_out, int c_in, int backward, int k_per_group, int n_split, float* records_host);
+int nf_conv3x3_wino_bf(const float* records, int k_per_group, int n_split, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi,
+                       int Wi, int pad, float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out,
+                       nf_stream_t stream);
 /* The one-pixel border ring of a backward-data pass, g = d(padded input) [N, c_dx, H + 2, W + 2] from dy [N, c_dy, H, W]: the ring
  * sees one row / column of dy, i.e. four 1-D convolutions -- computed apart so that the Winograd kernel covers an H x W region
  * with the forward pass's block count (48 x 63: 24 blocks instead of 35) at pad 1 on the output shifted by (1, 1).

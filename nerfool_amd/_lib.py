@@ -91,6 +91,10 @@ _PROTOTYPES = {
     'nf_wino_pack': (c_int, [_P, c_int, c_int, c_int, c_int, _P]),
     'nf_conv3x3_wino': (c_int, [_P, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int,
                                 c_int, c_int, c_int, c_int, c_int, _P]),
+    'nf_wino_bf_pack_floats': (c_int64, [c_int, c_int, c_int, c_int]),
+    'nf_wino_bf_pack': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'nf_conv3x3_wino_bf': (c_int, [_P, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int,
+                                   c_int, c_int, c_int, c_int, _P]),
     'nf_wino_ring_pack_floats': (c_int64, [c_int, c_int]),
     'nf_wino_ring_pack': (c_int, [_P, c_int, c_int, _P]),
     'nf_conv3x3_bwd_ring': (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int,

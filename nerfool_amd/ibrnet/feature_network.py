@@ -97,6 +97,9 @@ class ResUNet(nn.Module):
         self.upconv2 = _Up(128, 64)
         self.iconv2 = _ConvNormELU(64 + 64, out_ch, 3)
         self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
+        # operand form of the stride-1 3x3 convolutions' Winograd products: None = the module default WINO_OPERANDS (fp32-grade);
+        # 'bf16' = plain bf16 operands, set by IBRNetModel for args.ibrnet_precision == 'bf16' (BASELINE config 5) -- never silently
+        self.conv_precision = None
 
     def describe_output(self, H, W):
         """(channels of the distinct maps, same-map-twice, second-is-None, Hf, Wf) of forward() on [*, 3, H, W]: every
@@ -207,9 +210,11 @@ CONV3X3 = 'auto'
 _CONV_CHOICE = {}          # (direction, c_in, c_out, input shape) -> chosen form: what bench.py reports
 
 
-def _wino_width(c_out, n_img, h_out, w_out):
-    """output channels per workgroup for a Winograd launch producing [n_img, c_out, h_out, w_out] (8 x 16 output blocks)"""
-    if c_out <= 64:
+def _wino_width(c_out, n_img, h_out, w_out, n_split=0):
+    """output channels per workgroup for a Winograd launch producing [n_img, c_out, h_out, w_out] (8 x 16 output blocks).  The
+    bf16-split kernels always take 64: their 32-wide form holds too many registers for a third workgroup per CU, which is what
+    made 32 pay on thin grids (256 -> 256 at 48 x 63, bf16x3: 63 us at 64 against 75 us at 32)."""
+    if c_out <= 64 or n_split:
         return ops.wino_group(c_out)
     blocks64 = n_img * (-(-h_out // 8)) * (-(-w_out // 16)) * (c_out // 64)
     return 32 if blocks64 < 512 else 64
@@ -227,18 +232,26 @@ def _pick(key, candidates, rule):
     return name
 
 
-def _wino_records(conv_w, k_per_group):
-    """(forward records, backward-data records) of a weight for one workgroup width; packed on first use.  The records hang
-    on the weight tensor itself (like conv._nf_records of the 1x1 convolutions), so they die with it and can never be taken
+# Operand form of the Winograd products (csrc/nf_wino.hip / nf_wino_bf.hip): 'fp32' = v_mfma_f32_32x32x2_f32; 'bf16x3' = every fp32 operand
+# as three bf16 parts on v_mfma_f32_32x32x16_bf16, the six cross terms of order <= 2^-16 (dropped: <= 2^-24 of a product, fp32 rounding
+# level -- same parity bars as 'fp32'); 'bf16' = plain bf16 operands (BASELINE config 5's opt-in precision, never the default).
+# WINO_OPERANDS is the default for networks that do not ask for 'bf16' (ResUNet.conv_precision); test / diagnostic hook.
+WINO_OPERANDS = 'bf16x3'
+_N_SPLIT = {'fp32': 0, 'bf16x3': 3, 'bf16': 1}
+
+
+def _wino_records(conv_w, k_per_group, n_split=0):
+    """(forward records, backward-data records) of a weight for one workgroup width and operand form; packed on first use.  The
+    records hang on the weight tensor itself (like conv._nf_records of the 1x1 convolutions), so they die with it and can never be taken
     for another weight's; they are re-packed when the weight's storage, version or device changed."""
     key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
     store = getattr(conv_w, '_nf_wino', None)
     if store is None:
         store = conv_w._nf_wino = {}
-    cache = store.get(k_per_group)
+    cache = store.get((k_per_group, n_split))
     if cache is None or cache[0] != key:
-        cache = (key, ops.wino_pack(conv_w, False, conv_w.device, k_per_group), ops.wino_pack(conv_w, True, conv_w.device, k_per_group))
-        store[k_per_group] = cache
+        cache = (key, ops.wino_pack(conv_w, False, conv_w.device, k_per_group, n_split), ops.wino_pack(conv_w, True, conv_w.device, k_per_group, n_split))
+        store[(k_per_group, n_split)] = cache
     return cache[1], cache[2]
 
 
@@ -252,14 +265,17 @@ def _wino_ring_records(conv_w):
     return cache[1]
 
 
-def _conv3x3(tape, inp, w, sink):
-    """3x3 stride-1 convolution on a pre-padded activation (padding 0) and its backward-data pass"""
+def _conv3x3(tape, inp, w, sink, operands=None):
+    """3x3 stride-1 convolution on a pre-padded activation (padding 0) and its backward-data pass; operands: 'fp32' / 'bf16x3' / 'bf16'
+    (None = WINO_OPERANDS)"""
     c_out, c_in = w.shape[0], w.shape[1]
     N, Hi, Wi = inp.shape[0], inp.shape[2], inp.shape[3]
-    fwd = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out))[0], inp, c_out, 0, k_per_group=ops.wino_group(c_out))}
+    ns = _N_SPLIT[operands or WINO_OPERANDS]
+    fwd = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out), ns)[0], inp, c_out, 0, k_per_group=ops.wino_group(c_out),
+                                            n_split=ns)}
     if c_out > 64:                      # narrower workgroups only matter when they add workgroups to a thin grid
-        fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32)[0], inp, c_out, 0, k_per_group=32)
-    rule = 'wino32' if _wino_width(c_out, N, Hi - 2, Wi - 2) == 32 and c_out > 64 else 'wino'
+        fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32, ns)[0], inp, c_out, 0, k_per_group=32, n_split=ns)
+    rule = 'wino32' if _wino_width(c_out, N, Hi - 2, Wi - 2, ns) == 32 and c_out > 64 else 'wino'
     out = _Slot(fwd[_pick(('f', c_in, c_out) + tuple(inp.shape), fwd, rule)]())
 
     def bwd():
@@ -270,15 +286,15 @@ def _conv3x3(tape, inp, w, sink):
         plan = ops.wino_bwd_split_plan(g_out.shape[2], g_out.shape[3]) if g_out.shape[1] <= ops.WINO_RING_MAX_CHANNELS else None
 
         def bwd_data(kpg):
-            rec = _wino_records(w, kpg)[1]
+            rec = _wino_records(w, kpg, ns)[1]
             if plan is None:
-                return ops.conv3x3_wino(rec, g_out, c_in, 2, k_per_group=kpg)
-            return ops.conv3x3_wino_bwd_split(rec, _wino_ring_records(w), g_out, c_in, plan, k_per_group=kpg)
+                return ops.conv3x3_wino(rec, g_out, c_in, 2, k_per_group=kpg, n_split=ns)
+            return ops.conv3x3_wino_bwd_split(rec, _wino_ring_records(w), g_out, c_in, plan, k_per_group=kpg, n_split=ns)
         cand = {'wino': lambda: bwd_data(ops.wino_group(c_in))}
         if c_in > 64:
             cand['wino32'] = lambda: bwd_data(32)
         ho, wo = (g_out.shape[2] + 2, g_out.shape[3] + 2) if plan is None else (plan[0], plan[1])
-        rule_b = 'wino32' if _wino_width(c_in, N, ho, wo) == 32 and c_in > 64 else 'wino'
+        rule_b = 'wino32' if _wino_width(c_in, N, ho, wo, ns) == 32 and c_in > 64 else 'wino'
         sink(cand[_pick(('b', c_in, c_out) + tuple(inp.shape), cand, rule_b)]())
         out.g = None
     tape.append(bwd)
@@ -311,9 +327,9 @@ def _conv_s2(tape, inp, w, sink):
     return out
 
 
-def _conv(tape, inp, w, stride, sink, bias=None):
+def _conv(tape, inp, w, stride, sink, bias=None, operands=None):
     if stride == 1 and bias is None and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 32 == 0:
-        return _conv3x3(tape, inp, w, sink)
+        return _conv3x3(tape, inp, w, sink, operands)
     if stride == 2 and bias is None and tuple(w.shape[2:]) in ((3, 3), (7, 7)) and (w.shape[2] == 3 or w.shape[1] <= 3):
         return _conv_s2(tape, inp, w, sink)
     out = _Slot(_aten.convolution(inp, w, bias, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1))
@@ -375,12 +391,12 @@ def _fuse(tape, xs, norm, res, act, pad):
     return a
 
 
-def _resblock(tape, blk, xin):
+def _resblock(tape, blk, xin, operands=None):
     """xin: _Act padded by 1.  conv3x3(s) -> IN -> ReLU -> conv3x3 -> IN -> (+ identity | 1x1 conv + IN) -> ReLU."""
     stride = blk.conv1.stride[0]
-    t1 = _conv(tape, xin.yp, blk.conv1.weight, stride, xin.add_p)
+    t1 = _conv(tape, xin.yp, blk.conv1.weight, stride, xin.add_p, operands=operands)
     a1 = _fuse(tape, t1, blk.bn1, None, ops.ACT_RELU, 1)
-    t2 = _conv(tape, a1.yp, blk.conv2.weight, 1, a1.add_p)
+    t2 = _conv(tape, a1.yp, blk.conv2.weight, 1, a1.add_p, operands=operands)
     if blk.downsample is not None:
         # 1x1 stride-s convolution == 1x1 stride-1 convolution of the subsampled activation: a quarter of the bytes to gather,
         # and the gradient comes back subsampled (the fused backward adds it at the even positions)
@@ -451,6 +467,7 @@ class _NoTape:
 def fused_forward(net, x, need_grad=True):
     """x [V,3,H,W] -> (out [V,64,Hf,Wf] NCHW, tape, input slot)."""
     tape = [] if need_grad else _NoTape()
+    operands = getattr(net, 'conv_precision', None)      # None = WINO_OPERANDS; 'bf16' = BASELINE config 5's opt-in
     # the input image is read in whatever layout it comes (the attack hands over a permuted view of the channels-last
     # src + delta) and leaves reflect-padded for the 7x7 stem; its gradient is written back in the same layout
     xin = _Slot(x)
@@ -466,15 +483,15 @@ def fused_forward(net, x, need_grad=True):
     feats = []
     for layer in (net.layer1, net.layer2, net.layer3):
         for blk in layer:
-            a = _resblock(tape, blk, a)
+            a = _resblock(tape, blk, a, operands)
         feats.append(a)
     x1, x2, x3 = feats
 
     def decoder_stage(src, up, iconv, enc):
         up_p = _upsample_pad(tape, src, 1)
-        t = _conv(tape, up_p.yp, up.conv.conv.weight, 1, up_p.add_p)
+        t = _conv(tape, up_p.yp, up.conv.conv.weight, 1, up_p.add_p, operands=operands)
         jp = _join_pad(tape, enc, t, up.conv.bn, 1)
-        t = _conv(tape, jp.yp, iconv.conv.weight, 1, jp.add_p)
+        t = _conv(tape, jp.yp, iconv.conv.weight, 1, jp.add_p, operands=operands)
         return _fuse(tape, t, iconv.bn, None, ops.ACT_ELU, 0)
 
     y = decoder_stage(x3, net.upconv3, net.iconv3, x2)

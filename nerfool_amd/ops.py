@@ -645,23 +645,39 @@ def conv_s2_bwd(records, dy, c_in, ks, Hi, Wi):
     return dx
 
 
-def wino_pack(weight, backward, device, k_per_group=None):
+def wino_pack(weight, backward, device, k_per_group=None, n_split=0):
     """weight [c_out, c_in, 3, 3] -> Winograd-domain MFMA records (backward: the backward-data convolution);
-    k_per_group: output channels per workgroup, 64 or 32 (default wino_group)"""
+    k_per_group: output channels per workgroup, 64 or 32 (default wino_group); n_split: 0 = fp32 matrix-core operands (nf_wino_pack),
+    3 / 1 = bf16 parts of the three-way split / plain bf16 operands (nf_wino_bf_pack)"""
     L = _lib.lib()
     w = weight.detach().to('cpu', torch.float32).contiguous()
     c_out, c_in = w.shape[0], w.shape[1]
     n_out = c_in if backward else c_out
     kg = wino_group(n_out) if k_per_group is None else int(k_per_group)
+    if n_split:
+        out = torch.empty(L.nf_wino_bf_pack_floats(n_out, c_out if backward else c_in, kg, int(n_split)), dtype=torch.float32)
+        _lib.check(L.nf_wino_bf_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), kg, int(n_split), out.data_ptr()), 'nf_wino_bf_pack')
+        return out.to(device)
     out = torch.empty(L.nf_wino_pack_floats(n_out, c_out if backward else c_in, kg), dtype=torch.float32)
     _lib.check(L.nf_wino_pack(w.data_ptr(), c_out, c_in, int(bool(backward)), kg, out.data_ptr()), 'nf_wino_pack')
     return out.to(device)
 
 
-def conv3x3_wino(records, x, c_out, pad, tile_blocks=0, k_per_group=None):
+def _wino_launch(records, kpg, n_split, x, xs, Hi, Wi, pad, y_ptr, ys, Ho, Wo, N, c_in, c_out):
+    """one Winograd launch on raw strides (the entry point by operand form)"""
+    L = _lib.lib()
+    if n_split:
+        _launch(L.nf_conv3x3_wino_bf, 'nf_conv3x3_wino_bf', x, _ptr(records), int(kpg), int(n_split), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi,
+                int(pad), y_ptr, ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out)
+    else:
+        _launch(L.nf_conv3x3_wino, 'nf_conv3x3_wino', x, _ptr(records), int(kpg), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), y_ptr,
+                ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out, 0)
+
+
+def conv3x3_wino(records, x, c_out, pad, tile_blocks=0, k_per_group=None, n_split=0):
     """3x3 stride-1 convolution of x [N, c_in, Hi, Wi] (unit column stride) with zero padding `pad` (0: the network's
     forward on pre-padded activations, 2: its backward-data on the gradient) -> [N, c_out, Hi - 2 + 2 pad, Wi - 2 + 2 pad].
-    k_per_group must be the value the records were packed with."""
+    k_per_group / n_split must be the values the records were packed with."""
     _f32(x, 'x')
     if x.stride(3) != 1:
         x = x.contiguous()
@@ -669,9 +685,9 @@ def conv3x3_wino(records, x, c_out, pad, tile_blocks=0, k_per_group=None):
     Ho, Wo = Hi - 2 + 2 * pad, Wi - 2 + 2 * pad
     y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
     xs, ys = x.stride(), y.stride()
-    with prof.launch('nf_conv3x3_wino', x, n_img=N, c_in=c_in, c_out=c_out, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo):
-        _launch(_lib.lib().nf_conv3x3_wino, 'nf_conv3x3_wino', x, _ptr(records), wino_group(c_out) if k_per_group is None else int(k_per_group), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, int(pad), _ptr(y),
-                                              ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out, int(tile_blocks))
+    with prof.launch('nf_conv3x3_wino', x, n_img=N, c_in=c_in, c_out=c_out, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, n_split=int(n_split)):
+        _wino_launch(records, wino_group(c_out) if k_per_group is None else k_per_group, n_split, x, xs, Hi, Wi, pad, _ptr(y), ys, Ho, Wo,
+                     N, c_in, c_out)
     return y
 
 
@@ -703,7 +719,7 @@ def wino_bwd_split_plan(H, W):
     return rows, cols, 1 | (0 if rows == H + 1 else 2) | 4 | (0 if cols == W + 1 else 8)
 
 
-def conv3x3_wino_bwd_split(records, ring_records, dy, c_dx, plan, k_per_group=None):
+def conv3x3_wino_bwd_split(records, ring_records, dy, c_dx, plan, k_per_group=None, n_split=0):
     """backward-data of a 3x3 stride-1 convolution, dy [N, c_dy, H, W] -> d(padded input) [N, c_dx, H + 2, W + 2], as the Winograd
     kernel on the interior-aligned region + the 1-D ring kernel (plan = wino_bwd_split_plan(H, W)); every element of the result
     is written exactly once."""
@@ -715,9 +731,9 @@ def conv3x3_wino_bwd_split(records, ring_records, dy, c_dx, plan, k_per_group=No
     g = torch.empty(N, c_dx, H + 2, W + 2, dtype=torch.float32, device=dy.device)
     xs, gs = dy.stride(), g.stride()
     L = _lib.lib()
-    with prof.launch('nf_conv3x3_wino', dy, n_img=N, c_in=c_dy, c_out=c_dx, Hi=H, Wi=W, Ho=rows, Wo=cols):
-        _launch(L.nf_conv3x3_wino, 'nf_conv3x3_wino', dy, _ptr(records), wino_group(c_dx) if k_per_group is None else int(k_per_group), _ptr(dy), xs[0], xs[1], xs[2],
-                                     H, W, 1, g.data_ptr() + 4 * (gs[2] + 1), gs[0], gs[1], gs[2], rows, cols, N, c_dy, c_dx, 0)
+    with prof.launch('nf_conv3x3_wino', dy, n_img=N, c_in=c_dy, c_out=c_dx, Hi=H, Wi=W, Ho=rows, Wo=cols, n_split=int(n_split)):
+        _wino_launch(records, wino_group(c_dx) if k_per_group is None else k_per_group, n_split, dy, xs, H, W, 1,
+                     g.data_ptr() + 4 * (gs[2] + 1), gs, rows, cols, N, c_dy, c_dx)
     with prof.launch('nf_conv3x3_bwd_ring', dy, n=N * c_dx * (2 * (W + 2) + 2 * H)):
         _launch(L.nf_conv3x3_bwd_ring, 'nf_conv3x3_bwd_ring', dy, _ptr(ring_records), _ptr(dy), xs[0], xs[1], xs[2], H, W, _ptr(g), gs[0], gs[1], gs[2], N, c_dy, c_dx,
                                          int(kinds))

@@ -819,11 +819,16 @@ def check_fused_cnn_glue(dev):
         ref = F.conv2d(xin, wgt)
         gy = torch.randn(ref.shape, generator=gen)
         gref = F.conv_transpose2d(gy, wgt)
+        ref64, gref64 = F.conv2d(xin.double(), wgt.double()), F.conv_transpose2d(gy.double(), wgt.double())
         for kpg in ((64, 32) if (dev != 'cpu' or co > 64) else (64,)):        # both workgroup widths (on the CPU stand-in where they differ)
-            got = ops.conv3x3_wino(ops.wino_pack(wgt, False, dev, kpg), xin.to(dev), co, 0, k_per_group=kpg)
-            assert_close(got, ref, 1e-4, 1e-4 * float(ref.abs().max()), 'Winograd 3x3 forward (%d per group)' % kpg)
-            ggot = ops.conv3x3_wino(ops.wino_pack(wgt, True, dev, kpg), gy.to(dev), ci, 2, k_per_group=kpg)
-            assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'Winograd 3x3 backward-data (%d per group)' % kpg)
+            # operand forms: fp32 matrix-core operands, the three-way bf16 split (fp32-grade: the same bar), plain bf16 (8 bits)
+            for ns, bar in ((0, 2e-6), (3, 4e-6), (1, 2e-2)):
+                got = ops.conv3x3_wino(ops.wino_pack(wgt, False, dev, kpg, ns), xin.to(dev), co, 0, k_per_group=kpg, n_split=ns)
+                ggot = ops.conv3x3_wino(ops.wino_pack(wgt, True, dev, kpg, ns), gy.to(dev), ci, 2, k_per_group=kpg, n_split=ns)
+                ef = float((got.cpu().double() - ref64).abs().max() / ref64.abs().max())
+                eb = float((ggot.cpu().double() - gref64).abs().max() / gref64.abs().max())
+                assert ef <= bar and eb <= bar, 'Winograd 3x3 (%d per group, n_split %d): forward %.2e backward-data %.2e of the largest ' \
+                    'output vs float64 (bar %.0e)' % (kpg, ns, ef, eb, bar)
     # backward-data split into the Winograd kernel on the interior-aligned region + the 1-D border ring kernel: every combination
     # of ring segments (forced plans) and the plan the executor would take, ragged channel counts included
     for (N, ci, co, H, W) in (((2, 32, 64, 8, 15), (2, 16, 48, 3, 70)) if dev == 'cpu' else
@@ -835,9 +840,12 @@ def check_fused_cnn_glue(dev):
         plans = {(H, W, 1 | 2 | 4 | 8), (H + 1, W, 1 | 4 | 8), (H, W + 1, 1 | 2 | 4), (H + 1, W + 1, 1 | 4)}
         if ops.wino_bwd_split_plan(H, W) is not None:
             plans.add(ops.wino_bwd_split_plan(H, W))
+        rb3 = ops.wino_pack(wgt, True, dev, None, 3)
         for plan in sorted(plans):
             ggot = ops.conv3x3_wino_bwd_split(rb, ring, gy.to(dev), ci, plan)
             assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'split backward-data %s of %dx%d' % (plan, H, W))
+            ggot = ops.conv3x3_wino_bwd_split(rb3, ring, gy.to(dev), ci, plan, n_split=3)
+            assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'split backward-data %s of %dx%d, bf16x3 operands' % (plan, H, W))
     assert ops.wino_bwd_split_plan(48, 63) == (48, 64, 1 | 2 | 4) and ops.wino_bwd_split_plan(189, 252) is None
     assert ops.wino_bwd_split_plan(32, 32) == (32, 32, 15)
     # 1x1 convolutions as MFMA GEMMs over the pixels: subsampled / strided input, bias, channels-last output, backward-data

@@ -95,19 +95,21 @@ def test_winograd_full_size_layers_repeated():
         ref = F.conv2d(x_c[1:2].double(), wgt_c.double())
         gref = F.conv_transpose2d(gy_c[1:2].double(), wgt_c.double())
         wgt, x, gy = wgt_c.cuda(), x_c.cuda(), gy_c.cuda()
-        for kg in (64, 32):              # both workgroup widths the per-layer timing chooses from
-            rf, rb = ops.wino_pack(wgt, False, 'cuda', kg), ops.wino_pack(wgt, True, 'cuda', kg)
+        # both workgroup widths the shape rule chooses from, fp32 operands (csrc/nf_wino.hip) and the three-way bf16 split
+        # (csrc/nf_wino_bf.hip: the default of the executor; the same float64 bar)
+        for kg, ns in ((64, 0), (32, 0), (64, 3), (32, 3)):
+            rf, rb = ops.wino_pack(wgt, False, 'cuda', kg, ns), ops.wino_pack(wgt, True, 'cuda', kg, ns)
             first = None
             for _ in range(6):
-                got = ops.conv3x3_wino(rf, x, co, 0, k_per_group=kg)
-                ggot = ops.conv3x3_wino(rb, gy, ci, 2, k_per_group=kg)
-                assert float((got[1:2].cpu().double() - ref).abs().max()) <= 5e-6 * float(ref.abs().max()), (ci, co, H, W, kg)
-                assert float((ggot[1:2].cpu().double() - gref).abs().max()) <= 5e-6 * float(gref.abs().max()), (ci, co, H, W, kg)
+                got = ops.conv3x3_wino(rf, x, co, 0, k_per_group=kg, n_split=ns)
+                ggot = ops.conv3x3_wino(rb, gy, ci, 2, k_per_group=kg, n_split=ns)
+                assert float((got[1:2].cpu().double() - ref).abs().max()) <= 5e-6 * float(ref.abs().max()), (ci, co, H, W, kg, ns)
+                assert float((ggot[1:2].cpu().double() - gref).abs().max()) <= 5e-6 * float(gref.abs().max()), (ci, co, H, W, kg, ns)
                 if first is None:
                     first = (got.clone(), ggot.clone())
                 else:            # every launch, every image: bit for bit the first launch (no atomics, no race)
-                    assert torch.equal(got, first[0]) and torch.equal(ggot, first[1]), (ci, co, H, W, kg)
-            alone = ops.conv3x3_wino(rf, x[3:4].contiguous(), co, 0, k_per_group=kg)
+                    assert torch.equal(got, first[0]) and torch.equal(ggot, first[1]), (ci, co, H, W, kg, ns)
+            alone = ops.conv3x3_wino(rf, x[3:4].contiguous(), co, 0, k_per_group=kg, n_split=ns)
             assert torch.equal(alone, first[0][3:4]), 'an image must not depend on its batch neighbours'
 
 

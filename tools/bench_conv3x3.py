@@ -50,6 +50,21 @@ def main():
         t_f32, y3 = timed(lambda: ops.conv3x3_wino(rf32, x, co, 0, k_per_group=32), iters)
         t_b32, dx3 = timed(lambda: ops.conv3x3_wino(rb32, g, ci, 2, k_per_group=32), iters)
         t1 = (t_wf, t_f32, t_wb, t_b32, float((y - y3).abs().max() / y.abs().max()), float((dx - dx3).abs().max() / dx.abs().max()))
+        # bf16-split operand forms (csrc/nf_wino_bf.hip): the three-way split (fp32-grade) and plain bf16
+        for ns, tag in ((3, 'bf16x3'), (1, 'bf16')):
+            r_f, r_b = ops.wino_pack(w, False, dev, None, ns), ops.wino_pack(w, True, dev, None, ns)
+            t_f, y4 = timed(lambda: ops.conv3x3_wino(r_f, x, co, 0, n_split=ns), iters)
+            t_b, dx4 = timed(lambda: ops.conv3x3_wino(r_b, g, ci, 2, n_split=ns), iters)
+            msg = '      %-6s operands: fwd %.1f us, bwd %.1f us (rel err vs MIOpen %.1e %.1e)' % (
+                tag, t_f, t_b, float((y - y4).abs().max() / y.abs().max()), float((dx - dx4).abs().max() / dx.abs().max()))
+            if co > 64:
+                r_f32, r_b32 = ops.wino_pack(w, False, dev, 32, ns), ops.wino_pack(w, True, dev, 32, ns)
+                t_f2, _ = timed(lambda: ops.conv3x3_wino(r_f32, x, co, 0, k_per_group=32, n_split=ns), iters)
+                msg += ' | 32 per workgroup: fwd %.1f us' % t_f2
+            if ci > 64:
+                t_b2, _ = timed(lambda: ops.conv3x3_wino(r_b32 if co > 64 else ops.wino_pack(w, True, dev, 32, ns), g, ci, 2, k_per_group=32, n_split=ns), iters)
+                msg += ' bwd %.1f us' % t_b2
+            print(msg)
         fl = 2.0 * 4 * H * W * ci * co * 9
         err_f = float((y - y2).abs().max() / y.abs().max())
         err_b = float((dx - dx2).abs().max() / dx.abs().max())
