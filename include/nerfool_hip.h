@@ -116,11 +116,13 @@ int nf_ibrnet_bwd(const float* blob, const float* pos_enc, const float* rgb_feat
 int64_t nf_ibrnet_mfma_blob_floats(void);
 int nf_ibrnet_pack_mfma(const float* natural_blob_host, float* mfma_blob_host);
 int nf_ibrnet_mfma_supported(int n_samples, int n_views);
-/* TEST / DIAGNOSTIC hook.  The per-(sample, view) part of the matrix-core kernels exists in two forms: sample-on-the-lane (a wave
+/* TEST / DIAGNOSTIC hook.  The per-(sample, view) part of the matrix-core FORWARD exists in two forms: sample-on-the-lane (a wave
  * owns 32 samples and walks their views in time; the view-invariant part of base_fc.0 -- ibrnet/mlp_network.py:245-247 -- is
- * multiplied once per sample; fp32 operands, 2 <= V <= 10) and the row form (a wave owns 32 (sample, view) rows; any V <= 32, bf16
- * operands).  form 0 = the faster one that exists for the shape (default), 1 = the row form always.  Returns the previous
- * setting.  Process-wide. */
+ * multiplied once per sample; 2 <= V <= 10) and the row form (a wave owns 32 (sample, view) rows; any V <= 32, also the bf16-operand
+ * precision of config 5 and every backward).  The sample-on-the-lane kernels multiply on the bf16 matrix cores with every fp32
+ * operand split into three bf16 parts (six cross terms of order <= 2^-16: error at fp32 rounding level) or, for comparison, on
+ * the fp32 matrix cores.  form 0 = sample-on-the-lane with the split operands where it exists (default), 1 = the row form always,
+ * 2 = sample-on-the-lane with fp32 operands (V <= 4).  Returns the previous setting.  Process-wide. */
 int nf_ibrnet_rows_form(int form);
 /* 1 when the sample-on-the-lane form runs for this view count / operand precision under the current setting */
 int nf_ibrnet_sol_selected(int n_views, int bf16_operands);

@@ -107,7 +107,15 @@ enum {
     RYT_OG0 = 0, RYT_FC = 8, RYT_QKV = 16, RYT_GEO1 = 40, RYT_GEO0 = 56, RYT_RECORDS = 120,
     RYS_GEO0W = RYT_BASE + RYT_RECORDS * 64,     // [2 tiles][h][16] column 64 (the wmean input) of geometry_fc.0
     RY_FLOATS = RYS_GEO0W + 64,
-    NF_MFMA_BLOB_FLOATS = RY_BASE + RY_FLOATS
+    // ---- "bf16x3" image of the forward row network (sample-on-the-lane kernels): every fp32 record value as three bf16 parts
+    //      (hi + mid + lo, 8 significant bits each: the six cross products of order <= 2^-16 reproduce the fp32 product to fp32
+    //      rounding level on the bf16 matrix pipe, which runs at 16x the fp32 matrix rate and beside the vector pipe).
+    //      [part 3][group 33][lane 64][8 bf16], then a copy of the VALU tables [MS_BASE, MS_END)
+    X3_BASE = RY_BASE + RY_FLOATS,
+    X3_PART = 33 * 256,              // floats per part: BF_FWD_GROUPS groups of 256
+    X3_TAB = 3 * X3_PART,            // the tables, relative to X3_BASE
+    X3_FLOATS = X3_TAB + (MS_END - MS_BASE),
+    NF_MFMA_BLOB_FLOATS = X3_BASE + X3_FLOATS
 };
 enum { BT_DIR0, BT_DIR1, BT_BASE0A, BT_BASE0B, BT_BASE1, BT_VIS0, BT_VIS1, BT_VISB0, BT_RGB0 };
 
@@ -169,6 +177,7 @@ enum {
     NF_BF_BLOB_FLOATS = MS_END + (BF_BWD_GROUPS - BF_BWD_IN_GAP) * BF_GROUP_FLOATS          // 64 KB: forward + backward
 };
 static_assert(bf_grp_fwd(MR_RGB0 + 16) == BF_FWD_GROUPS - 1, "forward group count");
+static_assert(X3_PART == BF_FWD_GROUPS * BF_GROUP_FLOATS, "bf16x3 image: one part = the forward groups");
 static_assert(bf_grp_bwd(MT_BASE0 + 120) == BF_BWD_GROUPS - 1, "backward group count");
 static_assert(BF_BWD_IN_GAP >= 1 && BF_BWD_IN_GAP < BF_BWD_GROUPS && MS_END % 4 == 0, "bf16 image layout");
 static_assert(MS_BIAS % 4 == 0 && MS_VIS1L % 4 == 0 && MS_VISB1 % 4 == 0 && RYF_FLOATS % 4 == 0 && RY_FLOATS % 4 == 0,
@@ -209,6 +218,13 @@ static void emit_bias_tile(float* dst, const float* b, int N, int base) {
             int n = base + nf_nidx(r, h);
             dst[h * 16 + r] = (n >= 0 && n - base < 32 && n < N) ? b[n] : 0.f;
         }
+}
+
+static uint16_t bf16_rne(float f) {       // round to nearest even, NaN kept a NaN (the blob holds finite weights)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
 extern "C" int64_t nf_ibrnet_mfma_blob_floats(void) { return NF_MFMA_BLOB_FLOATS; }
@@ -353,17 +369,35 @@ extern "C" int nf_ibrnet_pack_mfma(const float* nat, float* out) {
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r) ry[RYS_GEO0W + t * 32 + h * 16 + r] = W[(size_t)(t * 32 + nf_nidx(r, h)) * 65 + 64];
     }
+    // ================= bf16x3 image of the forward records =================
+    {
+        float* x3 = out + X3_BASE;
+        int g0 = 0;
+        for (int i = 0; i < BF_FWD_SEGS; ++i) {
+            const BfSeg sg = bf_fwd_seg(i);
+            for (int g = 0; g < (sg.n + 7) / 8; ++g)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int st = 8 * g + j;
+                        float rem = st < sg.n ? out[(size_t)(sg.start + st) * 64 + lane] : 0.f;
+                        for (int p = 0; p < 3; ++p) {
+                            const uint16_t b = bf16_rne(rem);
+                            reinterpret_cast<uint16_t*>(x3 + (size_t)p * X3_PART + (size_t)(g0 + g) * 256)[lane * 8 + j] = b;
+                            const uint32_t u = (uint32_t)b << 16;
+                            float up;
+                            memcpy(&up, &u, 4);
+                            rem -= up;            // exact
+                        }
+                    }
+            g0 += (sg.n + 7) / 8;
+        }
+        if (g0 != BF_FWD_GROUPS) return 5;
+        for (int i = MS_BASE; i < MS_END; ++i) x3[X3_TAB + (i - MS_BASE)] = out[i];
+    }
     return 0;
 }
 
 extern "C" int64_t nf_ibrnet_mfma_bf16_blob_floats(void) { return NF_BF_BLOB_FLOATS; }
-
-static uint16_t bf16_rne(float f) {       // round to nearest even, NaN kept a NaN (the blob holds finite weights)
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
 
 /* mfma_blob: output of nf_ibrnet_pack_mfma (host memory); out: nf_ibrnet_mfma_bf16_blob_floats() floats (host memory) */
 extern "C" int nf_ibrnet_pack_mfma_bf16(const float* mfma_blob, float* out) {
@@ -496,6 +530,80 @@ __device__ __forceinline__ f32x16 gemm_small(const float* lds, int rec, int lane
         for (int j = 0; j < N; ++j) acc = NF_MFMA(lds[(rec + j) * 64 + lane], v[j], acc);
     }
     return acc;
+}
+
+// ---- operand forms of the sample-on-the-lane kernels: OP 0 = fp32 records on v_mfma_f32_32x32x2_f32, OP 1 = plain bf16 groups,
+//      OP 3 = "bf16x3": weights AND activations as three bf16 parts, the six cross products of order <= 2^-16 on
+//      v_mfma_f32_32x32x16_bf16 -- the dropped terms are <= 2^-24 of the product (fp32 rounding level), the matrix pipe is busy
+//      6 / 16 of the fp32 form's time, and its instructions run BESIDE the vector instructions (the fp32 matrix instructions'
+//      time adds to theirs: profiles/r03_probe_mfma_valu_overlap.txt, tools/experimental/probe_bf3.hip).
+//      For OP 3 the kernel's `lds` pointer is the TABLE base (lds[MS_...] as in the other images); the parts sit in front of it.
+#define X3_LDS_SHIFT (X3_TAB - MS_BASE)        // lds (table base) - shared-memory base, in floats
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two fp32 values -> their bf16 roundings (one packed register) and, in place, the exact remainders
+__device__ __forceinline__ unsigned x3_split_pair(float& x0, float& x1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 p = bf16x2{(__bf16)x0, (__bf16)x1};          // v_cvt_pk_bf16_f32, round to nearest even
+    const unsigned u = __builtin_bit_cast(unsigned, p);
+    x0 -= __builtin_bit_cast(float, u << 16);
+    x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
+    return u;
+#else
+    const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
+    unsigned short s0, s1;
+    memcpy(&s0, &b0, 2);
+    memcpy(&s1, &b1, 2);
+    x0 -= (float)b0;
+    x1 -= (float)b1;
+    return (unsigned)s0 | ((unsigned)s1 << 16);
+#endif
+}
+// acc += W(group g) . (8 values), all six cross terms
+__device__ __forceinline__ f32x16 x3_group(const float* lds, int g, int lane, float (&v)[8], f32x16 acc) {
+    u32x4 b[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p][q] = x3_split_pair(v[2 * q], v[2 * q + 1]);
+    const float* rec = lds - X3_LDS_SHIFT + g * BF_GROUP_FLOATS + lane * 4;
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(rec), a1 = *reinterpret_cast<const u32x4*>(rec + X3_PART),
+                a2 = *reinterpret_cast<const u32x4*>(rec + 2 * X3_PART);
+#define X3_PROD(a, bb) acc = NF_MFMA_BF(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bb), acc)
+    X3_PROD(a0, b[0]);
+    X3_PROD(a0, b[1]);
+    X3_PROD(a1, b[0]);
+    X3_PROD(a0, b[2]);
+    X3_PROD(a2, b[0]);
+    X3_PROD(a1, b[1]);
+#undef X3_PROD
+    return acc;
+}
+template <int OP, int NSTEPS>
+__device__ __forceinline__ f32x16 sgemm_frag(const float* lds, int rec, int lane, const f32x16& x, f32x16 acc) {
+    if constexpr (OP == 3) {
+        static_assert(NSTEPS % 8 == 0, "whole groups");
+        const int g0 = bf_grp_fwd(rec);
+#pragma unroll
+        for (int g = 0; g < NSTEPS / 8; ++g) {
+            float v[8] = {x[8 * g], x[8 * g + 1], x[8 * g + 2], x[8 * g + 3], x[8 * g + 4], x[8 * g + 5], x[8 * g + 6], x[8 * g + 7]};
+            acc = x3_group(lds, g0 + g, lane, v, acc);
+        }
+        return acc;
+    } else {
+        return gemm_frag<OP == 1, NSTEPS>(lds, rec, lane, x, acc);
+    }
+}
+template <int OP, int N>
+__device__ __forceinline__ f32x16 sgemm_small(const float* lds, int rec, int lane, const float (&v)[N], f32x16 acc) {
+    if constexpr (OP == 3) {
+        float p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = j < N ? v[j] : 0.f;
+        return x3_group(lds, bf_grp_fwd(rec), lane, p, acc);
+    } else {
+        return gemm_small<OP == 1, N>(lds, rec, lane, v, acc);
+    }
 }
 
 // ... and over a fragment the scaling by log2(e) and the "- 1" are packed (v_pk_mul_f32 / v_pk_add_f32: two elements per
@@ -859,17 +967,17 @@ __host__ __device__ constexpr int sol_fwd_waves(int occ) { return 4 * occ; }
 #define NF_SOL_MAX_V 10
 
 // direction MLP 4 -> 16 -> 35 and f = rgb_feat + dir_feat of one (sample, view)   (mlp_network.py:231-233)
-template <bool BF>
+template <int OP>
 __device__ __forceinline__ void sol_direction(const float* lds, int lane, int h, const RowIn& in, f32x16& F, float (&fc)[3]) {
     f32x16 d1 = bias_tile(lds, BT_DIR0, h);
     {
         const float v2[2] = {h ? in.rd[1] : in.rd[0], h ? in.rd[3] : in.rd[2]};
-        d1 = gemm_small<BF, 2>(lds, MR_DIR0, lane, v2, d1);
+        d1 = sgemm_small<OP, 2>(lds, MR_DIR0, lane, v2, d1);
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) d1[r] = mf_elu(d1[r]);
     {
-        const f32x16 df = elu16(gemm_frag<BF, 8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h)));
+        const f32x16 df = elu16(sgemm_frag<OP, 8>(lds, MR_DIR1, lane, d1, bias_tile(lds, BT_DIR1, h)));
 #pragma unroll
         for (int r = 0; r < 16; ++r) F[r] = in.feat[r] + df[r];
     }
@@ -887,26 +995,26 @@ __device__ __forceinline__ void sol_direction(const float* lds, int lane, int h,
 }
 
 // the view-invariant part of base_fc.0, output tile NT: bias + W[:, mean] . mean + W[:, var] . var   (once per sample)
-template <bool BF, int NT>
+template <int OP, int NT>
 __device__ __forceinline__ f32x16 sol_base0_global(const float* lds, int lane, int h, const f32x16& MEAN, const float (&mc)[3],
                                                    const f32x16& VAR, const float (&vc)[3]) {
     constexpr int rec = MR_BASE0 + NT * 54;
     f32x16 acc = bias_tile(lds, BT_BASE0A + NT, h);
-    acc = gemm_frag<BF, 16>(lds, rec, lane, MEAN, acc);
+    acc = sgemm_frag<OP, 16>(lds, rec, lane, MEAN, acc);
     const float m2[2] = {h ? mc[1] : mc[0], h ? 0.f : mc[2]};
-    acc = gemm_small<BF, 2>(lds, rec + 16, lane, m2, acc);
-    acc = gemm_frag<BF, 16>(lds, rec + 18, lane, VAR, acc);
+    acc = sgemm_small<OP, 2>(lds, rec + 16, lane, m2, acc);
+    acc = sgemm_frag<OP, 16>(lds, rec + 18, lane, VAR, acc);
     const float v2[2] = {h ? vc[1] : vc[0], h ? 0.f : vc[2]};
-    acc = gemm_small<BF, 2>(lds, rec + 34, lane, v2, acc);
+    acc = sgemm_small<OP, 2>(lds, rec + 34, lane, v2, acc);
     return acc;
 }
 // ... and the per-view part on top of it: G + W[:, f] . f_v
-template <bool BF, int NT>
+template <int OP, int NT>
 __device__ __forceinline__ f32x16 sol_base0_view(const float* lds, int lane, int h, const f32x16& G, const f32x16& F, const float (&fc)[3]) {
     constexpr int rec = MR_BASE0 + NT * 54;
-    f32x16 acc = gemm_frag<BF, 16>(lds, rec + 36, lane, F, G);
+    f32x16 acc = sgemm_frag<OP, 16>(lds, rec + 36, lane, F, G);
     const float f2[2] = {h ? fc[1] : fc[0], h ? 0.f : fc[2]};
-    return gemm_small<BF, 2>(lds, rec + 52, lane, f2, acc);
+    return sgemm_small<OP, 2>(lds, rec + 52, lane, f2, acc);
 }
 
 // everything of one (sample, view) behind base_fc.0 that does not look at the other views: base_fc.2, vis_fc, vis_fc2 and the
@@ -916,21 +1024,21 @@ struct SolViewActs {
     float r1[8], r2[8];
     float logit, sig1, vis1, sig2, vis2, y;
 };
-template <bool BF>
+template <int OP>
 __device__ __forceinline__ void sol_view_chain(const float* lds, int lane, int h, const f32x16& H1a, const f32x16& H1b, float w, float mk,
                                                const float (&rd)[4], SolViewActs& a) {
     {
         f32x16 acc = bias_tile(lds, BT_BASE1, h);
-        acc = gemm_frag<BF, 16>(lds, MR_BASE1, lane, H1a, acc);
-        acc = gemm_frag<BF, 16>(lds, MR_BASE1 + 16, lane, H1b, acc);
+        acc = sgemm_frag<OP, 16>(lds, MR_BASE1, lane, H1a, acc);
+        acc = sgemm_frag<OP, 16>(lds, MR_BASE1 + 16, lane, H1b, acc);
         a.H = elu16(acc);
     }
     {
         f32x16 t;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = a.H[r] * w;
-        a.V1 = elu16(gemm_frag<BF, 16>(lds, MR_VIS0, lane, t, bias_tile(lds, BT_VIS0, h)));
-        a.XV = elu16(gemm_frag<BF, 16>(lds, MR_VIS1, lane, a.V1, bias_tile(lds, BT_VIS1, h)));
+        a.V1 = elu16(sgemm_frag<OP, 16>(lds, MR_VIS0, lane, t, bias_tile(lds, BT_VIS0, h)));
+        a.XV = elu16(sgemm_frag<OP, 16>(lds, MR_VIS1, lane, a.V1, bias_tile(lds, BT_VIS1, h)));
         a.logit = mf_elu(dot_frag16(lds + MS_VIS1L + h * 16, a.V1) + lds[MS_VIS1L + 32]);
         a.sig1 = mf_sigmoid(a.logit);
         a.vis1 = a.sig1 * mk;
@@ -939,16 +1047,16 @@ __device__ __forceinline__ void sol_view_chain(const float* lds, int lane, int h
             a.X2[r] = a.H[r] + a.XV[r];
             t[r] = a.X2[r] * a.vis1;
         }
-        a.U = elu16(gemm_frag<BF, 16>(lds, MR_VISB0, lane, t, bias_tile(lds, BT_VISB0, h)));
+        a.U = elu16(sgemm_frag<OP, 16>(lds, MR_VISB0, lane, t, bias_tile(lds, BT_VISB0, h)));
         const float z2 = dot_frag16(lds + MS_VISB1 + h * 16, a.U) + lds[MS_VISB1 + 32];
         a.sig2 = mf_sigmoid(z2);
         a.vis2 = a.sig2 * mk;
     }
     // colour head: rgb_fc 37 -> 16 -> 8 -> 1
     {
-        f32x16 acc = gemm_frag<BF, 16>(lds, MR_RGB0, lane, a.X2, bias_tile(lds, BT_RGB0, h));
+        f32x16 acc = sgemm_frag<OP, 16>(lds, MR_RGB0, lane, a.X2, bias_tile(lds, BT_RGB0, h));
         const float v3[3] = {h ? rd[0] : a.vis2, h ? rd[2] : rd[1], h ? 0.f : rd[3]};
-        acc = gemm_small<BF, 3>(lds, MR_RGB0 + 16, lane, v3, acc);
+        acc = sgemm_small<OP, 3>(lds, MR_RGB0 + 16, lane, v3, acc);
 #pragma unroll
         for (int r = 0; r < 8; ++r) a.r1[r] = mf_elu(acc[r]);
         float y = lds[MS_RGB2 + 8];
@@ -1032,12 +1140,18 @@ __device__ __forceinline__ void sol_pool_first(const float* lds, int aa, SolView
     }
 }
 
-template <int V, bool BF, bool GATH, int OCC>
+template <int V, int OP, bool GATH, int OCC>
 __global__ void __launch_bounds__(64 * sol_fwd_waves(OCC), OCC) k_ibr_sol_fwd(const float* __restrict__ wblob, const float* __restrict__ rgb_feat,
                                                          const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                          int64_t n_samples, int aa, float* __restrict__ smp, RowGather gather) {
-    HIP_DYNAMIC_SHARED(float, lds)
-    for (int i = threadIdx.x; i < NF_MFMA_FWD_FLOATS; i += blockDim.x) lds[i] = wblob[i];      // BF: wblob is the bf16 image
+    HIP_DYNAMIC_SHARED(float, smem_base)
+    // OP 0 / 1: the fp32 / bf16 forward image (wblob points at it); OP 3: the bf16x3 section of the matrix-core blob, `lds` = its tables
+    constexpr int IMG = OP == 3 ? (int)X3_FLOATS : (int)NF_MFMA_FWD_FLOATS;
+    {
+        const float* src = wblob + (OP == 3 ? (int)X3_BASE : 0);
+        for (int i = threadIdx.x; i < IMG; i += blockDim.x) smem_base[i] = src[i];
+    }
+    const float* lds = smem_base + (OP == 3 ? (int)X3_LDS_SHIFT : 0);
     __syncthreads();
     constexpr int NWV = sol_fwd_waves(OCC);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1061,7 +1175,7 @@ __global__ void __launch_bounds__(64 * sol_fwd_waves(OCC), OCC) k_ibr_sol_fwd(co
             const int64_t row = sample * V + v;
             if (GATH) load_row_gather(gather, V, row, sample, v, h, live, in);
             else load_row<1>(rgb_feat, ray_diff, mask, row, h, in);
-            sol_direction<BF>(lds, lane, h, in, vw[v].F, vw[v].fc);
+            sol_direction<OP>(lds, lane, h, in, vw[v].F, vw[v].fc);
             if constexpr (GATH) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -1081,8 +1195,8 @@ __global__ void __launch_bounds__(64 * sol_fwd_waves(OCC), OCC) k_ibr_sol_fwd(co
             f32x16 MEAN, VAR;
             float mc[3], vc[3];
             sol_pool_first<V, GATH>(lds, aa, vw, MEAN, VAR, mc, vc);
-            G0 = sol_base0_global<BF, 0>(lds, lane, h, MEAN, mc, VAR, vc);
-            G1 = sol_base0_global<BF, 1>(lds, lane, h, MEAN, mc, VAR, vc);
+            G0 = sol_base0_global<OP, 0>(lds, lane, h, MEAN, mc, VAR, vc);
+            G1 = sol_base0_global<OP, 1>(lds, lane, h, MEAN, mc, VAR, vc);
         }
         // ---- per view: the rest of the row network; second-pooling sums around the pivot x2 of view 0
         f32x16 piv, S1, S2;
@@ -1097,8 +1211,8 @@ __global__ void __launch_bounds__(64 * sol_fwd_waves(OCC), OCC) k_ibr_sol_fwd(co
 #endif
             SolViewActs a;
             {
-                const f32x16 H1a = elu16(sol_base0_view<BF, 0>(lds, lane, h, G0, vw[v].F, vw[v].fc));
-                const f32x16 H1b = elu16(sol_base0_view<BF, 1>(lds, lane, h, G1, vw[v].F, vw[v].fc));
+                const f32x16 H1a = elu16(sol_base0_view<OP, 0>(lds, lane, h, G0, vw[v].F, vw[v].fc));
+                const f32x16 H1b = elu16(sol_base0_view<OP, 1>(lds, lane, h, G1, vw[v].F, vw[v].fc));
                 float rd[4];
                 if constexpr (GATH) {
                     rd[0] = vw[v].rd[0]; rd[1] = vw[v].rd[1]; rd[2] = vw[v].rd[2];
@@ -1107,7 +1221,7 @@ __global__ void __launch_bounds__(64 * sol_fwd_waves(OCC), OCC) k_ibr_sol_fwd(co
                     rd[0] = p[0]; rd[1] = p[1]; rd[2] = p[2];
                 }
                 rd[3] = vw[v].rd3;
-                sol_view_chain<BF>(lds, lane, h, H1a, H1b, vw[v].w, vw[v].mk, rd, a);
+                sol_view_chain<OP>(lds, lane, h, H1a, H1b, vw[v].w, vw[v].mk, rd, a);
             }
             vis2[v] = a.vis2;
             y[v] = a.y;
@@ -2317,32 +2431,47 @@ static void launch_rows_fwd(const float* wblob, const float* bf_blob, const floa
 #undef NF_ROWS_FWD_GO
 }
 
-// ---- which form of kernel A runs: the sample-on-the-lane form where it is built (fp32 operands, 2 <= V <= NF_SOL_MAX_V), the row
-// form otherwise.  nf_ibrnet_rows_form(1) pins the row form (TEST / DIAGNOSTIC hook: the tests run both forms on the same inputs).
+// ---- which form of kernel A runs (forward): the sample-on-the-lane form where it is built (fp32-grade operands, 2 <= V <=
+// NF_SOL_MAX_V), the row form otherwise.  nf_ibrnet_rows_form: 0 = default (sample-on-the-lane, bf16x3 operands), 1 = the row form
+// always, 2 = sample-on-the-lane with fp32 matrix-core operands (V <= 4; above that the row form) -- TEST / DIAGNOSTIC hook: the
+// tests run the forms on the same inputs.
 static int g_rows_form = 0;
 extern "C" int nf_ibrnet_rows_form(int form) {
     const int old = g_rows_form;
-    if (form == 0 || form == 1) g_rows_form = form;
+    if (form >= 0 && form <= 2) g_rows_form = form;
     return old;
 }
-static bool sol_selected(int n_views, bool bf16) { return g_rows_form == 0 && !bf16 && n_views >= 2 && n_views <= NF_SOL_MAX_V; }
+static bool sol_selected(int n_views, bool bf16) {
+    if (bf16 || n_views < 2 || n_views > NF_SOL_MAX_V) return false;
+    return g_rows_form == 0 || (g_rows_form == 2 && n_views <= 4);
+}
 /* does the sample-on-the-lane form run for this shape under the current setting? */
 extern "C" int nf_ibrnet_sol_selected(int n_views, int bf16_operands) { return sol_selected(n_views, bf16_operands != 0) ? 1 : 0; }
 
-template <int V, int OCC>
+template <int V, int OP, int OCC>
 static int launch_sol_fwd_vo(const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_samples, int aa,
                              float* smp, const RowGather& g, hipStream_t st) {
     constexpr int NWV = sol_fwd_waves(OCC);
     const int64_t tiles = (n_samples + 31) / 32;
     int64_t blocks = (tiles + NWV - 1) / NWV;
-    const int64_t cap = 256;                // one resident workgroup per CU (MI355X: 256) stages the 58 KB weight image once and walks its tiles
+    const int64_t cap = 256;                // one resident workgroup per CU (MI355X: 256) stages the weight image once and walks its tiles
     if (blocks > cap) blocks = cap;
-    const size_t smem = (size_t)NF_MFMA_FWD_FLOATS * sizeof(float);
+    const size_t smem = (size_t)(OP == 3 ? (int)X3_FLOATS : (int)NF_MFMA_FWD_FLOATS) * sizeof(float);
+    static bool configured_on[NF_MAX_DEVICES][2] = {};      // > 64 KB of dynamic LDS: opt-in once per kernel and device
+    bool& configured = configured_on[nf_current_device()][g.featmap ? 1 : 0];
+    if (!configured && smem > 64 * 1024) {
+        const void* fn = g.featmap ? (const void*)k_ibr_sol_fwd<V, OP, true, OCC> : (const void*)k_ibr_sol_fwd<V, OP, false, OCC>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            nf_set_error("nf_ibrnet_fwd_mfma: cannot reserve %zu bytes of LDS", smem);
+            return 1;
+        }
+        configured = true;
+    }
     if (g.featmap)
-        hipLaunchKernelGGL((k_ibr_sol_fwd<V, false, true, OCC>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, wblob, rgb_feat, ray_diff, mask,
+        hipLaunchKernelGGL((k_ibr_sol_fwd<V, OP, true, OCC>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, wblob, rgb_feat, ray_diff, mask,
                            n_samples, aa, smp, g);
     else
-        hipLaunchKernelGGL((k_ibr_sol_fwd<V, false, false, OCC>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, wblob, rgb_feat, ray_diff, mask,
+        hipLaunchKernelGGL((k_ibr_sol_fwd<V, OP, false, OCC>), dim3((unsigned)blocks), dim3(64 * NWV), smem, st, wblob, rgb_feat, ray_diff, mask,
                            n_samples, aa, smp, g);
     return 0;
 }
@@ -2351,11 +2480,15 @@ static int launch_sol_fwd_v(const float* wblob, const float* rgb_feat, const flo
                             float* smp, const RowGather& g, hipStream_t st) {
     // A tile is 32 samples x V views of serial work.  With no more tiles than the chip has SIMDs (1024) every tile gets a SIMD of its own
     // in four-wave workgroups (the attack's coarse level: 512 rays x 64 samples = 1024 tiles); beyond that two waves per SIMD hide each
-    // other's LDS / memory latency where the registers allow it (V <= 4: measured 0.361 -> 0.311 ms at 4096 x 64 x 4).
+    // other's LDS / memory latency where the registers allow it (V <= 4: measured 0.361 -> 0.311 ms at 4096 x 64 x 4, fp32 operands).
+    const bool two = V <= 4 && (n_samples + 31) / 32 > 1024;
     if constexpr (V <= 4) {
-        if ((n_samples + 31) / 32 > 1024) return launch_sol_fwd_vo<V, 2>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st);
+        if (g_rows_form == 2)
+            return two ? launch_sol_fwd_vo<V, 0, 2>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st)
+                       : launch_sol_fwd_vo<V, 0, 1>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st);
+        if (two) return launch_sol_fwd_vo<V, 3, 2>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st);
     }
-    return launch_sol_fwd_vo<V, 1>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st);
+    return launch_sol_fwd_vo<V, 3, 1>(wblob, rgb_feat, ray_diff, mask, n_samples, aa, smp, g, st);
 }
 static int launch_sol_fwd(int n_views, const float* wblob, const float* rgb_feat, const float* ray_diff, const float* mask, int64_t n_samples,
                           int aa, float* smp, const RowGather& g, hipStream_t st) {

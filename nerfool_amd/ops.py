@@ -190,9 +190,10 @@ def ibrnet_mfma_supported(S, V):
 
 
 def ibrnet_rows_form(form):
-    """TEST / DIAGNOSTIC hook (nf_ibrnet_rows_form): 'auto' = the sample-on-the-lane kernels where they exist (fp32, 2 <= V <= 10),
-    'rows' = the row-form kernels always.  Returns the previous setting."""
-    names = ('auto', 'rows')
+    """TEST / DIAGNOSTIC hook (nf_ibrnet_rows_form): 'auto' = the sample-on-the-lane forward kernels where they exist (fp32-grade
+    operands as three bf16 parts, 2 <= V <= 10), 'rows' = the row-form kernels always, 'sol_fp32' = sample-on-the-lane with fp32
+    matrix-core operands (V <= 4).  Returns the previous setting."""
+    names = ('auto', 'rows', 'sol_fp32')
     return names[_lib.lib().nf_ibrnet_rows_form(names.index(form))]
 
 

@@ -82,9 +82,10 @@ def check_stage_kernels(case, dev):
 
 
 def check_row_kernel_forms(case, dev):
-    """kernel A exists in two forms (include/nerfool_hip.h: nf_ibrnet_rows_form): the sample-on-the-lane form must be the one that
-    runs by default at this view count, both forms must meet the reference's capture, and they must agree with each other far inside
-    that tolerance (same arithmetic up to the order of the cross-view sums and the pivot form of the second variance)."""
+    """kernel A's forward exists in three forms (include/nerfool_hip.h: nf_ibrnet_rows_form): the sample-on-the-lane form with
+    bf16x3 operands must be the one that runs by default at this view count, every form must meet the reference's capture, and they
+    must agree with each other far inside that tolerance (same arithmetic up to the order of the cross-view sums, the pivot form of
+    the second variance and the <= 2^-24 terms the operand split drops)."""
     g = Golden(case)
     cfg = g.stage_cfg()
     S, V = cfg['S'], cfg['V']
@@ -92,23 +93,24 @@ def check_row_kernel_forms(case, dev):
     ins = (g.t('coarse/rgb_feat', dev), g.t('coarse/ray_diff', dev), g.t('coarse/mask', dev))
     ref_raw = g.np('coarse/raw')
     scale = float(np.abs(ref_raw).max())
-    assert ops.ibrnet_rows_form('auto') in ('auto', 'rows')
+    assert ops.ibrnet_rows_form('auto') in ('auto', 'rows', 'sol_fp32')
+    raws = {}
     try:
-        assert ops.ibrnet_sol_selected(V) == (2 <= V <= 10), 'the sample-on-the-lane form must run for V = %d' % V
-        with torch.no_grad():
-            raw_sol = net(*ins)
-        ops.ibrnet_rows_form('rows')
-        assert not ops.ibrnet_sol_selected(V)
-        with torch.no_grad():
-            raw_rows = net(*ins)
+        for form in ('auto', 'rows', 'sol_fp32'):
+            ops.ibrnet_rows_form(form)
+            want_sol = (2 <= V <= 10) if form == 'auto' else (form == 'sol_fp32' and 2 <= V <= 4)
+            assert ops.ibrnet_sol_selected(V) == want_sol, 'form %s at V = %d' % (form, V)
+            with torch.no_grad():
+                raws[form] = net(*ins)
+            assert_close(raws[form], ref_raw, 1e-3, 1e-3 * scale, 'IBRNet raw, form ' + form)
     finally:
         ops.ibrnet_rows_form('auto')
-    assert_close(raw_sol, ref_raw, 1e-3, 1e-3 * scale, 'IBRNet raw, sample-on-the-lane form')
-    assert_close(raw_rows, ref_raw, 1e-3, 1e-3 * scale, 'IBRNet raw, row form')
-    assert_close(raw_sol, raw_rows, 2e-5, 2e-5 * scale, 'the two forms of kernel A')
-    print('[row kernel forms] %s V %d: max |sol - rows| %.2e of scale, sol vs reference %.2e, rows vs reference %.2e'
-          % (case, V, float((raw_sol - raw_rows).abs().max()) / scale, float((raw_sol.cpu() - torch.from_numpy(ref_raw)).abs().max()) / scale,
-             float((raw_rows.cpu() - torch.from_numpy(ref_raw)).abs().max()) / scale))
+    assert_close(raws['auto'], raws['rows'], 2e-5, 2e-5 * scale, 'sample-on-the-lane (bf16x3) vs row form')
+    assert_close(raws['sol_fp32'], raws['rows'], 2e-5, 2e-5 * scale, 'sample-on-the-lane (fp32 operands) vs row form')
+    err = lambda a: float((a.cpu() - torch.from_numpy(ref_raw)).abs().max()) / scale
+    print('[row kernel forms] %s V %d: max |sol bf16x3 - rows| %.2e, |sol fp32 - rows| %.2e of scale; vs reference: bf16x3 %.2e fp32-sol %.2e rows %.2e'
+          % (case, V, float((raws['auto'] - raws['rows']).abs().max()) / scale, float((raws['sol_fp32'] - raws['rows']).abs().max()) / scale,
+             err(raws['auto']), err(raws['sol_fp32']), err(raws['rows'])))
 
 
 def check_ibrnet_backward(case, dev):

@@ -59,7 +59,7 @@ def main():
         fm = torch.randn(V, 200, 200, 32, generator=gen).to(dev).permute(0, 3, 1, 2)
         cam_ws = ops.camera_setup(rb['camera'], rb['src_cameras'])
         out = {}
-        for form in ('rows', 'auto'):
+        for form in ('rows', 'sol_fp32', 'auto'):
             ops.ibrnet_rows_form(form)
             raw, ws = ops.ibrnet_fwd_mfma(mblob, blob, pe, rgb_feat, rd, mask, True)
             tf = timed(lambda: ops.ibrnet_fwd_mfma(mblob, blob, pe, rgb_feat, rd, mask, True), iters)
@@ -72,11 +72,11 @@ def main():
         F = flops(R, S, V)
         d1 = float((out['rows'][3] - out['auto'][3]).abs().max() / out['rows'][3].abs().max())
         d2 = float((out['rows'][4] - out['auto'][4]).abs().max() / out['rows'][4].abs().max())
-        print('R %5d S %3d V %2d | fwd rows %.3f ms (%.1f TF) sol %.3f ms (%.1f TF) x%.2f | gather-fused fwd rows %.3f sol %.3f ms x%.2f | bwd rows %.3f '
-              'sol %.3f ms x%.2f | max diff %.1e / %.1e' % (R, S, V, out['rows'][0], F / out['rows'][0] / 1e9, out['auto'][0], F / out['auto'][0] / 1e9,
-                                                          out['rows'][0] / out['auto'][0], out['rows'][2], out['auto'][2], out['rows'][2] / out['auto'][2],
-                                                          out['rows'][1], out['auto'][1], out['rows'][1] / out['auto'][1], d1, d2), flush=True)
-
+        print('R %5d S %3d V %2d | fwd (rows + per-ray kernels): rows %.3f ms (%.1f TF), sol fp32 %.3f, sol bf16x3 %.3f ms (%.1f TF) x%.2f | gather-fused: '
+              'rows %.3f, sol fp32 %.3f, sol bf16x3 %.3f ms x%.2f | bwd %.3f ms | max diff bf16x3 vs rows %.1e / %.1e'
+              % (R, S, V, out['rows'][0], F / out['rows'][0] / 1e9, out['sol_fp32'][0], out['auto'][0], F / out['auto'][0] / 1e9,
+                 out['rows'][0] / out['auto'][0], out['rows'][2], out['sol_fp32'][2], out['auto'][2], out['rows'][2] / out['auto'][2],
+                 out['rows'][1], d1, d2), flush=True)
 
 if __name__ == '__main__':
     main()
