@@ -7,7 +7,7 @@ import csv
 import json
 import sys
 
-ABI = {'nf_ibrnet_fwd_mfma': ('k_ibr_rows_fwd', 'k_ibr_ray_fwd'),
+ABI = {'nf_ibrnet_fwd_mfma': ('k_ibr_rows_fwd', 'k_ibr_sol_fwd', 'k_ibr_ray_fwd'),
        'nf_ibrnet_bwd_mfma': ('k_ibr_rows_bwd', 'k_ibr_ray_bwd'),
        'nf_project_gather_fwd': ('k_project_gather_fwd',), 'nf_project_gather_bwd': ('k_project_gather_bwd',),
        'nf_pgd_adam_step': ('k_pgd_adam_step',), 'nf_conv3x3_wino': ('k_wino3x3',),
