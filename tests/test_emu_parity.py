@@ -44,6 +44,19 @@ def fast_paths():
         mlp_network.KERNEL_PATH, feature_network.CNN_PATH = saved
 
 
+@contextlib.contextmanager
+def wino_fp32_operands():
+    """the GNT attack tests below exercise the GNT kernels; their feature CNN runs on the fp32-operand Winograd kernel, which the
+    stand-in emulates three times faster than the bf16x3 default (that form has its own tests: test_fused_cnn_glue, test_feature_net,
+    test_attack_step_on_the_product_dispatch)"""
+    from nerfool_amd.ibrnet import feature_network
+    saved, feature_network.WINO_OPERANDS = feature_network.WINO_OPERANDS, 'fp32'
+    try:
+        yield
+    finally:
+        feature_network.WINO_OPERANDS = saved
+
+
 @pytest.mark.parametrize('case', TINY)
 def test_stage_kernels(case):
     pc.check_stage_kernels(case, 'cpu')
@@ -161,7 +174,8 @@ def test_gnt_config4_shape_on_the_matrix_core_kernels():
 
 
 def test_gnt_attack_step():
-    pc.check_gnt_attack_step('cpu')
+    with wino_fp32_operands():
+        pc.check_gnt_attack_step('cpu')
 
 
 def test_render_single_image():
@@ -207,7 +221,8 @@ def test_gnt_matrix_core_forward_matches_generic():
 
 
 def test_gnt_attack_gradient_on_the_matrix_core_kernels():
-    pc.check_gnt_attack_gradient_kernel_paths('cpu', shapes=((4, 32, 3, 2),))
+    with wino_fp32_operands():
+        pc.check_gnt_attack_gradient_kernel_paths('cpu', shapes=((4, 32, 3, 2),))
 
 
 def test_gnt_ret_alpha_and_hierarchical_sampling():

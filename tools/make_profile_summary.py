@@ -49,8 +49,8 @@ def main():
               'bash tools/pmc_render.sh                                                         -> %(r)s_pmc_render_traffic.txt\n'
               'python3 -m pytest tests -m gpu -q -s | grep ...                                  -> %(r)s_parity_numbers.txt\n'
               '```\n' % {'r': rnd})
-    md.append('The `--stats` CSVs cover the whole process (including the one-off per-shape timing of the two Winograd workgroup widths in the\n'
-              'first warm-up step); the steady-state tables are the TIMED region only: the kernel trace cut between the fused update kernels of\n'
+    md.append('The `--stats` CSVs cover the whole process (warm-up steps included; the Winograd workgroup width is a rule on the shape since round 4, no\n'
+              'timing runs); the steady-state tables are the TIMED region only: the kernel trace cut between the fused update kernels of\n'
               'the last warm-up step and of the last timed step.  In the traced runs the bench\'s HIP-event brackets are off (`--event-every 0`);\n'
               'in the bench lines they are live on every 4th timed step (`roofline_sampling`).  FETCH_SIZE is doubled as MI355X_MICROARCH.md\n'
               'prescribes for gfx950 (confirmed on the delta update: %.2f MB counted vs %.2f MB = 8 streams).\n'
@@ -59,7 +59,7 @@ def main():
     md.append('## Config 2 (headline)\n')
     k = ex['kernels'][r['kernel']]
     md.append('`%.0f rays/s`, `%.2f ms/step` (N_rand 512, 756x1008, V 4, 64+64 samples; 1000 steps: %.3f ms/step); dominant hand-written entry\n'
-              'point `%s`: %.1f %s = %.3f of the fp32 matrix peak (Winograd-domain products; %.0f TFLOP/s in direct-form terms), HBM traffic\n'
+              'point `%s`: %.1f %s = %.3f of the fp32 matrix peak (Winograd-domain products, each counted once -- executed as six bf16 products; %.0f TFLOP/s in direct-form terms), HBM traffic\n'
               '%.1f MB per launch (PMC) vs %.1f MB algorithmic.  Whole step: %.1f TFLOP/s of direct-form FLOPs = %.3f of the fp32 matrix peak.\n'
               'cpu_baseline %.1f rays/s (%.2f s per PGD iteration) on %d physical cores (%s); CPU render leg %.0f rays/s.\n'
               % (b['value'], b['ms_per_step'], k1000['ms_per_step'], r['kernel'], r['achieved'], r['unit'], r['frac'],
@@ -93,8 +93,19 @@ def main():
         md.append('Steady-state kernel table:\n\n```\n' + text('%s_steady_state_kernels_%s.txt' % (rnd, tag), 24) + '\n```\n')
         md.append('Issue counters:\n\n```\n' + text('%s_sq_pipe_%s.txt' % (rnd, tag), 14) + '\n```\n')
         md.append('PMC HBM traffic per launch (2 x FETCH_SIZE + WRITE_SIZE, separate passes):\n\n```\n' + text('%s_pmc_traffic_%s.txt' % (rnd, tag), 14) + '\n```\n')
-    md.append('## MFMA / VALU overlap probe (`tools/experimental/probe_overlap.hip`)\n\n```\n' + text(rnd + '_probe_mfma_valu_overlap.txt') + '\n```\n')
-    md.append('fp32 and bf16 matrix instructions and fp32 vector instructions of the waves of one SIMD do not overlap: the times add (DESIGN.md section 4).\n')
+    def opt(title, name, note=''):
+        if os.path.exists(os.path.join(P, rnd + name)):
+            md.append('## %s (`%s`)\n\n%s```\n%s\n```\n' % (title, rnd + name, note, text(rnd + name)))
+    opt('bf16-split operand mix against the fp32 mix (`tools/experimental/probe_bf3.hip`)', '_probe_bf16_split_mix.txt',
+        'fp32 matrix instructions run at the vector rate and their time adds to the vector instructions around them; the bf16 ones run at\n'
+        '16x the rate and beside the vector pipe: the 3-way split mix of a Winograd chunk takes 0.43 of the shipped fp32 mix.\n\n')
+    opt('Winograd kernel, operand forms and ablations (`tools/bench_wino_bf.py`)', '_wino_bf16x3_ablation.txt',
+        'fp32 / bf16x3 / bf16 per layer; then timing-only builds of the bf16x3 kernel (wrong results): one record piece streamed per step instead of\n'
+        'three, no operand split arithmetic, both.\n\n')
+    opt('IBRNet forward, row form vs sample-on-the-lane (`tools/bench_sol.py`)', '_row_kernel_forms.txt')
+    opt('CNN glue micro-benchmark (`tools/bench_cnn_glue.py`)', '_cnn_glue_microbench.txt')
+    opt('Plain bf16 operands in the 3x3 convolutions: measured and rejected (`tools/diag_bf16_cnn.py`)', '_plain_bf16_cnn_rejected.txt')
+    opt('MFMA / VALU overlap probe (`tools/experimental/probe_overlap.hip`)', '_probe_mfma_valu_overlap.txt')
     md.append('## Parity figures printed by the GPU tests (`%s_parity_numbers.txt`)\n\n```\n%s\n```\n' % (rnd, text(rnd + '_parity_numbers.txt')))
     with open(os.path.join(P, rnd + '_rocprofv3_summary.md'), 'w') as f:
         f.write('\n'.join(md))
