@@ -14,6 +14,8 @@
 // X mod 2) of dx are four stride-1 correlations of dy with 2x2 / 2x1 / 1x2 / 1x1 (3x3) or 4x4 / 4x3 / 3x4 / 3x3 (7x7) taps;
 // a lane keeps the accumulators of all four classes of its (u, v) position, so the two column classes leave as one 8-byte
 // store and dx is written exactly once, zeros included.  Two to four workgroups per CU overlap one another's staging.
+#include <string.h>
+
 #include "nf_common.h"
 
 typedef float s2_f16 __attribute__((ext_vector_type(16)));
@@ -479,6 +481,178 @@ __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd(const float* __restrict_
             }
         }
     }
+}
+
+// ---- backward-data of the stride-2 3x3 convolutions on the BF16 matrix cores, operands as three bf16 parts ("bf16x3", as
+// csrc/nf_wino_bf.hip: the six cross products of order <= 2^-16 on v_mfma_f32_32x32x16_bf16 reproduce the fp32 product to fp32 rounding
+// level at 6 / 16 of the fp32 matrix instructions' time, and beside the vector pipe).  Same workgroup geometry as k_conv_s2_bwd<3>
+// (4 rows of u x 32 columns of v x 32 input channels, all four parity classes), a chunk = 16 dy channels = ONE k-block of the bf16
+// instruction: lane (v, h) supplies the channels 2 j + h, j = 0..7, of its dy position.  The nine (class, tap) products of a chunk read
+// only FOUR distinct dy positions (u - i, v - jj), i, jj in {0, 1}: each is gathered and split once and multiplied with the weight
+// parts of every class that uses it.  Records: [group of 32 inputs][chunk][position (i, jj)][class using it][part 3][lane][8 bf16].
+typedef unsigned s2_u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 s2_bf8 __attribute__((ext_vector_type(8)));
+#define S2_X3_COMBOS 9
+#define S2_X3_CHUNK_FLOATS (S2_X3_COMBOS * 3 * 256)
+
+static inline uint16_t s2_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+extern "C" int64_t nf_conv_s2_x3_pack_floats(int c_out, int c_in) {
+    return (int64_t)((c_in + 31) / 32) * ((c_out + 15) / 16) * S2_X3_CHUNK_FLOATS;
+}
+
+/* HOST: weight [c_out][c_in][3][3] -> bf16x3 records of the backward-data pass (see above); lane (c = 32 g + (lane & 31), h = lane >> 5),
+ * element j <-> dy channel k = 16 chunk + 2 j + h; tap a = 2 i + ya, b = 2 jj + xb */
+extern "C" int nf_conv_s2_x3_pack(const float* weight, int c_out, int c_in, float* out) {
+    const int groups = (c_in + 31) / 32, chunks = (c_out + 15) / 16;
+    uint16_t* piece = reinterpret_cast<uint16_t*>(out);
+    for (int g = 0; g < groups; ++g)
+        for (int ch = 0; ch < chunks; ++ch)
+            for (int i = 0; i < 2; ++i)
+                for (int jj = 0; jj < 2; ++jj)
+                    for (int ya = 0; 2 * i + ya < 3 && ya < 2; ++ya)
+                        for (int xb = 0; 2 * jj + xb < 3 && xb < 2; ++xb, piece += 3 * 512)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int c = 32 * g + (lane & 31), k = 16 * ch + 2 * j + (lane >> 5), a = 2 * i + ya, b = 2 * jj + xb;
+                                    float rem = (k < c_out && c < c_in) ? weight[(((size_t)k * c_in + c) * 3 + a) * 3 + b] : 0.f;
+                                    for (int p = 0; p < 3; ++p) {
+                                        const uint16_t q = s2_rne(rem);
+                                        piece[(size_t)p * 512 + lane * 8 + j] = q;
+                                        const uint32_t u = (uint32_t)q << 16;
+                                        float up;
+                                        memcpy(&up, &u, 4);
+                                        rem -= up;
+                                    }
+                                }
+    return (reinterpret_cast<float*>(piece) - out) == nf_conv_s2_x3_pack_floats(c_out, c_in) ? 0 : 2;
+}
+
+__device__ __forceinline__ unsigned s2_split_pair(float& x0, float& x1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __bf16 s2_bf2 __attribute__((ext_vector_type(2)));
+    const s2_bf2 p = s2_bf2{(__bf16)x0, (__bf16)x1};
+    const unsigned u = __builtin_bit_cast(unsigned, p);
+    x0 -= __builtin_bit_cast(float, u << 16);
+    x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
+    return u;
+#else
+    const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
+    unsigned short s0, s1;
+    memcpy(&s0, &b0, 2);
+    memcpy(&s1, &b1, 2);
+    x0 -= (float)b0;
+    x1 -= (float)b1;
+    return (unsigned)s0 | ((unsigned)s1 << 16);
+#endif
+}
+
+__global__ void __launch_bounds__(256, 2) k_conv_s2_bwd3_x3(const float* __restrict__ rec, const float* __restrict__ dy, S2Tensor di, int Ho, int Wo,
+                                                            float* __restrict__ dx, S2Tensor xo, int Hi, int Wi, int C, int K, int groups,
+                                                            int tiles_x, int tiles_y) {
+    using G = S2Bwd<3>;
+    constexpr int CK = G::CK, WR = G::WR, CHF = G::CHF, T0 = G::T0;
+    static_assert(CK == 16 && T0 == 2, "one bf16 k-block per chunk, taps i, jj in {0, 1}");
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* win = smem;
+    float* wgt = smem + G::WIN;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int grp = bid % groups;
+    bid /= groups;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, n = bid / tiles_y;
+    const int u0 = ty * 4, v0 = tx * 32;
+    const int chunks = (K + CK - 1) / CK;
+    const float* dn = dy + n * di.ns;
+    const float* wsrc = rec + (size_t)grp * chunks * S2_X3_CHUNK_FLOATS;
+    const int bbase = h * CHF + (T0 - 1 + w) * S2_PW + (T0 - 1) + j;
+
+    s2_f16 acc[2][2];         // [ya][xb]
+#pragma unroll
+    for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+        for (int xb = 0; xb < 2; ++xb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ya][xb][r] = 0.f;
+
+    S2BwdStage<CK, WR, G::WCOLS, T0, S2_X3_CHUNK_FLOATS> stage;
+    stage.fetch(dn, di, Ho, Wo, K, 0, u0, v0, wsrc, w, lane);
+    for (int ch = 0; ch < chunks; ++ch) {
+        __syncthreads();
+        stage.commit(win, wgt, w, lane);
+        __syncthreads();
+        if (ch + 1 < chunks) stage.fetch(dn, di, Ho, Wo, K, ch + 1, u0, v0, wsrc, w, lane);
+        int combo = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                // the lane's 8 channels (2 p + h) of dy[u - i][v - jj], split into bf16 parts
+                s2_u4 bv[3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v0f = win[bbase + 2 * (2 * q) * CHF - i * S2_PW - jj], v1f = win[bbase + 2 * (2 * q + 1) * CHF - i * S2_PW - jj];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bv[p][q] = s2_split_pair(v0f, v1f);
+                }
+#pragma unroll
+                for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+                    for (int xb = 0; xb < 2; ++xb) {
+                        if (2 * i + ya >= 3 || 2 * jj + xb >= 3) continue;
+                        const float* rs = wgt + combo * (3 * 256) + 4 * lane;
+                        const s2_u4 a0 = *reinterpret_cast<const s2_u4*>(rs), a1 = *reinterpret_cast<const s2_u4*>(rs + 256),
+                                    a2 = *reinterpret_cast<const s2_u4*>(rs + 512);
+#define S2_PROD(a, b) acc[ya][xb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s2_bf8, a), __builtin_bit_cast(s2_bf8, b), acc[ya][xb], 0, 0, 0)
+                        S2_PROD(a0, bv[0]);
+                        S2_PROD(a0, bv[1]);
+                        S2_PROD(a1, bv[0]);
+                        S2_PROD(a0, bv[2]);
+                        S2_PROD(a2, bv[0]);
+                        S2_PROD(a1, bv[1]);
+#undef S2_PROD
+                        ++combo;
+                    }
+            }
+    }
+    // ---- store: as k_conv_s2_bwd
+    float* xn = dx + n * xo.ns;
+    const int u = u0 + w, v = v0 + j;
+#pragma unroll
+    for (int ya = 0; ya < 2; ++ya) {
+        const int Y = 2 * u + ya, X = 2 * v;
+        if (Y < Hi && X < Wi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * grp + s2_nidx(r, h);
+                if (c < C) {
+                    float* p = xn + c * xo.cs + Y * xo.rs + X;
+                    if (X + 1 < Wi) *reinterpret_cast<s2_f2*>(p) = s2_f2{acc[ya][0][r], acc[ya][1][r]};
+                    else p[0] = acc[ya][0][r];
+                }
+            }
+        }
+    }
+}
+
+/* nf_conv_s2_bwd for ks = 3 on the bf16 matrix cores with three-way split operands (fp32-grade); records: nf_conv_s2_x3_pack */
+extern "C" int nf_conv_s2_bwd_x3(const float* records, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int Ho, int Wo, float* dx,
+                                 int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, int n_img, int c_in, int c_out, nf_stream_t stream) {
+    NF_REQUIRE(n_img >= 1 && c_in >= 1 && c_out >= 1 && Hi >= 3 && Wi >= 3, "nf_conv_s2_bwd_x3: bad arguments");
+    NF_REQUIRE(Ho == (Hi - 3) / 2 + 1 && Wo == (Wi - 3) / 2 + 1, "nf_conv_s2_bwd_x3: gradient %d x %d does not match input %d x %d", Ho, Wo, Hi, Wi);
+    const S2Tensor di{ds_n, ds_c, ds_h}, xo{xs_n, xs_c, xs_h};
+    const int tiles_x = ((Wi + 1) / 2 + 31) / 32, tiles_y = ((Hi + 1) / 2 + 3) / 4, groups = (c_in + 31) / 32;
+    constexpr size_t smem = sizeof(float) * (S2Bwd<3>::WIN + S2_X3_CHUNK_FLOATS);
+    hipLaunchKernelGGL(k_conv_s2_bwd3_x3, dim3((unsigned)(tiles_x * tiles_y * n_img * groups)), dim3(256), smem, (hipStream_t)stream, records, dy,
+                       di, Ho, Wo, dx, xo, Hi, Wi, c_in, c_out, groups, tiles_x, tiles_y);
+    NF_LAUNCH_CHECK("nf_conv_s2_bwd_x3");
+    return 0;
 }
 
 // ---- backward-data of the 7x7 stem (at most 4 input channels): the four parity classes share ONE accumulator tile -- row

@@ -232,14 +232,20 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
         float E[8][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+#ifdef WB_EXP_NO_E
+            const float* pa = pbuf + hh * WN_CH;          // TIMING EXPERIMENT (wrong results): one channel's rows for all eight
+#else
             const float* pa = pbuf + (2 * j + hh) * WN_CH;
+#endif
             const w2a a0 = *reinterpret_cast<const w2a*>(pa + ra * WN_PS), a1 = *reinterpret_cast<const w2a*>(pa + ra * WN_PS + 2);
             const w2a b0 = *reinterpret_cast<const w2a*>(pa + rb * WN_PS), b1 = *reinterpret_cast<const w2a*>(pa + rb * WN_PS + 2);
             // sb = +-1: the fused form is exact
             E[j][0] = fmaf(sb, b0[0], a0[0]), E[j][1] = fmaf(sb, b0[1], a0[1]), E[j][2] = fmaf(sb, b1[0], a1[0]), E[j][3] = fmaf(sb, b1[1], a1[1]);
         }
         // the next chunk's window travels global -> registers under this chunk's products, -> LDS in front of the last step
+#ifndef WB_EXP_NO_FETCH
         if (!last) fetch(chunk + 1);
+#endif
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
             // column nu of B^T d B for the 8 channels, split into bf16 parts: part p of channel pair (2 q, 2 q + 1) -> bv[p][q]
@@ -264,8 +270,12 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                 const int s = nu * KB + kb;           // compile-time after unrolling
                 // the chunk hand-over sits in front of the last step, as in nf_wino.hip
                 if (s == NSTEP - 1 && !last) {
+#ifndef WB_EXP_NO_FETCH
                     commit(chunk + 1);
+#endif
+#ifndef WB_EXP_NO_BARRIER
                     __syncthreads();
+#endif
                 }
                 // [A] records of step s + DIST; never past the end of the stream
                 if (!last || s + DIST < NSTEP) issue_step(s + DIST);
@@ -275,7 +285,11 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                     // fetch is issued at the top of the chunk, IN FRONT of step 0's refill: it is younger than the records of steps
                     // 1 .. DIST - 1 only)
                     if (!last) {
+#ifdef WB_EXP_NO_FETCH
+                        if (s < DIST - 1) wn_wait_vm<(DIST - 1) * PCS>();
+#else
                         if (s < DIST - 1) wn_wait_vm<(DIST - 1) * PCS + WN_FETCH_OPS>();
+#endif
                         else wn_wait_vm<(DIST - 1) * PCS>();
                     } else {
                         // (s is a constant after unrolling: the switch folds to one wait)

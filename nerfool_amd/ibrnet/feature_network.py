@@ -314,14 +314,28 @@ def _s2_records(conv_w):
 # stride-2 convolutions (7x7 stem, first 3x3 of layer1-3): csrc/nf_conv_s2.hip
 
 
-def _conv_s2(tape, inp, w, sink):
+def _s2_records_x3(conv_w):
+    """bf16x3 backward-data records of a stride-2 3x3 weight (csrc/nf_conv_s2.hip: k_conv_s2_bwd3_x3), kept on the weight tensor"""
+    key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
+    cache = getattr(conv_w, '_nf_s2_x3', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.conv_s2_pack_x3(conv_w, conv_w.device))
+        conv_w._nf_s2_x3 = cache
+    return cache[1]
+
+
+def _conv_s2(tape, inp, w, sink, operands=None):
     c_out, c_in, ks = w.shape[0], w.shape[1], w.shape[2]
     rf, rb = _s2_records(w)
     out = _Slot(ops.conv_s2_fwd(rf, inp, c_out, ks))
     Hi, Wi = inp.shape[2], inp.shape[3]
+    x3 = ks == 3 and (operands or WINO_OPERANDS) == 'bf16x3'      # the 3x3 backward-data pass on the split operands (fp32-grade)
 
     def bwd():
-        sink(ops.conv_s2_bwd(rb, out.g, c_in, ks, Hi, Wi))
+        if x3:
+            sink(ops.conv_s2_bwd_x3(_s2_records_x3(w), out.g, c_in, Hi, Wi))
+        else:
+            sink(ops.conv_s2_bwd(rb, out.g, c_in, ks, Hi, Wi))
         out.g = None
     tape.append(bwd)
     return out
@@ -331,7 +345,7 @@ def _conv(tape, inp, w, stride, sink, bias=None, operands=None):
     if stride == 1 and bias is None and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 32 == 0:
         return _conv3x3(tape, inp, w, sink, operands)
     if stride == 2 and bias is None and tuple(w.shape[2:]) in ((3, 3), (7, 7)) and (w.shape[2] == 3 or w.shape[1] <= 3):
-        return _conv_s2(tape, inp, w, sink)
+        return _conv_s2(tape, inp, w, sink, operands)
     out = _Slot(_aten.convolution(inp, w, bias, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1))
 
     def bwd():

@@ -646,6 +646,30 @@ def conv_s2_bwd(records, dy, c_in, ks, Hi, Wi):
     return dx
 
 
+def conv_s2_pack_x3(weight, device):
+    """weight [c_out, c_in, 3, 3] -> bf16x3 records of the stride-2 backward-data pass (nf_conv_s2_bwd_x3)"""
+    L = _lib.lib()
+    w = weight.detach().to('cpu', torch.float32).contiguous()
+    assert tuple(w.shape[2:]) == (3, 3)
+    out = torch.empty(L.nf_conv_s2_x3_pack_floats(w.shape[0], w.shape[1]), dtype=torch.float32)
+    _lib.check(L.nf_conv_s2_x3_pack(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr()), 'nf_conv_s2_x3_pack')
+    return out.to(device)
+
+
+def conv_s2_bwd_x3(records, dy, c_in, Hi, Wi):
+    """conv_s2_bwd for ks = 3 on the bf16 matrix cores with three-way split operands (fp32-grade)"""
+    _f32(dy, 'dy')
+    if dy.stride(3) != 1:
+        dy = dy.contiguous()
+    N, c_out, Ho, Wo = dy.shape
+    dx = torch.empty(N, c_in, Hi, Wi, dtype=torch.float32, device=dy.device)
+    ds, xs = dy.stride(), dx.stride()
+    with prof.launch('nf_conv_s2_bwd', dy, n_img=N, c_in=c_in, c_out=c_out, ks=3, Ho=Ho, Wo=Wo, n_split=3):
+        _launch(_lib.lib().nf_conv_s2_bwd_x3, 'nf_conv_s2_bwd_x3', dy, _ptr(records), _ptr(dy), ds[0], ds[1], ds[2], Ho, Wo, _ptr(dx), xs[0], xs[1],
+                xs[2], Hi, Wi, N, c_in, c_out)
+    return dx
+
+
 def wino_pack(weight, backward, device, k_per_group=None, n_split=0):
     """weight [c_out, c_in, 3, 3] -> Winograd-domain MFMA records (backward: the backward-data convolution);
     k_per_group: output channels per workgroup, 64 or 32 (default wino_group); n_split: 0 = fp32 matrix-core operands (nf_wino_pack),

@@ -1383,6 +1383,10 @@ def check_conv_s2(dev, shapes=None):
         ef = float((y.cpu().double() - ref.detach()).abs().max() / ref.abs().max())
         eb = float((dx.cpu().double() - gref).abs().max() / gref.abs().max())
         assert ef <= 5e-6 and eb <= 5e-6, ('conv_s2', N, cin, cout, ks, Hi, Wi, ef, eb)
+        if ks == 3:      # the backward-data pass on the bf16 matrix cores with three-way split operands: the same float64 bar
+            dx3 = ops.conv_s2_bwd_x3(ops.conv_s2_pack_x3(w, dev), g.to(dev), cin, Hi, Wi)
+            eb3 = float((dx3.cpu().double() - gref).abs().max() / gref.abs().max())
+            assert eb3 <= 5e-6, ('conv_s2 bf16x3 backward', N, cin, cout, Hi, Wi, eb3)
         # a strided (non-contiguous) input view: the executor hands the kernel interior views of padded buffers
         big = torch.randn(N, cin, Hi + 3, Wi + 4, generator=gen).to(dev)
         view = big[:, :, 1:1 + Hi, 2:2 + Wi]

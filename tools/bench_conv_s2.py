@@ -42,6 +42,11 @@ for (cin, cout, ks, Hi, Wi) in ((3, 64, 7, 762, 1014), (64, 64, 3, 380, 506), (6
     gc = g[:1, :, :yc.shape[2], :yc.shape[3]].contiguous()
     gref, = torch.autograd.grad(yc, xc, gc.cpu().double())
     eb = float((ops.conv_s2_bwd(rb, gc, cin, ks, 41, 73).cpu().double() - gref).abs().max() / gref.abs().max())
+    if ks == 3:
+        r3 = ops.conv_s2_pack_x3(w, 'cuda')
+        t_3, d3 = timed(lambda: ops.conv_s2_bwd_x3(r3, g, cin, Hi, Wi))
+        e3 = float((ops.conv_s2_bwd_x3(r3, gc, cin, 41, 73).cpu().double() - gref).abs().max() / gref.abs().max())
+        print('      bf16x3 backward-data: %6.1f us (fp32 operands %6.1f us), err vs float64 %.1e' % (t_3, t_ob, e3))
     print('%3d -> %3d %dx%d s2 at %dx%d: fwd MIOpen %6.1f us  own %6.1f us (%.1f TFLOP/s) | bwd-data MIOpen %6.1f us  own %6.1f us (%.1f TFLOP/s) | '
           'err fwd %.1e bwd %.1e | own vs MIOpen %.1e %.1e'
           % (cin, cout, ks, ks, Hi, Wi, t_m, t_o, fl / t_o / 1e6, t_mb, t_ob, fl / t_ob / 1e6, ef, eb,
