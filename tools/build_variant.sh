@@ -8,7 +8,8 @@ mkdir -p build/variants/$name
 for f in nerfool_amd/csrc/*.hip; do
   o=build/variants/$name/$(basename $f).o
   if [ "$(basename $f)" = ${NF_VARIANT_SRC:-nf_cnn.hip} ] || [ ! -f $o ]; then
-    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -std=c++17 -Iinclude -Inerfool_amd/csrc "$@" -c $f -o $o &
+    extra=""; [ "$(basename $f)" = nf_wino_bf.hip ] && extra="-fno-slp-vectorize"       # as __graft_entry__.HIPCC_EXTRA
+    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -std=c++17 -Iinclude -Inerfool_amd/csrc $extra "$@" -c $f -o $o &
   fi
 done
 wait
