@@ -271,10 +271,6 @@ int64_t nf_conv_s2_x3_pack_floats(int c_out, int c_in);
 int nf_conv_s2_x3_pack(const float* weight_host, int c_out, int c_in, float* records_host);
 int nf_conv_s2_bwd_x3(const float* records, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int Ho, int Wo, float* dx, int64_t xs_n,
                       int64_t xs_c, int64_t xs_h, int Hi, int Wi, int n_img, int c_in, int c_out, nf_stream_t stream);
-/* nf_conv_s2_bwd for the 7x7 stem reading  dy := coef[n][k][0] d_pre + coef[n][k][1] x + coef[n][k][2]  (nf_in_act_pad_bwd_open) */
-int nf_conv_s2_bwd_stem_affine(const float* records, const float* d_pre, const float* x, const float* coef, int64_t ds_n, int64_t ds_c,
-                               int64_t ds_h, int Ho, int Wo, float* dx, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, int n_img,
-                               int c_in, int c_out, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * a14  ResUNet 3x3 stride-1 convolutions as Winograd F(2x2, 3x3) on the fp32 matrix cores.
@@ -382,12 +378,6 @@ int nf_in_act_pad_fwd(const float* x, int n_img, int C, int H, int W, const floa
 int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, const float* y_padded, const float* x, int n_img, int C,
                       int H, int W, const float* gamma, const float* beta, const float* mean, const float* rstd, int act, int pad,
                       float* d_res, float* dx, void* scratch, int64_t dy_n_stride, const float* d_extra_sub, nf_stream_t stream);
-/* nf_in_act_pad_bwd stopped behind its first pass, for a consumer that applies the second pass while it reads (the 7x7 stem's
- * backward-data convolution): writes d_pre [N,C,H,W] and coef [N*C][4] = (A, B, C, 0) with  d x = A d_pre + B x + C  per plane.
- * Normalised layers without a residual input (ibrnet/feature_network.py:188-190, backward).  scratch: 512 bytes per plane. */
-int nf_in_act_pad_bwd_open(const float* dy_padded, const float* d_extra, const float* x, int n_img, int C, int H, int W, const float* gamma,
-                           const float* beta, const float* mean, const float* rstd, int act, int pad, float* d_pre, float* coef,
-                           void* scratch, int64_t dy_n_stride, const float* d_extra_sub, nf_stream_t stream);
 
 #ifdef __cplusplus
 }

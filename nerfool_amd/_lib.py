@@ -107,9 +107,6 @@ _PROTOTYPES = {
                                   c_int, c_int, _P, c_int64, _P, _P, _P, _P]),
     'nf_in_act_pad_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64,
                                   _P, _P]),
-    'nf_in_act_pad_bwd_open': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, _P, _P]),
-    'nf_conv_s2_bwd_stem_affine': (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int,
-                                           c_int, c_int, c_int, _P]),
     'nf_upsample2x_pad_fwd': (c_int, [_P, c_int64, c_int64, c_int64, c_int, c_int, c_int, _P, _P]),
     'nf_legacy_choice': (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     'nf_project_perturb': (c_int, [_P, _P, c_int64, c_float, c_float, c_float, _P]),

@@ -698,46 +698,6 @@ extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, c
     return 0;
 }
 
-// ---- the InstanceNorm backward's second pass as an AFFINE combination, for a consumer that applies it while it stages its input
-// (the 7x7 stem's backward-data convolution, csrc/nf_conv_s2.hip):  dx = gr (d_pre - m1 - xhat m2),  xhat = (x - mean) rstd,  gr = gamma rstd
-//   =>  dx = A d_pre + B x + C  with  A = gr,  B = -gr m2 rstd,  C = gr (m2 rstd mean - m1)      (per (image, channel) plane)
-__global__ void k_in_bwd_coef(const double* __restrict__ sums, int n_splits, int planes, int C, int HW, const float* __restrict__ gamma,
-                              const float* __restrict__ mean_in, const float* __restrict__ rstd_in, float* __restrict__ coef) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= planes) return;
-    double sa, sb;
-    plane_sums(sums, p, n_splits, sa, sb);
-    const float m1 = (float)(sa / (double)HW), m2 = (float)(sb / (double)HW);
-    const float mean = mean_in[p], rstd = rstd_in[p], gr = gamma[p % C] * rstd;
-    coef[4 * p + 0] = gr;
-    coef[4 * p + 1] = -gr * m2 * rstd;
-    coef[4 * p + 2] = gr * (m2 * rstd * mean - m1);
-    coef[4 * p + 3] = 0.f;
-}
-
-/* nf_in_act_pad_bwd stopped behind its first pass (fold of the padded gradient, activation derivative, the two plane sums): writes
- * d_pre [N,C,H,W] and coef [N*C][4] = (A, B, C, 0) with  d x = A d_pre + B x + C  per plane -- the second pass is then applied by the
- * consumer of d x while it reads (nf_conv_s2_bwd_stem_affine).  Normalised layers without residual input only (the stem's bn1). */
-extern "C" int nf_in_act_pad_bwd_open(const float* dy_padded, const float* d_extra, const float* x, int n_img, int C, int H, int W,
-                                      const float* gamma, const float* beta, const float* mean, const float* rstd, int act, int pad,
-                                      float* d_pre, float* coef, void* scratch, int64_t dy_n_stride, const float* d_extra_sub,
-                                      nf_stream_t stream) {
-    NF_REQUIRE(n_img >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad < H && pad < W && act >= 0 && act <= 2 && gamma && beta && x &&
-                   d_pre && coef && scratch && (dy_padded || d_extra || d_extra_sub),
-               "nf_in_act_pad_bwd_open: bad arguments");
-    if (dy_n_stride == 0) dy_n_stride = (int64_t)C * (H + 2 * pad) * (W + 2 * pad);
-    hipStream_t st = (hipStream_t)stream;
-    const int planes = n_img * C, HW = H * W;
-    dim3 grid(nf_apply_splits(planes, HW), (unsigned)planes);
-    hipLaunchKernelGGL(k_in_act_pad_bwd1, grid, dim3(NF_CNN_BLOCK), 0, st, dy_padded, d_extra, (const float*)nullptr, x, H, W, mean, rstd, 1, act,
-                       pad, (float*)nullptr, d_pre, (double*)scratch, 1, C, gamma, beta, dy_n_stride, d_extra_sub);
-    NF_LAUNCH_CHECK("nf_in_act_pad_bwd_open (fold)");
-    hipLaunchKernelGGL(k_in_bwd_coef, dim3((unsigned)((planes + 255) / 256)), dim3(256), 0, st, (const double*)scratch, (int)grid.x, planes, C, HW,
-                       gamma, mean, rstd, coef);
-    NF_LAUNCH_CHECK("nf_in_act_pad_bwd_open (coefficients)");
-    return 0;
-}
-
 extern "C" int nf_upsample2x_pad_fwd(const float* x, int64_t planes, int64_t xs_plane, int64_t xs_row, int h, int w, int pad,
                                      float* y_padded, nf_stream_t stream) {
     NF_REQUIRE(planes >= 1 && planes <= 0x7fffffff && h >= 1 && w >= 1 && pad >= 0 && pad < 2 * h && pad < 2 * w && xs_row >= w,

@@ -342,26 +342,14 @@ template <int KS> struct S2Bwd {
 // ---- software-pipelined staging of the backward kernels: the dy window of CK channels (WR rows x WCOLS columns, zeros outside
 // the tensor) and WFLOATS floats of weight records travel global -> registers (fetch, issued under the previous chunk's
 // matrix-core work) -> LDS (commit, behind the barrier that retires the previous chunk)
-// AFF: the staged value is  A[k] dn[..] + B[k] dn2[..] + C[k]  (coef [K][4] of this image: the InstanceNorm backward's second pass
-// applied on the fly, nf_in_act_pad_bwd_open) instead of dn[..]
-template <int CK, int WR, int WCOLS, int T0, int WFLOATS, bool AFF = false>
+template <int CK, int WR, int WCOLS, int T0, int WFLOATS>
 struct S2BwdStage {
     static constexpr int NROW = (CK * WR + 7) / 8, XC = WCOLS - 32, NXC = (CK * WR * XC + 255) / 256, NWG = (WFLOATS / 4 + 255) / 256;
     static constexpr int CHF = WR * S2_PW;
     float pre_w[NROW], pre_x[NXC];
     s2_f4 pre_g[NWG];
-    __device__ __forceinline__ float element(const float* __restrict__ dn, const float* __restrict__ dn2, const float* __restrict__ coef, int64_t off,
-                                             int gk) const {
-        if constexpr (AFF) {
-            const float4 q = *reinterpret_cast<const float4*>(coef + 4 * gk);
-            return fmaf(q.x, dn[off], fmaf(q.y, dn2[off], q.z));
-        } else {
-            return dn[off];
-        }
-    }
     __device__ __forceinline__ void fetch(const float* __restrict__ dn, S2Tensor di, int Ho, int Wo, int K, int ch, int u0, int v0,
-                                          const float* __restrict__ wsrc, int w, int lane, const float* __restrict__ dn2 = nullptr,
-                                          const float* __restrict__ coef = nullptr) {
+                                          const float* __restrict__ wsrc, int w, int lane) {
         const int l = lane & 31, sub = lane >> 5;
 #pragma unroll
         for (int it = 0; it < NROW; ++it) {
@@ -370,7 +358,7 @@ struct S2BwdStage {
             if (rr < CK * WR) {
                 const int c = rr / WR, r = rr - c * WR;
                 const int gk = ch * CK + c, gu = u0 - (T0 - 1) + r, gv = v0 - (T0 - 1) + l;
-                if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = element(dn, dn2, coef, gk * di.cs + gu * di.rs + gv, gk);
+                if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = dn[gk * di.cs + gu * di.rs + gv];
             }
             pre_w[it] = v;
         }
@@ -382,7 +370,7 @@ struct S2BwdStage {
                 const int rr = i / XC, cc = 32 + (i - rr * XC);
                 const int c = rr / WR, r = rr - c * WR;
                 const int gk = ch * CK + c, gu = u0 - (T0 - 1) + r, gv = v0 - (T0 - 1) + cc;
-                if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = element(dn, dn2, coef, gk * di.cs + gu * di.rs + gv, gk);
+                if (gk < K && gu >= 0 && gu < Ho && gv >= 0 && gv < Wo) v = dn[gk * di.cs + gu * di.rs + gv];
             }
             pre_x[it] = v;
         }
@@ -673,11 +661,9 @@ extern "C" int nf_conv_s2_bwd_x3(const float* records, const float* dy, int64_t 
 // accumulator tiles.  Per (u, v) position and dy channel this is 16 x 0.5 matrix-core cycles against 49 x 1 in the per-class
 // 32 x 32 form (measured on the stem: 1.30 ms per-class, 0.45 ms merged on 32 x 32 x 2, see DESIGN for this form).
 typedef float s2_f4v __attribute__((ext_vector_type(4)));
-template <bool AFF>
 __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd_stem(const float* __restrict__ rec, const float* __restrict__ dy, S2Tensor di, int Ho,
                                                              int Wo, float* __restrict__ dx, S2Tensor xo, int Hi, int Wi, int C, int K,
-                                                             int tiles_x, int tiles_y, const float* __restrict__ dy2,
-                                                             const float* __restrict__ coef) {
+                                                             int tiles_x, int tiles_y) {
     constexpr int CK = S2_STEM_CK, T0 = 4, WR = 4 + T0 - 1, WCOLS = 32 + T0 - 1, CHF = WR * S2_PW, WIN = CK * CHF, STEPS = (CK / 4) * 16;
     HIP_DYNAMIC_SHARED(float, smem)
     float* win = smem;
@@ -690,21 +676,19 @@ __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd_stem(const float* __rest
     const int u0 = ty * 4, v0 = tx * 32;
     const int chunks = (K + CK - 1) / CK;
     const float* dn = dy + n * di.ns;
-    const float* dn2 = AFF ? dy2 + n * di.ns : nullptr;          // AFF: dy = d_pre, dy2 = x (same strides), coef [n_img][K][4]
-    const float* cf = AFF ? coef + (int64_t)n * K * 4 : nullptr;
     const int bbase = q * CHF + (T0 - 1 + w) * S2_PW + (T0 - 1) + col;
     s2_f4v acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
-    S2BwdStage<CK, WR, WCOLS, T0, STEPS * 64, AFF> stage;
-    stage.fetch(dn, di, Ho, Wo, K, 0, u0, v0, rec, w, lane, dn2, cf);
+    S2BwdStage<CK, WR, WCOLS, T0, STEPS * 64> stage;
+    stage.fetch(dn, di, Ho, Wo, K, 0, u0, v0, rec, w, lane);
     for (int ch = 0; ch < chunks; ++ch) {
         __syncthreads();
         stage.commit(win, wgt, w, lane);
         __syncthreads();
-        if (ch + 1 < chunks) stage.fetch(dn, di, Ho, Wo, K, ch + 1, u0, v0, rec, w, lane, dn2, cf);
+        if (ch + 1 < chunks) stage.fetch(dn, di, Ho, Wo, K, ch + 1, u0, v0, rec, w, lane);
         int s = 0;
 #pragma unroll
         for (int gq = 0; gq < CK / 4; ++gq)
@@ -762,28 +746,11 @@ extern "C" int nf_conv_s2_bwd(const float* records, int ks, const float* dy, int
         NF_REQUIRE(c_in <= 4, "nf_conv_s2_bwd: the 7x7 form takes at most 4 input channels (got %d)", c_in);
         const int tiles_x = ((Wi + 1) / 2 + 31) / 32, tiles_y = ((Hi + 1) / 2 + 3) / 4;
         constexpr size_t smem = sizeof(float) * (S2_STEM_CK * 7 * S2_PW + (S2_STEM_CK / 4) * 16 * 64);
-        hipLaunchKernelGGL(k_conv_s2_bwd_stem<false>, dim3((unsigned)(tiles_x * tiles_y * n_img)), dim3(256), smem, st, records, dy, di, Ho, Wo, dx, xo,
-                           Hi, Wi, c_in, c_out, tiles_x, tiles_y, (const float*)nullptr, (const float*)nullptr);
+        hipLaunchKernelGGL(k_conv_s2_bwd_stem, dim3((unsigned)(tiles_x * tiles_y * n_img)), dim3(256), smem, st, records, dy, di, Ho, Wo, dx, xo,
+                           Hi, Wi, c_in, c_out, tiles_x, tiles_y);
     } else {
         s2_launch_bwd<3>(records, dy, di, Ho, Wo, dx, xo, Hi, Wi, n_img, c_in, c_out, st);
     }
     NF_LAUNCH_CHECK("nf_conv_s2_bwd");
-    return 0;
-}
-
-/* nf_conv_s2_bwd for the 7x7 stem with the InstanceNorm backward's second pass folded into its input staging:
- * dy[n,k,u,v] := coef[n][k][0] d_pre[n,k,u,v] + coef[n][k][1] x[n,k,u,v] + coef[n][k][2]  (d_pre, x: the same strides; coef from
- * nf_in_act_pad_bwd_open).  ref: ibrnet/feature_network.py:188-190 (conv1 -> bn1 -> relu), backward. */
-extern "C" int nf_conv_s2_bwd_stem_affine(const float* records, const float* d_pre, const float* x, const float* coef, int64_t ds_n, int64_t ds_c,
-                                          int64_t ds_h, int Ho, int Wo, float* dx, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi,
-                                          int n_img, int c_in, int c_out, nf_stream_t stream) {
-    NF_REQUIRE(n_img >= 1 && c_in >= 1 && c_in <= 4 && c_out >= 1 && Hi >= 7 && Wi >= 7 && d_pre && x && coef, "nf_conv_s2_bwd_stem_affine: bad arguments");
-    NF_REQUIRE(Ho == (Hi - 7) / 2 + 1 && Wo == (Wi - 7) / 2 + 1, "nf_conv_s2_bwd_stem_affine: gradient %d x %d does not match input %d x %d", Ho, Wo, Hi, Wi);
-    const S2Tensor di{ds_n, ds_c, ds_h}, xo{xs_n, xs_c, xs_h};
-    const int tiles_x = ((Wi + 1) / 2 + 31) / 32, tiles_y = ((Hi + 1) / 2 + 3) / 4;
-    constexpr size_t smem = sizeof(float) * (S2_STEM_CK * 7 * S2_PW + (S2_STEM_CK / 4) * 16 * 64);
-    hipLaunchKernelGGL(k_conv_s2_bwd_stem<true>, dim3((unsigned)(tiles_x * tiles_y * n_img)), dim3(256), smem, (hipStream_t)stream, records, d_pre, di,
-                       Ho, Wo, dx, xo, Hi, Wi, c_in, c_out, tiles_x, tiles_y, x, coef);
-    NF_LAUNCH_CHECK("nf_conv_s2_bwd_stem_affine");
     return 0;
 }

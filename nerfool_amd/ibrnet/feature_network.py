@@ -237,8 +237,6 @@ def _pick(key, candidates, rule):
 # level -- same parity bars as 'fp32'); 'bf16' = plain bf16 operands (BASELINE config 5's opt-in precision, never the default).
 # WINO_OPERANDS is the default for networks that do not ask for 'bf16' (ResUNet.conv_precision); test / diagnostic hook.
 WINO_OPERANDS = 'bf16x3'
-# the stem's InstanceNorm backward: second pass folded into the stem convolution's backward (test / diagnostic hook: False = two passes)
-STEM_NORM_FUSION = True
 _N_SPLIT = {'fp32': 0, 'bf16x3': 3, 'bf16': 1}
 
 
@@ -316,15 +314,6 @@ def _s2_records(conv_w):
 # stride-2 convolutions (7x7 stem, first 3x3 of layer1-3): csrc/nf_conv_s2.hip
 
 
-class _OpenNormGrad:
-    """gradient w.r.t. a convolution output left 'open' by the InstanceNorm behind it: d x = coef[:,0] d_pre + coef[:,1] x + coef[:,2]
-    (ops.in_act_pad_bwd_open); the convolution's backward applies it while it reads"""
-    __slots__ = ('d_pre', 'coef')
-
-    def __init__(self, d_pre, coef):
-        self.d_pre, self.coef = d_pre, coef
-
-
 def _s2_records_x3(conv_w):
     """bf16x3 backward-data records of a stride-2 3x3 weight (csrc/nf_conv_s2.hip: k_conv_s2_bwd3_x3), kept on the weight tensor"""
     key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
@@ -343,9 +332,7 @@ def _conv_s2(tape, inp, w, sink, operands=None):
     x3 = ks == 3 and (operands or WINO_OPERANDS) == 'bf16x3'      # the 3x3 backward-data pass on the split operands (fp32-grade)
 
     def bwd():
-        if isinstance(out.g, _OpenNormGrad):       # the stem: the norm's second backward pass is applied while dy is staged
-            sink(ops.conv_s2_bwd_stem_affine(rb, out.g.d_pre, out.v, out.g.coef, c_in, Hi, Wi))
-        elif x3:
+        if x3:
             sink(ops.conv_s2_bwd_x3(_s2_records_x3(w), out.g, c_in, Hi, Wi))
         else:
             sink(ops.conv_s2_bwd(rb, out.g, c_in, ks, Hi, Wi))
@@ -399,9 +386,7 @@ def _conv1x1(tape, inp, conv, sink, channels_last_out=False):
 TRACE_RELU = None
 
 
-def _fuse(tape, xs, norm, res, act, pad, open_norm=False):
-    """open_norm: the producer of xs applies the norm backward's second pass itself (the 7x7 stem: _conv_s2 / _OpenNormGrad) -- one
-    pass over the 195 MB stem activation less (378 x 504 planes do not fit the plane-resident kernels)"""
+def _fuse(tape, xs, norm, res, act, pad):
     gamma, beta = (norm.weight, norm.bias) if norm is not None else (None, None)
     yp, mean, rstd = ops.in_act_pad_fwd(xs.v, gamma, beta, None if res is None else res.interior(), act, pad,
                                         eps=norm.eps if norm is not None else 0.0)
@@ -410,11 +395,6 @@ def _fuse(tape, xs, norm, res, act, pad, open_norm=False):
         TRACE_RELU.append(a.interior())
 
     def bwd():
-        if open_norm and a.gi is None and xs.g is None:
-            d_pre, coef = ops.in_act_pad_bwd_open(a.gp, xs.v, gamma, beta, mean, rstd, act, pad, d_extra_sub=a.gs)
-            xs.g = _OpenNormGrad(d_pre, coef)
-            a.gp = a.gi = a.gs = None
-            return
         dx, d_res = ops.in_act_pad_bwd(a.gp, a.gi, yp, xs.v if norm is not None else None, gamma, mean, rstd, act, pad,
                                        res is not None, beta=beta, d_extra_sub=a.gs)
         xs.add(dx)
@@ -513,7 +493,7 @@ def fused_forward(net, x, need_grad=True):
         a_in.gp = None
     tape.append(input_bwd)
     t = _conv(tape, a.yp, net.conv1.weight, 2, a.add_p)
-    a = _fuse(tape, t, net.bn1, None, ops.ACT_RELU, 1, open_norm=STEM_NORM_FUSION and tuple(net.conv1.weight.shape[1:]) == (3, 7, 7))
+    a = _fuse(tape, t, net.bn1, None, ops.ACT_RELU, 1)
     feats = []
     for layer in (net.layer1, net.layer2, net.layer3):
         for blk in layer:

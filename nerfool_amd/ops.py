@@ -520,39 +520,6 @@ def in_act_pad_bwd(dyp, d_extra, yp, x, gamma, mean, rstd, act, pad, want_d_res,
     return dx, d_res
 
 
-def in_act_pad_bwd_open(dyp, x, gamma, beta, mean, rstd, act, pad, d_extra_sub=None):
-    """first pass of in_act_pad_bwd only (normalised layer, no residual): -> (d_pre [N,C,H,W], coef [N*C,4]) with
-    d x = coef[:,0] d_pre + coef[:,1] x + coef[:,2] per plane, applied by conv_s2_bwd_stem_affine while it reads"""
-    _f32(dyp, 'dy_padded')
-    x = _c(x, 'x')
-    N, C, H, W = x.shape
-    Hp, Wp = H + 2 * pad, W + 2 * pad
-    if tuple(dyp.shape) != (N, C, Hp, Wp):
-        raise ValueError('dy_padded shape %s does not match %s' % (tuple(dyp.shape), (N, C, Hp, Wp)))
-    dyp = dyp.contiguous()
-    if d_extra_sub is not None:
-        d_extra_sub = _c(d_extra_sub, 'd_extra_sub')
-    d_pre = torch.empty_like(x)
-    coef = torch.empty(N * C, 4, dtype=torch.float32, device=x.device)
-    scratch = torch.empty(N * C * 64, dtype=torch.float64, device=x.device)
-    with prof.launch('nf_in_act_pad_bwd', x, n=x.numel()):
-        _launch(_lib.lib().nf_in_act_pad_bwd_open, 'nf_in_act_pad_bwd_open', x, _ptr(dyp), None, _ptr(x), N, C, H, W, _ptr(gamma), _ptr(beta),
-                _ptr(mean), _ptr(rstd), int(act), int(pad), _ptr(d_pre), _ptr(coef), _ptr(scratch), 0, _ptr(d_extra_sub))
-    return d_pre, coef
-
-
-def conv_s2_bwd_stem_affine(records, d_pre, x, coef, c_in, Hi, Wi):
-    """backward-data of the 7x7 stem on dy = coef[:,0] d_pre + coef[:,1] x + coef[:,2] (in_act_pad_bwd_open): -> dx [N, c_in, Hi, Wi]"""
-    d_pre, x = _c(d_pre, 'd_pre'), _c(x, 'x')
-    N, c_out, Ho, Wo = d_pre.shape
-    dx = torch.empty(N, c_in, Hi, Wi, dtype=torch.float32, device=d_pre.device)
-    ds, xs = d_pre.stride(), dx.stride()
-    with prof.launch('nf_conv_s2_bwd', d_pre, n_img=N, c_in=c_in, c_out=c_out, ks=7, Ho=Ho, Wo=Wo):
-        _launch(_lib.lib().nf_conv_s2_bwd_stem_affine, 'nf_conv_s2_bwd_stem_affine', d_pre, _ptr(records), _ptr(d_pre), _ptr(x), _ptr(coef), ds[0], ds[1],
-                ds[2], Ho, Wo, _ptr(dx), xs[0], xs[1], xs[2], Hi, Wi, N, c_in, c_out)
-    return dx
-
-
 def conv1x1_pack(weight, transposed, device):
     """weight [c_out, c_in(, 1, 1)] -> MFMA records of nf_conv1x1 (transposed: the backward-data GEMM)"""
     L = _lib.lib()
