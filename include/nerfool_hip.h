@@ -264,11 +264,13 @@ int nf_conv_s2_fwd(const float* records, int ks, const float* x, int64_t xs_n, i
                    int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out, nf_stream_t stream);
 int nf_conv_s2_bwd(const float* records, int ks, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int Ho, int Wo, float* dx,
                    int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, int n_img, int c_in, int c_out, nf_stream_t stream);
-/* nf_conv_s2_bwd for the 3x3 convolutions on the BF16 matrix cores, every fp32 operand as three bf16 parts (six cross terms, error at
- * fp32 rounding level; ref ibrnet/feature_network.py:192-195 via :51, backward).  records = nf_conv_s2_x3_pack(weight [c_out][c_in][3][3])
- * (HOST pointers, nf_conv_s2_x3_pack_floats floats). */
-int64_t nf_conv_s2_x3_pack_floats(int c_out, int c_in);
-int nf_conv_s2_x3_pack(const float* weight_host, int c_out, int c_in, float* records_host);
+/* nf_conv_s2_fwd / nf_conv_s2_bwd for the 3x3 convolutions on the BF16 matrix cores, every fp32 operand as three bf16 parts (six cross
+ * terms, error at fp32 rounding level; ref ibrnet/feature_network.py:192-195 via :51).  records = nf_conv_s2_x3_pack(weight
+ * [c_out][c_in][3][3], backward) (HOST pointers, nf_conv_s2_x3_pack_floats floats; backward = 0: forward records). */
+int64_t nf_conv_s2_x3_pack_floats(int c_out, int c_in, int backward);
+int nf_conv_s2_x3_pack(const float* weight_host, int c_out, int c_in, int backward, float* records_host);
+int nf_conv_s2_fwd_x3(const float* records, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, float* y, int64_t ys_n,
+                      int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out, nf_stream_t stream);
 int nf_conv_s2_bwd_x3(const float* records, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int Ho, int Wo, float* dx, int64_t xs_n,
                       int64_t xs_c, int64_t xs_h, int Hi, int Wi, int n_img, int c_in, int c_out, nf_stream_t stream);
 

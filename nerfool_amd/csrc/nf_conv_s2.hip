@@ -501,13 +501,46 @@ static inline uint16_t s2_rne(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-extern "C" int64_t nf_conv_s2_x3_pack_floats(int c_out, int c_in) {
-    return (int64_t)((c_in + 31) / 32) * ((c_out + 15) / 16) * S2_X3_CHUNK_FLOATS;
+#define S2_X3_FWD_TP 5                                       // tap pairs of the 3 x 3 kernel (the tenth tap has zero weights)
+#define S2_X3_FWD_CHUNK_FLOATS (S2_X3_FWD_TP * 2 * 3 * 256)  // forward: [tap pair][channel tile 2][part 3][lane][8 bf16]
+
+extern "C" int64_t nf_conv_s2_x3_pack_floats(int c_out, int c_in, int backward) {
+    if (backward) return (int64_t)((c_in + 31) / 32) * ((c_out + 15) / 16) * S2_X3_CHUNK_FLOATS;
+    return (int64_t)((c_out + 63) / 64) * ((c_in + 7) / 8) * S2_X3_FWD_CHUNK_FLOATS;
 }
 
 /* HOST: weight [c_out][c_in][3][3] -> bf16x3 records of the backward-data pass (see above); lane (c = 32 g + (lane & 31), h = lane >> 5),
  * element j <-> dy channel k = 16 chunk + 2 j + h; tap a = 2 i + ya, b = 2 jj + xb */
-extern "C" int nf_conv_s2_x3_pack(const float* weight, int c_out, int c_in, float* out) {
+static void s2_x3_emit(uint16_t* piece, int lane, int j, float v) {
+    float rem = v;
+    for (int p = 0; p < 3; ++p) {
+        const uint16_t q = s2_rne(rem);
+        piece[(size_t)p * 512 + lane * 8 + j] = q;
+        const uint32_t u = (uint32_t)q << 16;
+        float up;
+        memcpy(&up, &u, 4);
+        rem -= up;
+    }
+}
+
+/* forward records (backward = 0): [group of 64 outputs][chunk of 8 inputs][tap pair tp][tile t][part][lane (i, h)][8 bf16], element j
+ * <-> input channel 8 chunk + 2 (j >> 1) + h and tap 2 tp + (j & 1) (tap = 3 a + b; tap 9: zero) of output 64 g + 32 t + i */
+extern "C" int nf_conv_s2_x3_pack(const float* weight, int c_out, int c_in, int backward, float* out) {
+    if (!backward) {
+        const int groups = (c_out + 63) / 64, chunks = (c_in + 7) / 8;
+        uint16_t* piece = reinterpret_cast<uint16_t*>(out);
+        for (int g = 0; g < groups; ++g)
+            for (int ch = 0; ch < chunks; ++ch)
+                for (int tp = 0; tp < S2_X3_FWD_TP; ++tp)
+                    for (int t = 0; t < 2; ++t, piece += 3 * 512)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int k = 64 * g + 32 * t + (lane & 31), c = 8 * ch + 2 * (j >> 1) + (lane >> 5), tap = 2 * tp + (j & 1);
+                                const float v = (k < c_out && c < c_in && tap < 9) ? weight[((size_t)k * c_in + c) * 9 + tap] : 0.f;
+                                s2_x3_emit(piece, lane, j, v);
+                            }
+        return (reinterpret_cast<float*>(piece) - out) == nf_conv_s2_x3_pack_floats(c_out, c_in, 0) ? 0 : 2;
+    }
     const int groups = (c_in + 31) / 32, chunks = (c_out + 15) / 16;
     uint16_t* piece = reinterpret_cast<uint16_t*>(out);
     for (int g = 0; g < groups; ++g)
@@ -529,7 +562,7 @@ extern "C" int nf_conv_s2_x3_pack(const float* weight, int c_out, int c_in, floa
                                         rem -= up;
                                     }
                                 }
-    return (reinterpret_cast<float*>(piece) - out) == nf_conv_s2_x3_pack_floats(c_out, c_in) ? 0 : 2;
+    return (reinterpret_cast<float*>(piece) - out) == nf_conv_s2_x3_pack_floats(c_out, c_in, 1) ? 0 : 2;
 }
 
 __device__ __forceinline__ unsigned s2_split_pair(float& x0, float& x1) {
@@ -639,6 +672,217 @@ __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd3_x3(const float* __restr
             }
         }
     }
+}
+
+// ---- forward of the stride-2 3x3 convolutions on bf16x3 operands.  Geometry, window staging (de-interleaved by column parity) and
+// output stage of k_conv_s2_fwd<3, RPW>; a chunk is 8 input channels, a k-block of the bf16 instruction = one PAIR of taps x the 4
+// channels of the lane half's parity (five blocks per chunk, the tenth tap slot carries zero weights): per block and output row a
+// lane gathers its 8 window values (immediate LDS offsets), splits them once and multiplies with the parts of both channel tiles.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define S2_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#else
+#define S2_OPAQUE_S(x) asm volatile("" : "+r"(x))
+#endif
+template <int RPW>
+__global__ void __launch_bounds__(256, 2) k_conv_s2_fwd3_x3(const float* __restrict__ rec, const float* __restrict__ x, S2Tensor xi, int Hi, int Wi,
+                                                            float* __restrict__ y, S2Tensor yo, int Ho, int Wo, int C, int K, int groups,
+                                                            int tiles_x, int tiles_y) {
+    using G = S2Fwd<3>;
+    using L = S2FwdLds<3, RPW>;
+    constexpr int CC = G::CC, WR = L::WR, WC = G::WC, ROWF = 2 * S2_PW, CHF = WR * ROWF, WFL = S2_X3_FWD_CHUNK_FLOATS;
+    static_assert(CC == 8, "four channel pairs per k-block");
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* win = smem;
+    float* wgt = smem + L::WIN;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int grp = bid % groups;
+    bid /= groups;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, n = bid / tiles_y;
+    const int oy0 = ty * (4 * RPW), ox0 = tx * 32;
+    const int iy0 = 2 * oy0, ix0 = 2 * ox0;
+    const int chunks = (C + CC - 1) / CC;
+    const float* xn = x + n * xi.ns;
+    const float* wsrc = rec + (size_t)grp * chunks * WFL;
+    const int bbase = h * CHF + (2 * RPW * w) * ROWF + j;
+    const bool pair_ok = ((xi.ns | xi.cs | xi.rs) & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+
+    s2_f16 acc[RPW][2];
+#pragma unroll
+    for (int b = 0; b < RPW; ++b)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
+
+    constexpr int NROW = (CC * WR + 7) / 8;
+    constexpr int XC = WC - 64, NXC = (CC * WR * XC + 255) / 256;
+    constexpr int NWG = (WFL / 4 + 255) / 256;                    // 16-byte weight pieces per thread
+    s2_f2 pre_w[NROW];
+    float pre_x[NXC];
+    s2_f4 pre_g[NWG];
+    const int l32 = lane & 31, sub = lane >> 5;
+    auto fetch = [&](int ch) {
+        S2_OPAQUE_S(ch);      // addresses from the chunk index every time: no per-piece pointer kept across the chunk loop
+#pragma unroll
+        for (int it = 0; it < NROW; ++it) {
+            const int rr = it * 8 + 2 * w + sub;
+            s2_f2 v = {0.f, 0.f};
+            if (rr < CC * WR) {
+                const int c = rr / WR, r = rr - c * WR;
+                const int gc = ch * CC + c, gy = iy0 + r, gx = ix0 + 2 * l32;
+                if (gc < C && gy < Hi) {
+                    const float* src = xn + gc * xi.cs + gy * xi.rs + gx;
+                    if (pair_ok && gx + 1 < Wi) v = *reinterpret_cast<const s2_f2*>(src);
+                    else {
+                        if (gx < Wi) v[0] = src[0];
+                        if (gx + 1 < Wi) v[1] = src[1];
+                    }
+                }
+            }
+            pre_w[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NXC; ++it) {
+            const int i = it * 256 + threadIdx.x;
+            float v = 0.f;
+            if (i < CC * WR * XC) {
+                const int rr = i / XC, col = 64 + (i - rr * XC);
+                const int c = rr / WR, r = rr - c * WR;
+                const int gc = ch * CC + c, gy = iy0 + r, gx = ix0 + col;
+                if (gc < C && gy < Hi && gx < Wi) v = xn[gc * xi.cs + gy * xi.rs + gx];
+            }
+            pre_x[it] = v;
+        }
+        const s2_f4* src = reinterpret_cast<const s2_f4*>(wsrc + (size_t)ch * WFL);
+#pragma unroll
+        for (int it = 0; it < NWG; ++it) {
+            const int i = it * 256 + threadIdx.x;
+            pre_g[it] = i < WFL / 4 ? src[i] : s2_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int it = 0; it < NROW; ++it) {
+            const int rr = it * 8 + 2 * w + sub;
+            if (rr < CC * WR) {
+                const int c = rr / WR, r = rr - c * WR;
+                float* dst = win + c * CHF + r * ROWF + l32;
+                dst[0] = pre_w[it][0];
+                dst[S2_PW] = pre_w[it][1];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NXC; ++it) {
+            const int i = it * 256 + threadIdx.x;
+            if (i < CC * WR * XC) {
+                const int rr = i / XC, col = 64 + (i - rr * XC);
+                const int c = rr / WR, r = rr - c * WR;
+                win[c * CHF + r * ROWF + (col & 1) * S2_PW + (col >> 1)] = pre_x[it];
+            }
+        }
+        s2_f4* dst = reinterpret_cast<s2_f4*>(wgt);
+#pragma unroll
+        for (int it = 0; it < NWG; ++it) {
+            const int i = it * 256 + threadIdx.x;
+            if (i < WFL / 4) dst[i] = pre_g[it];
+        }
+    };
+    fetch(0);
+    for (int ch = 0; ch < chunks; ++ch) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (ch + 1 < chunks) fetch(ch + 1);
+#pragma unroll
+        for (int tp = 0; tp < S2_X3_FWD_TP; ++tp) {
+            // taps 2 tp and 2 tp + 1 (tap = 3 a + bb; the tenth does not exist: zero weights, value 0)
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int t0 = 2 * tp, t1 = 2 * tp + 1;
+            const int ta0 = t0 / 3, tb0 = t0 - 3 * ta0, ta1 = t1 / 3, tb1 = t1 - 3 * ta1;
+            s2_u4 av[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) av[t][q] = *reinterpret_cast<const s2_u4*>(wgt + ((tp * 2 + t) * 3 + q) * 256 + 4 * lane);
+#pragma unroll
+            for (int b = 0; b < RPW; ++b) {
+                s2_u4 bv[3];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {      // channel 2 p + h
+                    float v0 = win[bbase + 2 * p * CHF + ta0 * ROWF + (tb0 & 1) * S2_PW + (tb0 >> 1) + 2 * b * ROWF];
+                    float v1 = t1 < 9 ? win[bbase + 2 * p * CHF + ta1 * ROWF + (tb1 & 1) * S2_PW + (tb1 >> 1) + 2 * b * ROWF] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bv[q][p] = s2_split_pair(v0, v1);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#define S2_PROD(qa, qb) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s2_bf8, av[t][qa]), __builtin_bit_cast(s2_bf8, bv[qb]), acc[b][t], 0, 0, 0)
+                    S2_PROD(0, 0);
+                    S2_PROD(0, 1);
+                    S2_PROD(1, 0);
+                    S2_PROD(0, 2);
+                    S2_PROD(2, 0);
+                    S2_PROD(1, 1);
+#undef S2_PROD
+                }
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    }
+    float* yn = y + n * yo.ns;
+    const int ox = ox0 + j;
+#pragma unroll
+    for (int b = 0; b < RPW; ++b) {
+        const int oy = oy0 + RPW * w + b;
+        if (oy < Ho && ox < Wo) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = 64 * grp + 32 * t + s2_nidx(r, h);
+                    if (k < K) yn[k * yo.cs + oy * yo.rs + ox] = acc[b][t][r];
+                }
+        }
+    }
+}
+
+template <int RPW>
+static int s2_launch_fwd3_x3(const float* rec, const float* x, S2Tensor xi, int Hi, int Wi, float* y, S2Tensor yo, int Ho, int Wo, int n_img,
+                             int C, int K, hipStream_t st) {
+    const int tiles_x = (Wo + 31) / 32, tiles_y = (Ho + 4 * RPW - 1) / (4 * RPW), groups = (K + 63) / 64;
+    constexpr size_t smem = sizeof(float) * (S2FwdLds<3, RPW>::WIN + S2_X3_FWD_CHUNK_FLOATS);
+    static bool once_on[NF_MAX_DEVICES] = {};
+    bool& once = once_on[nf_current_device()];
+    if (!once) {
+        if (smem > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)k_conv_s2_fwd3_x3<RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            nf_set_error("nf_conv_s2_fwd_x3: cannot reserve %zu bytes of LDS", smem);
+            return 1;
+        }
+        once = true;
+    }
+    hipLaunchKernelGGL((k_conv_s2_fwd3_x3<RPW>), dim3((unsigned)(tiles_x * tiles_y * n_img * groups)), dim3(256), smem, st, rec, x, xi, Hi, Wi, y,
+                       yo, Ho, Wo, C, K, groups, tiles_x, tiles_y);
+    return 0;
+}
+
+/* nf_conv_s2_fwd for ks = 3 on the bf16 matrix cores with three-way split operands (fp32-grade); records: nf_conv_s2_x3_pack(..., 0) */
+extern "C" int nf_conv_s2_fwd_x3(const float* records, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, float* y,
+                                 int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out, nf_stream_t stream) {
+    NF_REQUIRE(n_img >= 1 && c_in >= 1 && c_out >= 1 && Hi >= 3 && Wi >= 3, "nf_conv_s2_fwd_x3: bad arguments");
+    NF_REQUIRE(Ho == (Hi - 3) / 2 + 1 && Wo == (Wi - 3) / 2 + 1, "nf_conv_s2_fwd_x3: output %d x %d does not match input %d x %d", Ho, Wo, Hi, Wi);
+    const S2Tensor xi{xs_n, xs_c, xs_h}, yo{ys_n, ys_c, ys_h};
+    // one output row per wave (three waves per SIMD): measured faster than two rows (256 registers, spills) at every layer of config 2
+    const int rc = s2_launch_fwd3_x3<1>(records, x, xi, Hi, Wi, y, yo, Ho, Wo, n_img, c_in, c_out, (hipStream_t)stream);
+    if (rc) return rc;
+    NF_LAUNCH_CHECK("nf_conv_s2_fwd_x3");
+    return 0;
 }
 
 /* nf_conv_s2_bwd for ks = 3 on the bf16 matrix cores with three-way split operands (fp32-grade); records: nf_conv_s2_x3_pack */

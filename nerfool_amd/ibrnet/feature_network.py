@@ -315,25 +315,30 @@ def _s2_records(conv_w):
 
 
 def _s2_records_x3(conv_w):
-    """bf16x3 backward-data records of a stride-2 3x3 weight (csrc/nf_conv_s2.hip: k_conv_s2_bwd3_x3), kept on the weight tensor"""
+    """bf16x3 (forward, backward-data) records of a stride-2 3x3 weight (csrc/nf_conv_s2.hip: k_conv_s2_fwd3_x3 / k_conv_s2_bwd3_x3),
+    kept on the weight tensor"""
     key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
     cache = getattr(conv_w, '_nf_s2_x3', None)
     if cache is None or cache[0] != key:
-        cache = (key, ops.conv_s2_pack_x3(conv_w, conv_w.device))
+        cache = (key, ops.conv_s2_pack_x3(conv_w, False, conv_w.device), ops.conv_s2_pack_x3(conv_w, True, conv_w.device))
         conv_w._nf_s2_x3 = cache
-    return cache[1]
+    return cache[1], cache[2]
 
 
 def _conv_s2(tape, inp, w, sink, operands=None):
     c_out, c_in, ks = w.shape[0], w.shape[1], w.shape[2]
-    rf, rb = _s2_records(w)
-    out = _Slot(ops.conv_s2_fwd(rf, inp, c_out, ks))
+    x3 = ks == 3 and (operands or WINO_OPERANDS) == 'bf16x3'      # the 3x3 passes on the split operands (fp32-grade)
+    if x3:
+        rf, rb = _s2_records_x3(w)
+        out = _Slot(ops.conv_s2_fwd_x3(rf, inp, c_out))
+    else:
+        rf, rb = _s2_records(w)
+        out = _Slot(ops.conv_s2_fwd(rf, inp, c_out, ks))
     Hi, Wi = inp.shape[2], inp.shape[3]
-    x3 = ks == 3 and (operands or WINO_OPERANDS) == 'bf16x3'      # the 3x3 backward-data pass on the split operands (fp32-grade)
 
     def bwd():
         if x3:
-            sink(ops.conv_s2_bwd_x3(_s2_records_x3(w), out.g, c_in, Hi, Wi))
+            sink(ops.conv_s2_bwd_x3(rb, out.g, c_in, Hi, Wi))
         else:
             sink(ops.conv_s2_bwd(rb, out.g, c_in, ks, Hi, Wi))
         out.g = None

@@ -646,14 +646,29 @@ def conv_s2_bwd(records, dy, c_in, ks, Hi, Wi):
     return dx
 
 
-def conv_s2_pack_x3(weight, device):
-    """weight [c_out, c_in, 3, 3] -> bf16x3 records of the stride-2 backward-data pass (nf_conv_s2_bwd_x3)"""
+def conv_s2_pack_x3(weight, backward, device):
+    """weight [c_out, c_in, 3, 3] -> bf16x3 records of the stride-2 forward (nf_conv_s2_fwd_x3) or backward-data pass (nf_conv_s2_bwd_x3)"""
     L = _lib.lib()
     w = weight.detach().to('cpu', torch.float32).contiguous()
     assert tuple(w.shape[2:]) == (3, 3)
-    out = torch.empty(L.nf_conv_s2_x3_pack_floats(w.shape[0], w.shape[1]), dtype=torch.float32)
-    _lib.check(L.nf_conv_s2_x3_pack(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr()), 'nf_conv_s2_x3_pack')
+    out = torch.empty(L.nf_conv_s2_x3_pack_floats(w.shape[0], w.shape[1], int(bool(backward))), dtype=torch.float32)
+    _lib.check(L.nf_conv_s2_x3_pack(w.data_ptr(), w.shape[0], w.shape[1], int(bool(backward)), out.data_ptr()), 'nf_conv_s2_x3_pack')
     return out.to(device)
+
+
+def conv_s2_fwd_x3(records, x, c_out):
+    """conv_s2_fwd for ks = 3 on the bf16 matrix cores with three-way split operands (fp32-grade)"""
+    _f32(x, 'x')
+    if x.stride(3) != 1:
+        x = x.contiguous()
+    N, c_in, Hi, Wi = x.shape
+    Ho, Wo = (Hi - 3) // 2 + 1, (Wi - 3) // 2 + 1
+    y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
+    xs, ys = x.stride(), y.stride()
+    with prof.launch('nf_conv_s2_fwd', x, n_img=N, c_in=c_in, c_out=c_out, ks=3, Ho=Ho, Wo=Wo, n_split=3):
+        _launch(_lib.lib().nf_conv_s2_fwd_x3, 'nf_conv_s2_fwd_x3', x, _ptr(records), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, _ptr(y), ys[0], ys[1],
+                ys[2], Ho, Wo, N, c_in, c_out)
+    return y
 
 
 def conv_s2_bwd_x3(records, dy, c_in, Hi, Wi):

@@ -1369,7 +1369,7 @@ def check_conv_s2(dev, shapes=None):
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(11)
     shapes = shapes or ((1, 64, 64, 3, 21, 25), (2, 16, 64, 3, 38, 70), (1, 3, 64, 7, 29, 41), (1, 64, 128, 3, 12, 17),
-                        (2, 3, 64, 7, 75, 139), (1, 128, 256, 3, 33, 66), (1, 24, 40, 3, 19, 23))
+                        (2, 3, 64, 7, 75, 139), (1, 128, 256, 3, 33, 66), (1, 24, 40, 3, 19, 23), (8, 8, 128, 3, 131, 259))
     for (N, cin, cout, ks, Hi, Wi) in shapes:
         x = torch.randn(N, cin, Hi, Wi, generator=gen)
         w = torch.randn(cout, cin, ks, ks, generator=gen) * 0.1
@@ -1383,16 +1383,21 @@ def check_conv_s2(dev, shapes=None):
         ef = float((y.cpu().double() - ref.detach()).abs().max() / ref.abs().max())
         eb = float((dx.cpu().double() - gref).abs().max() / gref.abs().max())
         assert ef <= 5e-6 and eb <= 5e-6, ('conv_s2', N, cin, cout, ks, Hi, Wi, ef, eb)
-        if ks == 3:      # the backward-data pass on the bf16 matrix cores with three-way split operands: the same float64 bar
-            dx3 = ops.conv_s2_bwd_x3(ops.conv_s2_pack_x3(w, dev), g.to(dev), cin, Hi, Wi)
+        if ks == 3:      # both passes on the bf16 matrix cores with three-way split operands: the same float64 bar
+            y3 = ops.conv_s2_fwd_x3(ops.conv_s2_pack_x3(w, False, dev), x.to(dev), cout)
+            dx3 = ops.conv_s2_bwd_x3(ops.conv_s2_pack_x3(w, True, dev), g.to(dev), cin, Hi, Wi)
+            ef3 = float((y3.cpu().double() - ref.detach()).abs().max() / ref.abs().max())
             eb3 = float((dx3.cpu().double() - gref).abs().max() / gref.abs().max())
-            assert eb3 <= 5e-6, ('conv_s2 bf16x3 backward', N, cin, cout, Hi, Wi, eb3)
+            assert ef3 <= 5e-6 and eb3 <= 5e-6, ('conv_s2 bf16x3', N, cin, cout, Hi, Wi, ef3, eb3)
         # a strided (non-contiguous) input view: the executor hands the kernel interior views of padded buffers
         big = torch.randn(N, cin, Hi + 3, Wi + 4, generator=gen).to(dev)
         view = big[:, :, 1:1 + Hi, 2:2 + Wi]
         y2 = ops.conv_s2_fwd(rf, view, cout, ks)
         ref2 = F.conv2d(view.cpu().double(), w.double(), stride=2)
         assert float((y2.cpu().double() - ref2).abs().max() / ref2.abs().max()) <= 5e-6
+        if ks == 3:
+            y2 = ops.conv_s2_fwd_x3(ops.conv_s2_pack_x3(w, False, dev), view, cout)
+            assert float((y2.cpu().double() - ref2).abs().max() / ref2.abs().max()) <= 5e-6
 
 
 def check_pad_glue(dev):

@@ -1,11 +1,15 @@
 """The stride-2 direct convolutions (csrc/nf_conv_s2.hip) against MIOpen on the four layers of the ResUNet at BASELINE config 2
-(4 images 756 x 1008): time per call and accuracy against a float64 CPU convolution (small crop).  usage: python tools/bench_conv_s2.py"""
+(4 images 756 x 1008): time per call and accuracy against a float64 CPU convolution (small crop).  usage: python tools/bench_conv_s2.py [library.so]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F
 from nerfool_amd import ops
+if len(sys.argv) > 1:      # a tuning build (tools/build_variant.sh)
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'host_harness'))
+    import standin
+    standin.use_library(sys.argv[1], False)
 
 aten = torch.ops.aten
 
@@ -43,10 +47,14 @@ for (cin, cout, ks, Hi, Wi) in ((3, 64, 7, 762, 1014), (64, 64, 3, 380, 506), (6
     gref, = torch.autograd.grad(yc, xc, gc.cpu().double())
     eb = float((ops.conv_s2_bwd(rb, gc, cin, ks, 41, 73).cpu().double() - gref).abs().max() / gref.abs().max())
     if ks == 3:
-        r3 = ops.conv_s2_pack_x3(w, 'cuda')
+        r3 = ops.conv_s2_pack_x3(w, True, 'cuda')
         t_3, d3 = timed(lambda: ops.conv_s2_bwd_x3(r3, g, cin, Hi, Wi))
         e3 = float((ops.conv_s2_bwd_x3(r3, gc, cin, 41, 73).cpu().double() - gref).abs().max() / gref.abs().max())
         print('      bf16x3 backward-data: %6.1f us (fp32 operands %6.1f us), err vs float64 %.1e' % (t_3, t_ob, e3))
+        f3 = ops.conv_s2_pack_x3(w, False, 'cuda')
+        t_f3, _ = timed(lambda: ops.conv_s2_fwd_x3(f3, x, cout))
+        ef3 = float((ops.conv_s2_fwd_x3(f3, x[:1, :, :41, :73].contiguous(), cout).cpu().double() - yc).abs().max() / yc.abs().max())
+        print('      bf16x3 forward:       %6.1f us (fp32 operands %6.1f us), err vs float64 %.1e' % (t_f3, t_o, ef3))
     print('%3d -> %3d %dx%d s2 at %dx%d: fwd MIOpen %6.1f us  own %6.1f us (%.1f TFLOP/s) | bwd-data MIOpen %6.1f us  own %6.1f us (%.1f TFLOP/s) | '
           'err fwd %.1e bwd %.1e | own vs MIOpen %.1e %.1e'
           % (cin, cout, ks, ks, Hi, Wi, t_m, t_o, fl / t_o / 1e6, t_mb, t_ob, fl / t_ob / 1e6, ef, eb,
