@@ -101,6 +101,38 @@ __device__ __forceinline__ unsigned wb_split_pair(float& x0, float& x1) {
 #endif
 }
 
+#define NF_LAUNDER_WB(x) asm volatile("" : "+v"(x))
+#ifdef WB_PHASE_TIMERS
+// TUNING BUILD ONLY (NF_VARIANT_SRC=nf_wino_bf.hip tools/build_variant.sh <name> -DWB_PHASE_TIMERS; tools/experimental/wino_phases.py):
+// s_memtime ticks a wave spends in the phases of a chunk, one row per wave (no atomics: they would jam the memory path)
+// [0] chunks, [1] whole chunk, [2] window reads + row combination (E), [3] waits for streamed records, [4] window hand-over + barrier,
+// [6] one timer's own cost (two back-to-back readings), [7] prologue, [8] output stage
+#define WB_PH_SLOTS 32768
+__device__ unsigned long long wb_phase[WB_PH_SLOTS * 16];
+__device__ __forceinline__ unsigned long long wb_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+extern "C" int nf_wino_bf_phase_read(unsigned long long* out16, int reset) {
+    static unsigned long long host[WB_PH_SLOTS * 16];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(wb_phase), sizeof(host)) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (int r = 0; r < WB_PH_SLOTS; ++r)
+        for (int i = 0; i < 16; ++i) out16[i] += host[r * 16 + i];
+    if (reset) {
+        memset(host, 0, sizeof(host));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(wb_phase), host, sizeof(host)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#define WB_T(var) const unsigned long long var = wb_now()
+#define WB_ACC(i, d) ph[i] += (d)
+#else
+#define WB_T(var)
+#define WB_ACC(i, d)
+#endif
+
 template <int KB, int NS>
 __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__ rec, const float* __restrict__ x, WnTensor xi, int Hi, int Wi,
                                                         int pad, float* __restrict__ y, WnTensor yo, int Ho, int Wo, int C, int K, int groups, int n_img) {
@@ -191,6 +223,10 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][kb][r] = 0.f;
+#ifdef WB_PHASE_TIMERS
+    unsigned long long ph[9] = {};
+#endif
+    WB_T(t_begin);
 
     // ---- weight ring: a step = NS pieces of 1 KB under one M0 set-up, issued DIST steps ahead of their use
     const float* wnext = wsrc;
@@ -224,10 +260,17 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
     commit(0);          // the compiler drains the VM counter for the fetched registers here: the first DIST steps have landed too
     __syncthreads();
     read_a(opa[0], 0);
+    WB_T(t_pro);
+    WB_ACC(7, t_pro - t_begin);
 
     auto run_chunk = [&](auto last_c, int chunk) {
         constexpr bool last = decltype(last_c)::value;
         const float* pbuf = smem + (chunk & 1) * WN_BUF + lbase;
+        WB_T(t_c0);
+        {
+            WB_T(t_c0b);
+            WB_ACC(6, t_c0b - t_c0);
+        }
         // ---- this chunk's window rows -> the four row-combined values of the lane's 8 channels (channel 2 j + hh)
         float E[8][4];
 #pragma unroll
@@ -242,6 +285,14 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
             // sb = +-1: the fused form is exact
             E[j][0] = fmaf(sb, b0[0], a0[0]), E[j][1] = fmaf(sb, b0[1], a0[1]), E[j][2] = fmaf(sb, b1[0], a1[0]), E[j][3] = fmaf(sb, b1[1], a1[1]);
         }
+#ifdef WB_PHASE_TIMERS
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) NF_LAUNDER_WB(E[j][i]);
+#endif
+        WB_T(t_e);
+        WB_ACC(2, t_e - t_c0);
         // the next chunk's window travels global -> registers under this chunk's products, -> LDS in front of the last step
 #ifndef WB_EXP_NO_FETCH
         if (!last) fetch(chunk + 1);
@@ -270,16 +321,20 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                 const int s = nu * KB + kb;           // compile-time after unrolling
                 // the chunk hand-over sits in front of the last step, as in nf_wino.hip
                 if (s == NSTEP - 1 && !last) {
+                    WB_T(t_h0);
 #ifndef WB_EXP_NO_FETCH
                     commit(chunk + 1);
 #endif
 #ifndef WB_EXP_NO_BARRIER
                     __syncthreads();
 #endif
+                    WB_T(t_h1);
+                    WB_ACC(4, t_h1 - t_h0);
                 }
                 // [A] records of step s + DIST; never past the end of the stream
                 if (!last || s + DIST < NSTEP) issue_step(s + DIST);
                 if (!last || s < NSTEP - 1) {
+                    WB_T(t_w0);
                     // [C] the records of step s + 1 were issued DIST - 1 steps ago; behind them in the counter: the steps issued since
                     // (fewer at the end of the stream) and, while the window fetch of this chunk is younger than them, its 6 loads (the
                     // fetch is issued at the top of the chunk, IN FRONT of step 0's refill: it is younger than the records of steps
@@ -299,6 +354,8 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                         else if (left == 1) wn_wait_vm<PCS>();
                         else wn_wait_vm<0>();
                     }
+                    WB_T(t_w1);
+                    WB_ACC(3, t_w1 - t_w0);
                     // [D] next step's A parts
                     read_a(opa[(s + 1) & 1], s + 1);
                 }
@@ -316,9 +373,13 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
 #undef WB_PROD
             }
         }
+        WB_T(t_c1);
+        WB_ACC(1, t_c1 - t_c0);
+        WB_ACC(0, 1);
     };
     for (int chunk = 0; chunk + 1 < chunks; ++chunk) run_chunk(std::false_type{}, chunk);
     run_chunk(std::true_type{}, chunks - 1);
+    WB_T(t_out0);
     __syncthreads();
     // ---- output transform Y = A^T M A: identical to nf_wino.hip
     const int kbase = grp * (32 * KB);
@@ -367,6 +428,15 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
             }
         }
     }
+#ifdef WB_PHASE_TIMERS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WB_T(t_out1);
+    WB_ACC(8, t_out1 - t_out0);
+    if (lane == 0) {
+        unsigned long long* row = wb_phase + (size_t)((blockIdx.x * 4 + w) % WB_PH_SLOTS) * 16;
+        for (int i = 0; i < 9; ++i) row[i] += ph[i];
+    }
+#endif
 }
 
 template <int KB, int NS>
