@@ -271,6 +271,12 @@ int64_t nf_conv_s2_x3_pack_floats(int c_out, int c_in, int backward);
 int nf_conv_s2_x3_pack(const float* weight_host, int c_out, int c_in, int backward, float* records_host);
 int nf_conv_s2_fwd_x3(const float* records, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, float* y, int64_t ys_n,
                       int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out, nf_stream_t stream);
+/* the 7x7 stem (c_in <= 3) forward on the same operand split: records = nf_conv_s2_stem_x3_pack(weight [c_out][c_in][7][7]) (HOST pointers,
+ * nf_conv_s2_stem_x3_pack_floats floats); ref ibrnet/feature_network.py:188 */
+int64_t nf_conv_s2_stem_x3_pack_floats(int c_out);
+int nf_conv_s2_stem_x3_pack(const float* weight_host, int c_out, int c_in, float* records_host);
+int nf_conv_s2_stem_fwd_x3(const float* records, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, float* y, int64_t ys_n,
+                           int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out, nf_stream_t stream);
 int nf_conv_s2_bwd_x3(const float* records, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int Ho, int Wo, float* dx, int64_t xs_n,
                       int64_t xs_c, int64_t xs_h, int Hi, int Wi, int n_img, int c_in, int c_out, nf_stream_t stream);
 

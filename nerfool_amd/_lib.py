@@ -91,6 +91,10 @@ _PROTOTYPES = {
     'nf_conv_s2_x3_pack': (c_int, [_P, c_int, c_int, c_int, _P]),
     'nf_conv_s2_fwd_x3': (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                   c_int, _P]),
+    'nf_conv_s2_stem_x3_pack_floats': (c_int64, [c_int]),
+    'nf_conv_s2_stem_x3_pack': (c_int, [_P, c_int, c_int, _P]),
+    'nf_conv_s2_stem_fwd_x3': (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                                       c_int, _P]),
     'nf_conv_s2_bwd_x3': (c_int, [_P, _P, c_int64, c_int64, c_int64, c_int, c_int, _P, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                   c_int, _P]),
     'nf_wino_pack_floats': (c_int64, [c_int, c_int, c_int]),

@@ -885,6 +885,236 @@ extern "C" int nf_conv_s2_fwd_x3(const float* records, const float* x, int64_t x
     return 0;
 }
 
+// ---- the 7x7 stem forward on bf16x3 operands.  K = 3 colours x 7 rows x 7 columns: a k-block of the bf16 instruction is one (tap row a,
+// colour c) LINE of the kernel per lane half -- line r = 3 a + c = 2 kb + h, elements = the tap columns b = 0 .. 7 (b = 7: zero weights) --
+// eleven blocks, the last half-block (r = 21) of zero weights.  The input window is staged as lines (3 y + c) de-interleaved by column
+// parity, so that line r of output row o sits at line 6 o + r: lane base + compile-time immediate for every B read.  All 66 KB of split
+// weights stay in LDS for the life of the workgroup, which walks a strip of 4 ITER output rows (window re-staged per 4 rows, prefetched
+// into registers under the previous rows' products): the records come from L2 once per strip, not once per 4 rows.
+#define S2_STEM_X3_KB 11
+#define S2_STEM_X3_FLOATS (S2_STEM_X3_KB * 2 * 3 * 256)       // per group of 64 outputs: [kb][tile t][part][lane][8 bf16]
+
+extern "C" int64_t nf_conv_s2_stem_x3_pack_floats(int c_out) { return (int64_t)((c_out + 63) / 64) * S2_STEM_X3_FLOATS; }
+
+/* HOST: weight [c_out][c_in <= 3][7][7] -> [group of 64 outputs][kb][tile t][part][lane (i, h)][8 bf16]; element j of lane (i, h) =
+ * W[64 g + 32 t + i][c][a][b = j], 3 a + c = 2 kb + h (zero for a > 6, b > 6, c >= c_in) */
+extern "C" int nf_conv_s2_stem_x3_pack(const float* weight, int c_out, int c_in, float* out) {
+    if (c_in < 1 || c_in > 3) return 1;
+    const int groups = (c_out + 63) / 64;
+    uint16_t* piece = reinterpret_cast<uint16_t*>(out);
+    for (int g = 0; g < groups; ++g)
+        for (int kb = 0; kb < S2_STEM_X3_KB; ++kb)
+            for (int t = 0; t < 2; ++t, piece += 3 * 512)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 64 * g + 32 * t + (lane & 31), r = 2 * kb + (lane >> 5), a = r / 3, c = r - 3 * a;
+                        const float v = (k < c_out && a < 7 && j < 7 && c < c_in) ? weight[(((size_t)k * c_in + c) * 7 + a) * 7 + j] : 0.f;
+                        s2_x3_emit(piece, lane, j, v);
+                    }
+    return (reinterpret_cast<float*>(piece) - out) == nf_conv_s2_stem_x3_pack_floats(c_out) ? 0 : 2;
+}
+
+// NW waves x RPW output rows each per iteration; the A parts of a k-block are read once for the wave's RPW rows
+template <int NW, int RPW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) k_conv_s2_stem_fwd_x3(const float* __restrict__ rec, const float* __restrict__ x, S2Tensor xi, int Hi, int Wi,
+                                                                float* __restrict__ y, S2Tensor yo, int Ho, int Wo, int C, int K, int groups,
+                                                                int tiles_x, int strips, int iters) {
+    constexpr int ROWS = NW * RPW, NT = 64 * NW;                   // output rows per iteration, threads
+    constexpr int ROWF = 2 * S2_PW, LINES = 3 * (2 * (ROWS - 1) + 7) + 1, WINF = LINES * ROWF, WC = 70, XC = WC - 64;      // (+ the line kept zero)
+    constexpr int NROW = (LINES - 1 + 2 * NW - 1) / (2 * NW), NXC = ((LINES - 1) * XC + NT - 1) / NT;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* win = smem;
+    float* wgt = smem + WINF;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+    int bid = blockIdx.x;
+    const int grp = bid % groups;
+    bid /= groups;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int strip = bid % strips, n = bid / strips;
+    const int ox0 = tx * 32, ix0 = 2 * ox0, oy_first = strip * ROWS * iters;
+    const float* xn = x + n * xi.ns;
+    const bool pair_ok = ((xi.ns | xi.cs | xi.rs) & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0;
+    const int bbase = (6 * RPW * w + h) * ROWF + j;
+    const int l32 = lane & 31, sub = lane >> 5;
+
+    // the split weights of this group of 64 outputs: 66 KB, once
+    {
+        const s2_f4* src = reinterpret_cast<const s2_f4*>(rec + (size_t)grp * S2_STEM_X3_FLOATS);
+        s2_f4* dst = reinterpret_cast<s2_f4*>(wgt);
+        for (int i = threadIdx.x; i < S2_STEM_X3_FLOATS / 4; i += NT) dst[i] = src[i];
+        for (int i = threadIdx.x; i < ROWF; i += NT) win[(LINES - 1) * ROWF + i] = 0.f;       // the line only zero weights read
+    }
+    s2_f2 pre_w[NROW];
+    float pre_x[NXC];
+    auto fetch = [&](int it) {
+        const int iy0 = 2 * (oy_first + ROWS * it);
+        S2_OPAQUE_S(it);
+#pragma unroll
+        for (int q = 0; q < NROW; ++q) {
+            const int L = q * (2 * NW) + 2 * w + sub;
+            s2_f2 v = {0.f, 0.f};
+            if (L < LINES - 1) {
+                const int yl = L / 3, c = L - 3 * yl;
+                const int gy = iy0 + yl, gx = ix0 + 2 * l32;
+                if (c < C && gy < Hi) {
+                    const float* src = xn + c * xi.cs + gy * xi.rs + gx;
+                    if (pair_ok && gx + 1 < Wi) v = *reinterpret_cast<const s2_f2*>(src);
+                    else {
+                        if (gx < Wi) v[0] = src[0];
+                        if (gx + 1 < Wi) v[1] = src[1];
+                    }
+                }
+            }
+            pre_w[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NXC; ++q) {
+            const int i = q * NT + threadIdx.x;
+            float v = 0.f;
+            if (i < (LINES - 1) * XC) {
+                const int L = i / XC, col = 64 + (i - L * XC);
+                const int yl = L / 3, c = L - 3 * yl;
+                const int gy = iy0 + yl, gx = ix0 + col;
+                if (c < C && gy < Hi && gx < Wi) v = xn[c * xi.cs + gy * xi.rs + gx];
+            }
+            pre_x[q] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < NROW; ++q) {
+            const int L = q * (2 * NW) + 2 * w + sub;
+            if (L < LINES - 1) {
+                float* dst = win + L * ROWF + l32;
+                dst[0] = pre_w[q][0];
+                dst[S2_PW] = pre_w[q][1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NXC; ++q) {
+            const int i = q * NT + threadIdx.x;
+            if (i < (LINES - 1) * XC) {
+                const int L = i / XC, col = 64 + (i - L * XC);
+                win[L * ROWF + (col & 1) * S2_PW + (col >> 1)] = pre_x[q];
+            }
+        }
+    };
+    float* yn = y + n * yo.ns;
+    const int ox = ox0 + j;
+    fetch(0);
+    for (int it = 0; it < iters; ++it) {
+        if (oy_first + ROWS * it >= Ho) break;       // (uniform)
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (it + 1 < iters) fetch(it + 1);
+        s2_f16 acc[RPW][2];
+#pragma unroll
+        for (int b = 0; b < RPW; ++b)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < S2_STEM_X3_KB; ++kb) {
+            s2_u4 av[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) av[t][q] = *reinterpret_cast<const s2_u4*>(wgt + ((kb * 2 + t) * 3 + q) * 256 + 4 * lane);
+#pragma unroll
+            for (int b = 0; b < RPW; ++b) {
+                s2_u4 bv[3];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {      // tap columns 2 p, 2 p + 1 (column 7: zero weights, value 0)
+                    float v0 = win[bbase + (2 * kb + 6 * b) * ROWF + p];
+                    float v1 = p < 3 ? win[bbase + (2 * kb + 6 * b) * ROWF + S2_PW + p] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bv[q][p] = s2_split_pair(v0, v1);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+#define S2_PROD(qa, qb) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s2_bf8, av[t][qa]), __builtin_bit_cast(s2_bf8, bv[qb]), acc[b][t], 0, 0, 0)
+                    S2_PROD(0, 0);
+                    S2_PROD(0, 1);
+                    S2_PROD(1, 0);
+                    S2_PROD(0, 2);
+                    S2_PROD(2, 0);
+                    S2_PROD(1, 1);
+#undef S2_PROD
+                }
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);      // a k-block's reads stay with its products (hoisted across blocks they cost 60+ registers)
+#endif
+        }
+#pragma unroll
+        for (int b = 0; b < RPW; ++b) {
+            const int oy = oy_first + ROWS * it + RPW * w + b;
+            if (oy < Ho && ox < Wo) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = 64 * grp + 32 * t + s2_nidx(r, h);
+                        if (k < K) yn[k * yo.cs + oy * yo.rs + ox] = acc[b][t][r];
+                    }
+            }
+        }
+    }
+}
+
+#ifndef S2_STEM_X3_NW
+#define S2_STEM_X3_NW 4
+#define S2_STEM_X3_RPW 1
+#endif
+template <int NW, int RPW>
+static int s2_launch_stem_x3(const float* records, const float* x, S2Tensor xi, int Hi, int Wi, float* y, S2Tensor yo, int Ho, int Wo, int n_img,
+                             int c_in, int c_out, hipStream_t st) {
+    constexpr int ROWS = NW * RPW, LINES = 3 * (2 * (ROWS - 1) + 7) + 1, PER_CU = NW == 4 ? 2 : 1;
+    const int tiles_x = (Wo + 31) / 32, groups = (c_out + 63) / 64, row_groups = (Ho + ROWS - 1) / ROWS;
+    // iterations per workgroup (a strip of ROWS * iters output rows): the choice with the fewest (rounds over the chip) x (iterations + the
+    // ~1.5 iterations a workgroup spends on its 66 KB of records and its first window)
+    int iters = 1;
+    double best = 1e30;
+    for (int it = 1; it <= 16 && it <= row_groups; ++it) {
+        const int64_t wgs = (int64_t)tiles_x * ((row_groups + it - 1) / it) * n_img * groups;
+        const double cost = (double)((wgs + 256 * PER_CU - 1) / (256 * PER_CU)) * (it + 1.5);
+        if (cost < best - 1e-9) best = cost, iters = it;
+    }
+    const int strips = (row_groups + iters - 1) / iters;
+    constexpr size_t smem = sizeof(float) * (LINES * 2 * S2_PW + S2_STEM_X3_FLOATS);
+    static_assert(PER_CU * smem <= 160 * 1024, "workgroups per CU");
+    static bool once_on[NF_MAX_DEVICES] = {};
+    bool& once = once_on[nf_current_device()];
+    if (!once) {
+        if (hipFuncSetAttribute((const void*)k_conv_s2_stem_fwd_x3<NW, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            nf_set_error("nf_conv_s2_stem_fwd_x3: cannot reserve %zu bytes of LDS", smem);
+            return 1;
+        }
+        once = true;
+    }
+    hipLaunchKernelGGL((k_conv_s2_stem_fwd_x3<NW, RPW>), dim3((unsigned)(tiles_x * strips * n_img * groups)), dim3(64 * NW), smem, st, records, x, xi,
+                       Hi, Wi, y, yo, Ho, Wo, c_in, c_out, groups, tiles_x, strips, iters);
+    return 0;
+}
+
+/* nf_conv_s2_fwd for the 7x7 stem (c_in <= 3) on the bf16 matrix cores with three-way split operands (fp32-grade); records:
+ * nf_conv_s2_stem_x3_pack */
+extern "C" int nf_conv_s2_stem_fwd_x3(const float* records, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, float* y,
+                                      int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img, int c_in, int c_out,
+                                      nf_stream_t stream) {
+    NF_REQUIRE(n_img >= 1 && c_in >= 1 && c_in <= 3 && c_out >= 1 && Hi >= 7 && Wi >= 7, "nf_conv_s2_stem_fwd_x3: bad arguments (c_in %d)", c_in);
+    NF_REQUIRE(Ho == (Hi - 7) / 2 + 1 && Wo == (Wi - 7) / 2 + 1, "nf_conv_s2_stem_fwd_x3: output %d x %d does not match input %d x %d", Ho, Wo, Hi,
+               Wi);
+    const S2Tensor xi{xs_n, xs_c, xs_h}, yo{ys_n, ys_c, ys_h};
+    const int rc = s2_launch_stem_x3<S2_STEM_X3_NW, S2_STEM_X3_RPW>(records, x, xi, Hi, Wi, y, yo, Ho, Wo, n_img, c_in, c_out, (hipStream_t)stream);
+    if (rc) return rc;
+    NF_LAUNCH_CHECK("nf_conv_s2_stem_fwd_x3");
+    return 0;
+}
+
 /* nf_conv_s2_bwd for ks = 3 on the bf16 matrix cores with three-way split operands (fp32-grade); records: nf_conv_s2_x3_pack */
 extern "C" int nf_conv_s2_bwd_x3(const float* records, const float* dy, int64_t ds_n, int64_t ds_c, int64_t ds_h, int Ho, int Wo, float* dx,
                                  int64_t xs_n, int64_t xs_c, int64_t xs_h, int Hi, int Wi, int n_img, int c_in, int c_out, nf_stream_t stream) {

@@ -325,12 +325,26 @@ def _s2_records_x3(conv_w):
     return cache[1], cache[2]
 
 
+def _stem_records_x3(conv_w):
+    """bf16x3 forward records of the 7x7 stem weight (csrc/nf_conv_s2.hip: k_conv_s2_stem_fwd_x3), kept on the weight tensor"""
+    key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
+    cache = getattr(conv_w, '_nf_stem_x3', None)
+    if cache is None or cache[0] != key:
+        cache = (key, ops.conv_s2_stem_pack_x3(conv_w, conv_w.device))
+        conv_w._nf_stem_x3 = cache
+    return cache[1]
+
+
 def _conv_s2(tape, inp, w, sink, operands=None):
     c_out, c_in, ks = w.shape[0], w.shape[1], w.shape[2]
     x3 = ks == 3 and (operands or WINO_OPERANDS) == 'bf16x3'      # the 3x3 passes on the split operands (fp32-grade)
+    stem_x3 = ks == 7 and c_in <= 3 and (operands or WINO_OPERANDS) == 'bf16x3'      # the stem's forward likewise (backward: fp32 operands)
     if x3:
         rf, rb = _s2_records_x3(w)
         out = _Slot(ops.conv_s2_fwd_x3(rf, inp, c_out))
+    elif stem_x3:
+        rb = _s2_records(w)[1]
+        out = _Slot(ops.conv_s2_stem_fwd_x3(_stem_records_x3(w), inp, c_out))
     else:
         rf, rb = _s2_records(w)
         out = _Slot(ops.conv_s2_fwd(rf, inp, c_out, ks))

@@ -671,6 +671,31 @@ def conv_s2_fwd_x3(records, x, c_out):
     return y
 
 
+def conv_s2_stem_pack_x3(weight, device):
+    """weight [c_out, c_in <= 3, 7, 7] -> bf16x3 records of the stem's forward (nf_conv_s2_stem_fwd_x3)"""
+    L = _lib.lib()
+    w = weight.detach().to('cpu', torch.float32).contiguous()
+    assert tuple(w.shape[2:]) == (7, 7) and w.shape[1] <= 3
+    out = torch.empty(L.nf_conv_s2_stem_x3_pack_floats(w.shape[0]), dtype=torch.float32)
+    _lib.check(L.nf_conv_s2_stem_x3_pack(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr()), 'nf_conv_s2_stem_x3_pack')
+    return out.to(device)
+
+
+def conv_s2_stem_fwd_x3(records, x, c_out):
+    """conv_s2_fwd for the 7x7 stem on the bf16 matrix cores with three-way split operands (fp32-grade)"""
+    _f32(x, 'x')
+    if x.stride(3) != 1:
+        x = x.contiguous()
+    N, c_in, Hi, Wi = x.shape
+    Ho, Wo = (Hi - 7) // 2 + 1, (Wi - 7) // 2 + 1
+    y = torch.empty(N, c_out, Ho, Wo, dtype=torch.float32, device=x.device)
+    xs, ys = x.stride(), y.stride()
+    with prof.launch('nf_conv_s2_fwd', x, n_img=N, c_in=c_in, c_out=c_out, ks=7, Ho=Ho, Wo=Wo, n_split=3):
+        _launch(_lib.lib().nf_conv_s2_stem_fwd_x3, 'nf_conv_s2_stem_fwd_x3', x, _ptr(records), _ptr(x), xs[0], xs[1], xs[2], Hi, Wi, _ptr(y), ys[0],
+                ys[1], ys[2], Ho, Wo, N, c_in, c_out)
+    return y
+
+
 def conv_s2_bwd_x3(records, dy, c_in, Hi, Wi):
     """conv_s2_bwd for ks = 3 on the bf16 matrix cores with three-way split operands (fp32-grade)"""
     _f32(dy, 'dy')

@@ -1369,7 +1369,7 @@ def check_conv_s2(dev, shapes=None):
     import torch.nn.functional as F
     gen = torch.Generator().manual_seed(11)
     shapes = shapes or ((1, 64, 64, 3, 21, 25), (2, 16, 64, 3, 38, 70), (1, 3, 64, 7, 29, 41), (1, 64, 128, 3, 12, 17),
-                        (2, 3, 64, 7, 75, 139), (1, 128, 256, 3, 33, 66), (1, 24, 40, 3, 19, 23), (8, 8, 128, 3, 131, 259))
+                        (2, 3, 64, 7, 75, 139), (1, 128, 256, 3, 33, 66), (1, 24, 40, 3, 19, 23), (8, 8, 128, 3, 131, 259), (6, 3, 64, 7, 301, 215), (1, 2, 96, 7, 45, 77))
     for (N, cin, cout, ks, Hi, Wi) in shapes:
         x = torch.randn(N, cin, Hi, Wi, generator=gen)
         w = torch.randn(cout, cin, ks, ks, generator=gen) * 0.1
@@ -1383,6 +1383,10 @@ def check_conv_s2(dev, shapes=None):
         ef = float((y.cpu().double() - ref.detach()).abs().max() / ref.abs().max())
         eb = float((dx.cpu().double() - gref).abs().max() / gref.abs().max())
         assert ef <= 5e-6 and eb <= 5e-6, ('conv_s2', N, cin, cout, ks, Hi, Wi, ef, eb)
+        if ks == 7:      # the stem's forward on the bf16 matrix cores with three-way split operands: the same float64 bar
+            y7 = ops.conv_s2_stem_fwd_x3(ops.conv_s2_stem_pack_x3(w, dev), x.to(dev), cout)
+            ef7 = float((y7.cpu().double() - ref.detach()).abs().max() / ref.abs().max())
+            assert ef7 <= 5e-6, ('conv_s2 stem bf16x3', N, cin, cout, Hi, Wi, ef7)
         if ks == 3:      # both passes on the bf16 matrix cores with three-way split operands: the same float64 bar
             y3 = ops.conv_s2_fwd_x3(ops.conv_s2_pack_x3(w, False, dev), x.to(dev), cout)
             dx3 = ops.conv_s2_bwd_x3(ops.conv_s2_pack_x3(w, True, dev), g.to(dev), cin, Hi, Wi)
@@ -1397,6 +1401,9 @@ def check_conv_s2(dev, shapes=None):
         assert float((y2.cpu().double() - ref2).abs().max() / ref2.abs().max()) <= 5e-6
         if ks == 3:
             y2 = ops.conv_s2_fwd_x3(ops.conv_s2_pack_x3(w, False, dev), view, cout)
+            assert float((y2.cpu().double() - ref2).abs().max() / ref2.abs().max()) <= 5e-6
+        else:
+            y2 = ops.conv_s2_stem_fwd_x3(ops.conv_s2_stem_pack_x3(w, dev), view, cout)
             assert float((y2.cpu().double() - ref2).abs().max() / ref2.abs().max()) <= 5e-6
 
 

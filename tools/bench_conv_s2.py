@@ -55,6 +55,11 @@ for (cin, cout, ks, Hi, Wi) in ((3, 64, 7, 762, 1014), (64, 64, 3, 380, 506), (6
         t_f3, _ = timed(lambda: ops.conv_s2_fwd_x3(f3, x, cout))
         ef3 = float((ops.conv_s2_fwd_x3(f3, x[:1, :, :41, :73].contiguous(), cout).cpu().double() - yc).abs().max() / yc.abs().max())
         print('      bf16x3 forward:       %6.1f us (fp32 operands %6.1f us), err vs float64 %.1e' % (t_f3, t_o, ef3))
+    if ks == 7:
+        f7 = ops.conv_s2_stem_pack_x3(w, 'cuda')
+        t_f7, _ = timed(lambda: ops.conv_s2_stem_fwd_x3(f7, x, cout))
+        ef7 = float((ops.conv_s2_stem_fwd_x3(f7, x[:1, :, :41, :73].contiguous(), cout).cpu().double() - yc).abs().max() / yc.abs().max())
+        print('      bf16x3 stem forward:  %6.1f us (fp32 operands %6.1f us), err vs float64 %.1e' % (t_f7, t_o, ef7))
     print('%3d -> %3d %dx%d s2 at %dx%d: fwd MIOpen %6.1f us  own %6.1f us (%.1f TFLOP/s) | bwd-data MIOpen %6.1f us  own %6.1f us (%.1f TFLOP/s) | '
           'err fwd %.1e bwd %.1e | own vs MIOpen %.1e %.1e'
           % (cin, cout, ks, ks, Hi, Wi, t_m, t_o, fl / t_o / 1e6, t_mb, t_ob, fl / t_ob / 1e6, ef, eb,
