@@ -50,7 +50,7 @@ static constexpr int64_t GM_LAYER_FLOATS = (int64_t)MG_LAYER_RECORDS * 64 + MB_F
 // stem: rgbfeat_fc.0 (35 -> 64, k order 2 s + h, 18 steps per tile), rgbfeat_fc.2 (64 -> 64); then 2 + 2 bias tiles
 enum { MS_L1 = 0, MS_L2 = 36, MS_RECORDS = 100, MS_B1 = MS_RECORDS * 64, MS_B2 = MS_B1 + 64, GM_STEM_FLOATS = MS_B2 + 64 };
 // final: norm weight, bias (fragment order), rgb_fc weight [3] x fragment order, bias 3 (+1 pad)
-enum { MF_LNW = 0, MF_LNB = 64, MF_W = 128, MF_B = 320, GM_FINAL_FLOATS = 324 };
+enum { MF_LNW = 0, MF_LNB = 64, MF_W = 128, MF_B = 320, GM_FINAL_FLOATS = 384 };      // (whole records: every stream starts on one)
 
 NF_HD int64_t gm_layer_base(int i) { return GM_STEM_FLOATS + (int64_t)i * GM_LAYER_FLOATS; }
 
@@ -69,7 +69,15 @@ NF_HD int64_t gm_fwd_floats(int depth) { return GM_STEM_FLOATS + (int64_t)depth 
 NF_HD int64_t gm_bwd_layer_base(int depth, int i) { return gm_fwd_floats(depth) + (int64_t)i * GM_BWD_LAYER_FLOATS; }
 NF_HD int64_t gm_bwd_stem_base(int depth) { return gm_bwd_layer_base(depth, depth); }
 
-extern "C" int64_t nf_gnt_mfma_blob_floats(int depth) { return gm_bwd_stem_base(depth) + BSTEM_RECORDS * 64 + GM_BLOB_PAD; }
+// ---- bf16x3 image of the STREAMED records (behind the fp32 blob): the streamed GEMMs run on v_mfma_f32_32x32x16_bf16 with every fp32
+//      operand as three bf16 parts (six cross terms, fp32-grade; DESIGN "fp32-grade products on the bf16 matrix cores").  A k-block of the
+//      bf16 instruction = 8 consecutive fp32 k-steps: lane (i, h) holds the eight weights it held in records Y .. Y + 7, so the B operand
+//      is the lane's OWN eight activations of those k-steps.  The block of records [Y, Y + 8) lives at image offset 96 Y floats as
+//      [part 3][lane 64][8 bf16] (768 floats): any stream pointer p of the fp32 blob maps to image + (p - blob) * 3 / 2.
+NF_HD int64_t gm_fp32_floats(int depth) { return gm_bwd_stem_base(depth) + BSTEM_RECORDS * 64 + GM_BLOB_PAD; }
+#define GM_X3_CHUNK 1536     // floats per chunk of the image (two k-blocks of three 1 KB parts)
+
+extern "C" int64_t nf_gnt_mfma_blob_floats(int depth) { return gm_fp32_floats(depth) + gm_fp32_floats(depth) / 2 * 3; }
 
 extern "C" int nf_gnt_mfma_supported(int n_samples, int n_views) {
     return n_samples >= 32 && n_samples <= 128 && n_samples % 32 == 0 && n_views >= 1 && n_views <= 64;
@@ -235,6 +243,37 @@ extern "C" int nf_gnt_pack_mfma(int depth, const float* nat, float* out) {
         gm_lin64(rec, nat, 35, 64);                                    // rgbfeat_fc.0 [in = 35][out = 64]: two output tiles
         if (rec - (out + gm_bwd_stem_base(depth)) != BSTEM_RECORDS * 64) return 8;
     }
+    // the bf16x3 image of the streamed regions
+    {
+        const int64_t f32 = gm_fp32_floats(depth);
+        float* img = out + f32;
+        memset(img, 0, sizeof(float) * (size_t)(f32 / 2 * 3));
+        auto region = [&](int64_t base_floats, int records) {
+            for (int y = 0; y < records; y += 8) {
+                const float* src = out + base_floats + (int64_t)y * 64;
+                uint16_t* dst = reinterpret_cast<uint16_t*>(img + (base_floats + (int64_t)y * 64) / 2 * 3);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        float rem = src[j * 64 + lane];
+                        for (int part = 0; part < 3; ++part) {
+                            uint32_t u;
+                            memcpy(&u, &rem, 4);
+                            const uint16_t q = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);        // round to nearest even (finite weights)
+                            dst[(size_t)part * 512 + lane * 8 + j] = q;
+                            const uint32_t up = (uint32_t)q << 16;
+                            float f;
+                            memcpy(&f, &up, 4);
+                            rem -= f;
+                        }
+                    }
+            }
+        };
+        for (int i = 0; i < depth; ++i) {
+            region(gm_layer_base(i) + MG_STREAM * 64, ST_END);
+            region(gm_bwd_layer_base(depth, i) + BG_STREAM * 64, BS_END);
+        }
+        region(gm_bwd_stem_base(depth), BSTEM_RECORDS);
+    }
     return 0;
 }
 
@@ -313,45 +352,87 @@ __device__ __forceinline__ V64 gm_lin64(const float* __restrict__ rec, const flo
 // ---- weight stream: two chunks (2 x 16 records) are always in flight; consuming a chunk immediately issues the loads of the
 //      chunk two ahead (w.p).  With one wave per SIMD (512 rays x 2 waves = one wave per SIMD of the chip) nothing else hides
 //      the ~1 us L2 latency of the weight loads.  Non-contiguous transitions set w.p before the last TWO chunks of a segment.
-struct GmW { g16 a, b; const float* p; };
-__device__ __forceinline__ g16 gm_ld16(const float* __restrict__ p, int lane) {
-    g16 v;
+typedef unsigned gm_u4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gm_bf8 __attribute__((ext_vector_type(8)));
+struct GmChunk { gm_u4 q[6]; };      // [k-block 2][part 3]: one 32 x 32 weight block on bf16x3 operands
+struct GmW { GmChunk a, b; const float* p; const float* blob; const float* img; };      // p walks the fp32 blob's record space
+__device__ __forceinline__ GmChunk gm_ld16(const GmW& w, const float* __restrict__ p, int lane) {
+    const float* __restrict__ s = w.img + ((p - w.blob) >> 1) * 3 + 4 * lane;      // (uniform arithmetic; p - blob is a multiple of 64)
+    GmChunk c;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = p[r * 64 + lane];
-    return v;
+    for (int i = 0; i < 6; ++i) c.q[i] = *reinterpret_cast<const gm_u4*>(s + i * 256);
+    return c;
 }
-__device__ __forceinline__ void gm_w_start(GmW& w, const float* p, int lane) {
-    w.a = gm_ld16(p, lane);
-    w.b = gm_ld16(p + GM_CHUNK, lane);
+__device__ __forceinline__ void gm_w_start(GmW& w, const float* blob, int depth, const float* p, int lane) {
+    w.blob = blob;
+    w.img = blob + gm_fp32_floats(depth);
+    w.a = gm_ld16(w, p, lane);
+    w.b = gm_ld16(w, p + GM_CHUNK, lane);
     w.p = p + 2 * GM_CHUNK;
 }
-__device__ __forceinline__ g16 gm_mfma16(const g16& wv, const g16& x, g16 acc) {
+// two fp32 values -> their bf16 roundings (packed) and the exact remainders
+__device__ __forceinline__ unsigned gm_split_pair(float& x0, float& x1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __bf16 gm_bf2 __attribute__((ext_vector_type(2)));
+    const gm_bf2 pr = gm_bf2{(__bf16)x0, (__bf16)x1};                 // v_cvt_pk_bf16_f32 (round to nearest even)
+    const unsigned u = __builtin_bit_cast(unsigned, pr);
+    x0 -= __builtin_bit_cast(float, u << 16);
+    x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
+    return u;
+#else
+    const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
+    unsigned short s0, s1;
+    memcpy(&s0, &b0, 2);
+    memcpy(&s1, &b1, 2);
+    x0 -= (float)b0;
+    x1 -= (float)b1;
+    return (unsigned)s0 | ((unsigned)s1 << 16);
+#endif
+}
+// acc += (32 x 32 block) x (the lane's 16 activations of the k-tile): per k-block the six cross terms of order <= 2^-16
+__device__ __forceinline__ g16 gm_mfma16(const GmChunk& wv, const g16& x, g16 acc) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc = GM_MFMA(wv[r], x[r], acc);
+    for (int blk = 0; blk < 2; ++blk) {
+        gm_u4 bv[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v0 = x[8 * blk + 2 * q], v1 = x[8 * blk + 2 * q + 1];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) bv[part][q] = gm_split_pair(v0, v1);
+        }
+#define GM_PROD(pa, pb) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gm_bf8, wv.q[3 * blk + pa]), __builtin_bit_cast(gm_bf8, bv[pb]), acc, 0, 0, 0)
+        GM_PROD(0, 0);
+        GM_PROD(0, 1);
+        GM_PROD(1, 0);
+        GM_PROD(0, 2);
+        GM_PROD(2, 0);
+        GM_PROD(1, 1);
+#undef GM_PROD
+    }
     return acc;
 }
 // memory operations stay on their side of this point: under register pressure the instruction scheduler otherwise sinks the
 // loads of a chunk down to the MFMAs that consume them (load, s_waitcnt vmcnt(0), MFMA -- the whole L2 latency per record)
 #define GM_PIN() asm volatile("" ::: "memory")
-// ... and the MFMAs of the NEXT chunk stay behind it (they start with `next0`, the first record of the other buffer): hoisted
+// ... and the MFMAs of the NEXT chunk stay behind it (they start with `next0`, the first part of the other buffer): hoisted
 // above the pin they would run right behind the loads issued for the chunk after them, which shortens the distance between a
 // load and its use from two chunks to a few records
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GM_PIN_CHAIN(next0) asm volatile("" : "+v"(next0) : : "memory")
 #else
-#define GM_PIN_CHAIN(next0) asm volatile("" : "+r"(next0) : : "memory")
+#define GM_PIN_CHAIN(next0) asm volatile("" ::: "memory")
 #endif
 __device__ __forceinline__ g16 gm_take_a(GmW& w, int lane, const g16& x, g16 acc) {
     acc = gm_mfma16(w.a, x, acc);
-    w.a = gm_ld16(w.p, lane);
-    GM_PIN_CHAIN(w.b[0]);
+    w.a = gm_ld16(w, w.p, lane);
+    GM_PIN_CHAIN(w.b.q[0]);
     w.p += GM_CHUNK;
     return acc;
 }
 __device__ __forceinline__ g16 gm_take_b(GmW& w, int lane, const g16& x, g16 acc) {
     acc = gm_mfma16(w.b, x, acc);
-    w.b = gm_ld16(w.p, lane);
-    GM_PIN_CHAIN(w.a[0]);
+    w.b = gm_ld16(w, w.p, lane);
+    GM_PIN_CHAIN(w.a.q[0]);
     w.p += GM_CHUNK;
     return acc;
 }
@@ -589,7 +670,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
         }
     }
     GmW w;
-    gm_w_start(w, wb + gm_layer_base(0) + MG_STREAM * 64, lane);
+    gm_w_start(w, wb, depth, wb + gm_layer_base(0) + MG_STREAM * 64, lane);
     for (int i = 0; i < depth; ++i) {
         const float* Lbase = wb + gm_layer_base(i);
         const float* Lst = Lbase + MG_STREAM * 64;                                        // this layer's stream
@@ -983,7 +1064,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
         dcur = gm_ln_bwd(c, dm, F + MF_LNW, SW_XHF, SW_RSTDF);
     }
     GmW w;
-    gm_w_start(w, wb + gm_bwd_layer_base(depth, depth - 1) + BG_STREAM * 64, lane);
+    gm_w_start(w, wb, depth, wb + gm_bwd_layer_base(depth, depth - 1) + BG_STREAM * 64, lane);
     for (int i = depth - 1; i >= 0; --i) {
         const float* Bl = wb + gm_bwd_layer_base(depth, i);
         const float* Bst = Bl + BG_STREAM * 64;
