@@ -1490,6 +1490,9 @@ struct RowScatter {
     int64_t fs_v, fs_c, fs_h, fs_w;
     int Hf, Wf;
 };
+#ifndef NF_SCATTER_MERGE
+#define NF_SCATTER_MERGE 1     // contributions of neighbouring samples to one bilinear cell summed before the atomics
+#endif
 #define RS_ROW 33             // floats per row of the wave's staging tile (32 channels, padded: conflict-free column reads)
 #define RS_TAP 8              // per row: 4 tap weights, x0, y0 (as int bits), view, pad
 #define RS_FLOATS (32 * RS_ROW + 32 * RS_TAP)
@@ -1583,6 +1586,49 @@ __global__ void __launch_bounds__(64 * rows_bwd_waves(BF, SCAT), rows_bwd_occ(BF
             // the tile is private to the wave, whose lanes run in lockstep and whose LDS operations execute in order: rs_wave_sync
             // only keeps the compiler from moving the reads below above the writes of other lanes
             rs_wave_sync();
+            // lane & 31 = channel; half-wave h walks the 32 / V consecutive samples of view 2 i + h: neighbours along a ray mostly fall
+            // into the same bilinear cell of a source view, and their four tap contributions are summed before they go out as atomics
+            // (fine samples of config 5: ~2.5 of the 4 samples of a view per cell)
+#if NF_SCATTER_MERGE
+#pragma unroll 1
+            for (int i = 0; i < (V + 1) / 2; ++i) {
+                const int vv = 2 * i + h;
+                float accv[4] = {0.f, 0.f, 0.f, 0.f};
+                int cx = 0, cy = 0, cv = 0, have = 0;         // `have`: taps of the open cell that received a contribution
+                auto flush = [&]() {
+                    float* fb = sc.d_featmap + (int64_t)cv * sc.fs_v + (int64_t)m * sc.fs_c;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (have & (1 << t)) atomicAdd(fb + (int64_t)(cy + (t >> 1)) * sc.fs_h + (int64_t)(cx + (t & 1)) * sc.fs_w, accv[t]);
+                };
+                if (vv < V) {
+#pragma unroll 1
+                    for (int sl = 0; sl < 32 / V; ++sl) {
+                        const int j = sl * V + vv;                  // row of the tile
+                        const float* tj = tp + j * RS_TAP;
+                        int hit = 0;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) hit |= (tj[t] != 0.f) << t;
+                        if (!hit) continue;                         // (uniform over the half-wave: a row's taps are the same for its 32 channels)
+                        const int x0 = __builtin_bit_cast(int, (float)(tj[4])), y0 = __builtin_bit_cast(int, (float)(tj[5]));
+                        if (have && (x0 != cx || y0 != cy)) {
+                            flush();
+                            have = 0;
+                        }
+                        if (!have) {
+                            cx = x0, cy = y0, cv = __builtin_bit_cast(int, (float)(tj[6]));
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) accv[t] = 0.f;
+                        }
+                        const float gv = gt[j * RS_ROW + m];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) accv[t] += gv * tj[t];
+                        have |= hit;
+                    }
+                    if (have) flush();
+                }
+            }
+#else
 #pragma unroll 4
             for (int i = 0; i < 16; ++i) {
                 const int j = 2 * i + h;                    // row of the tile; lane & 31 = channel
@@ -1596,6 +1642,7 @@ __global__ void __launch_bounds__(64 * rows_bwd_waves(BF, SCAT), rows_bwd_occ(BF
                     if (wt != 0.f) atomicAdd(fb + (int64_t)(y0 + (t >> 1)) * sc.fs_h + (int64_t)(x0 + (t & 1)) * sc.fs_w, gv * wt);
                 }
             }
+#endif
             rs_wave_sync();         // ... and the next tile's writes below these reads
         } else if (live) {
             float* o = d_rgb_feat + row * 35;
