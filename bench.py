@@ -469,6 +469,16 @@ def main():
 
     hand_written_ms = None
     multi = None
+    host_issue_ms = None
+    if not standin:
+        # host time to ENQUEUE a step (no synchronisation inside the bracket; 3 steps = ~550 launches stay below the queue depth):
+        # the step is launch-bound when this approaches ms_per_step
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            attack.step(data)
+        host_issue_ms = 1e3 * (time.perf_counter() - t0) / 3
+        barrier()
     if a.extras:
         # every hand-written launch, timed over two extra steps OUTSIDE the timed region (extra.hand_written_kernel_ms_per_step)
         all_timer = prof.KernelTimer()
@@ -671,6 +681,7 @@ def main():
                    'rays_per_step_all_ranks': rays_per_step, 'parallelism': par,
                    'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step},
         'roofline': roofline,
+        'host_issue_ms_per_step': None if host_issue_ms is None else round(host_issue_ms, 4),
         'roofline_sampling': {'steps_with_hip_events': timed_steps, 'of_timed_steps': a.steps, 'every': a.event_every,
                               'note': 'per-launch durations from HIP events on the launch stream, live inside the timed region on every '
                                       'N-th step (an event pair costs the GPU ~11 us around the launch it brackets)'},
