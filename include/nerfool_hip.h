@@ -351,7 +351,9 @@ int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, cons
                int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 
 /* GNT forward on the matrix cores (S in {32, 64, 96, 128}): same arguments and workspace size as nf_gnt_fwd, with the weights
- * re-ordered by nf_gnt_pack_mfma (HOST pointers: natural blob -> MFMA-order blob of nf_gnt_mfma_blob_floats(depth) floats).
+ * re-ordered by nf_gnt_pack_mfma (HOST pointers: natural blob -> MFMA-order blob of nf_gnt_mfma_blob_floats(depth) floats: the fp32
+ * records, and behind them the bf16x3 image of the streamed records -- every weight as three bf16 parts -- that the streamed GEMMs
+ * multiply on the bf16 matrix cores with fp32-grade results).
  * What it saves is for nf_gnt_bwd_mfma ONLY: the view softmax as masked logits + per-channel maximum / reciprocal sum, the ReLU
  * layers as sign words, the view-attention output (nf_gnt.h); nf_gnt_bwd reads the workspace of nf_gnt_fwd.
  *                                                                             ref: gnt/transformer_network.py:270-309 */
