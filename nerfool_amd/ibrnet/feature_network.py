@@ -280,10 +280,13 @@ def _conv3x3(tape, inp, w, sink, operands=None):
 
     def bwd():
         g_out = out.g
-        # planes whose (H + 2) x (W + 2) gradient needs many more 8 x 16 output blocks than the H x W plane itself (48 x 63: 35
-        # against 24): the Winograd kernel on the interior-aligned region + the 1-D border ring kernel (a rule on the shape, not a
-        # timing: the two forms round differently)
-        plan = ops.wino_bwd_split_plan(g_out.shape[2], g_out.shape[3]) if g_out.shape[1] <= ops.WINO_RING_MAX_CHANNELS else None
+        # planes whose (H + 2) x (W + 2) gradient needs a round of 8 x 16 output blocks more than the H x W plane itself (48 x 63 at 4
+        # images: 560 workgroups against 384): the Winograd kernel on the interior-aligned region + the 1-D border ring kernel (a rule on
+        # the launch's shape, ops.wino_bwd_split_pays, not a timing: the two forms round differently)
+        plan = None
+        if g_out.shape[1] <= ops.WINO_RING_MAX_CHANNELS and ops.wino_bwd_split_pays(g_out.shape[2], g_out.shape[3], g_out.shape[0],
+                                                                                   g_out.shape[1], c_in):
+            plan = ops.wino_bwd_split_plan(g_out.shape[2], g_out.shape[3])
 
         def bwd_data(kpg):
             rec = _wino_records(w, kpg, ns)[1]

@@ -784,6 +784,26 @@ def wino_bwd_split_plan(H, W):
     return rows, cols, 1 | (0 if rows == H + 1 else 2) | 4 | (0 if cols == W + 1 else 8)
 
 
+WINO_SLOTS = 2 * 256      # workgroups of the Winograd kernel the chip holds at once (two per CU, 256 CUs)
+
+
+def wino_bwd_split_pays(H, W, n_img, c_dy, c_dx, k_per_group=64):
+    """Whether the split backward-data pass is the faster form for this launch: the border-ring kernel costs a fixed ~18 us (latency-bound),
+    so the split pays only where the one-launch form on the (H + 2) x (W + 2) output needs a ROUND of workgroups more than the
+    interior-aligned region (the chip holds WINO_SLOTS at once) and a workgroup runs long enough (>= 12 chunks of 16 gradient channels,
+    ~40 us) for that round to outweigh the ring.  Measured on the MI355X (tools/experimental/ab_split.py): config 2's 48 x 63 planes
+    (4 images, 256 channels: 560 -> 384 workgroups) 8.31 -> 8.16 ms per step with the split; config 5's 128^2 / 64^2 / 32^2 planes
+    (8 images: 1224 -> 1024, 720 -> 512, 480 -> 256 workgroups of 4 / 8 / 16 chunks) 7.35 -> 7.58 ms with it.  A function of the launch's
+    shape alone: the choice -- and with it every rounding -- is the same in every run."""
+    plan = wino_bwd_split_plan(H, W)
+    if plan is None:
+        return False
+    groups = -(-c_dx // k_per_group)
+    full = _wino_blocks(H + 2, W + 2) * n_img * groups
+    part = _wino_blocks(plan[0], plan[1]) * n_img * groups
+    return -(-full // WINO_SLOTS) > -(-part // WINO_SLOTS) and -(-c_dy // 16) >= 12
+
+
 def conv3x3_wino_bwd_split(records, ring_records, dy, c_dx, plan, k_per_group=None, n_split=0):
     """backward-data of a 3x3 stride-1 convolution, dy [N, c_dy, H, W] -> d(padded input) [N, c_dx, H + 2, W + 2], as the Winograd
     kernel on the interior-aligned region + the 1-D ring kernel (plan = wino_bwd_split_plan(H, W)); every element of the result

@@ -850,6 +850,10 @@ def check_fused_cnn_glue(dev):
             assert_close(ggot, gref, 1e-4, 1e-4 * float(gref.abs().max()), 'split backward-data %s of %dx%d, bf16x3 operands' % (plan, H, W))
     assert ops.wino_bwd_split_plan(48, 63) == (48, 64, 1 | 2 | 4) and ops.wino_bwd_split_plan(189, 252) is None
     assert ops.wino_bwd_split_plan(32, 32) == (32, 32, 15)
+    # the executor splits only where the one-launch form needs a round of workgroups more and a workgroup runs long (config 2's layer 3;
+    # none of config 5's planes)
+    assert ops.wino_bwd_split_pays(48, 63, 4, 256, 256) and not ops.wino_bwd_split_pays(189, 252, 4, 64, 64)
+    assert not any(ops.wino_bwd_split_pays(hw, hw, 8, c, c) for hw, c in ((128, 64), (64, 128), (32, 256)))
     # 1x1 convolutions as MFMA GEMMs over the pixels: subsampled / strided input, bias, channels-last output, backward-data
     for (N, ci, co, H, W, sub, cl) in ((2, 64, 64, 5, 7, False, True), (1, 64, 128, 6, 9, True, False), (1, 32, 40, 4, 5, False, False)):
         wgt = torch.randn(co, ci, 1, 1, generator=gen) * 0.2
