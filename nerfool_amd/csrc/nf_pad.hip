@@ -93,8 +93,14 @@ extern "C" int nf_pad_gather_bwd(const float* dout, int64_t os_n, int64_t os_c, 
 // Here: dx[i][j] = sum_{Y, X} wy(Y -> i) wx(X -> j) G[Y][X], G = the padded gradient folded onto the 2h x 2w plane.
 // A workgroup owns UT x UT source elements; the rows Y with h1 in [i0 - 1, i0 + UT - 1] lie in [2 i0 - 2, 2 (i0 + UT - 1) + 4]
 // (rh is just under 1/2), so the folded tile has 2 UT + 5 rows / columns.
+// Tile = UT rows x UTX columns of source elements (folded tile 37 x 133: 1.2x the tile's own gradient elements, rows of 532 contiguous
+// bytes; the 16 x 16 tile of rounds 2-3 read 1.34x in rows of 148 bytes and moved 1.6x its algorithmic bytes through HBM).  The folded
+// tile sits in LDS split by column parity, so that the stride-2 window reads of consecutive lanes hit consecutive banks.
 #define UT 16
+#define UTX 64
 #define UG (2 * UT + 5)
+#define UGX (2 * UTX + 5)
+#define UGXH ((UGX + 1) / 2 + 1)
 
 __device__ __forceinline__ float up_weight(int Y, int i, int h, int H2, float r) {       // wy(Y -> i); 0 outside the plane
     if (Y < 0 || Y >= H2) return 0.f;
@@ -107,14 +113,14 @@ __device__ __forceinline__ float up_weight(int Y, int i, int h, int H2, float r)
 
 __global__ void __launch_bounds__(PG_BLOCK) k_upsample2x_pad_bwd(const float* __restrict__ dyp, int h, int w, int pad, float* __restrict__ dx,
                                                                  int64_t xs_plane, int64_t xs_row, int tiles_x) {
-    __shared__ float G[UG][UG + 1];
+    __shared__ float G[2][UG][UGXH];          // [column parity][row][column / 2]
     const int H2 = 2 * h, W2 = 2 * w, Wp = W2 + 2 * pad, Hp = H2 + 2 * pad;
     const int64_t plane = blockIdx.y;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int i0 = ty * UT, j0 = tx * UT, Y0 = 2 * i0 - 2, X0 = 2 * j0 - 2;
+    const int i0 = ty * UT, j0 = tx * UTX, Y0 = 2 * i0 - 2, X0 = 2 * j0 - 2;
     const float* g = dyp + plane * (int64_t)Hp * Wp;
-    for (int idx = threadIdx.x; idx < UG * UG; idx += PG_BLOCK) {
-        const int a = idx / UG, b = idx - a * UG, Y = Y0 + a, X = X0 + b;
+    for (int idx = threadIdx.x; idx < UG * UGX; idx += PG_BLOCK) {
+        const int a = idx / UGX, b = idx - a * UGX, Y = Y0 + a, X = X0 + b;
         float acc = 0.f;
         if (Y >= 0 && Y < H2 && X >= 0 && X < W2) {
             int py[3], px[3];
@@ -122,31 +128,34 @@ __global__ void __launch_bounds__(PG_BLOCK) k_upsample2x_pad_bwd(const float* __
             for (int p = 0; p < ny; ++p)
                 for (int q = 0; q < nx; ++q) acc += g[(int64_t)py[p] * Wp + px[q]];
         }
-        G[a][b] = acc;
+        G[b & 1][a][b >> 1] = acc;
     }
     __syncthreads();
     const float rh = H2 > 1 ? (float)(h - 1) / (float)(H2 - 1) : 0.f;
     const float rw = W2 > 1 ? (float)(w - 1) / (float)(W2 - 1) : 0.f;
-    const int li = threadIdx.x / UT, lj = threadIdx.x - li * UT;          // 256 threads = UT x UT
-    const int i = i0 + li, j = j0 + lj;
-    if (i < h && j < w) {
-        float wy[7], wx[7];
+    const int lj = threadIdx.x % UTX, lrow = threadIdx.x / UTX;           // 256 threads = 4 rows x 64 columns per pass
+    const int j = j0 + lj;
+    float wx[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            wy[k] = up_weight(2 * i - 2 + k, i, h, H2, rh);
-            wx[k] = up_weight(2 * j - 2 + k, j, w, W2, rw);
-        }
-        float acc = 0.f;
+    for (int k = 0; k < 7; ++k) wx[k] = up_weight(2 * j - 2 + k, j, w, W2, rw);
+    static_assert(PG_BLOCK % UTX == 0 && UT % (PG_BLOCK / UTX) == 0, "whole passes over the tile");
+#pragma unroll 1
+    for (int li = lrow; li < UT; li += PG_BLOCK / UTX) {
+        const int i = i0 + li;
+        if (i < h && j < w) {
+            float acc = 0.f;
 #pragma unroll
-        for (int a = 0; a < 7; ++a) {
-            if (wy[a] != 0.f) {
-                float row = 0.f;
+            for (int a = 0; a < 7; ++a) {
+                const float wy = up_weight(2 * i - 2 + a, i, h, H2, rh);
+                if (wy != 0.f) {
+                    float row = 0.f;
 #pragma unroll
-                for (int b = 0; b < 7; ++b) row = fmaf(wx[b], G[2 * li + a][2 * lj + b], row);
-                acc = fmaf(wy[a], row, acc);
+                    for (int b = 0; b < 7; ++b) row = fmaf(wx[b], G[b & 1][2 * li + a][lj + (b >> 1)], row);      // column 2 lj + b
+                    acc = fmaf(wy, row, acc);
+                }
             }
+            dx[plane * xs_plane + (int64_t)i * xs_row + j] = acc;
         }
-        dx[plane * xs_plane + (int64_t)i * xs_row + j] = acc;
     }
 }
 
@@ -156,8 +165,7 @@ extern "C" int nf_upsample2x_pad_bwd(const float* d_y_padded, int64_t planes, in
                                      int64_t xs_row, nf_stream_t stream) {
     NF_REQUIRE(planes >= 1 && planes <= 0x7fffffff && h >= 1 && w >= 1 && pad >= 0 && pad < 2 * h && pad < 2 * w && xs_row >= w,
                "nf_upsample2x_pad_bwd: bad arguments (planes %lld h %d w %d pad %d)", (long long)planes, h, w, pad);
-    static_assert(UT * UT == PG_BLOCK, "one thread per source element of a tile");
-    const int tiles_x = (w + UT - 1) / UT, tiles_y = (h + UT - 1) / UT;
+    const int tiles_x = (w + UTX - 1) / UTX, tiles_y = (h + UT - 1) / UT;
     hipLaunchKernelGGL(k_upsample2x_pad_bwd, dim3((unsigned)(tiles_x * tiles_y), (unsigned)planes), dim3(PG_BLOCK), 0, (hipStream_t)stream,
                        d_y_padded, h, w, pad, dx, xs_plane, xs_row, tiles_x);
     NF_LAUNCH_CHECK("nf_upsample2x_pad_bwd");
