@@ -475,7 +475,8 @@ __global__ void __launch_bounds__(NT) k_plane_fwd(const float* __restrict__ x, i
 
 // KEEP_XH: xhat stays in registers between the two steps; otherwise (48 floats per thread already hold d_pre) the second
 // step re-reads x, which the first step just pulled through L2 / Infinity Cache
-template <int NT, int EPT, bool KEEP_XH>
+// XL > 0 (with KEEP_XH false): xhat of the first XL items per thread waits in LDS between the two steps instead of being re-read
+template <int NT, int EPT, bool KEEP_XH, int XL = 0>
 __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp, const float* __restrict__ d_extra,
                                                   const float* __restrict__ yp, const float* __restrict__ x, int C, int H, int W,
                                                   const float* __restrict__ gamma, const float* __restrict__ mean_in,
@@ -495,6 +496,7 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
     const float* xq = x + p * HW;
     const float mean = mean_in[p], rstd = rstd_in[p];
     nf_f4u dv[EPT], xhs[KEEP_XH ? EPT : 1];
+    HIP_DYNAMIC_SHARED(nf_f4u, xh_lds)          // [XL][NT] items
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
@@ -518,6 +520,7 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
             s2 += (double)dv[k][j] * xh[j];
         }
         if (KEEP_XH) xhs[k] = xh;
+        else if (k < XL) xh_lds[k * NT + threadIdx.x] = xh;      // (read back by the same thread)
     }
     block_sum2<NT>(s1, s2);
     const float m1 = (float)(s1 / (double)HW), m2 = (float)(s2 / (double)HW);
@@ -536,6 +539,8 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
         nf_f4u o, xh;
         if (KEEP_XH) {
             xh = xhs[k];
+        } else if (k < XL) {
+            xh = xh_lds[k * NT + threadIdx.x];
         } else {
             nf_f4u xv = load_item(xq + i0, nvalid);
 #pragma unroll
@@ -551,6 +556,9 @@ __global__ void __launch_bounds__(NT) k_plane_bwd(const float* __restrict__ dyp,
 // which plane-resident instantiation holds an H x W plane: 0 none, 1 (256 threads x 3 items), 2 (1024 x 3), 3 (768 x 16: 64 registers
 // of gradient per thread at three waves per SIMD -- 1024 x 12 at four waves per SIMD spilled 46 of its 48, two extra passes of the
 // tensor through scratch memory: 292 MB per launch where 195 MB are the tensors)
+#ifndef NF_PLANE3_XL
+#define NF_PLANE3_XL 13
+#endif
 static int nf_plane_variant(int H, int W) {
     const int64_t items = (int64_t)H * ((W + 3) / 4);
     if (items <= 256 * 3) return 1;
@@ -673,12 +681,26 @@ extern "C" int nf_in_act_pad_bwd(const float* dy_padded, const float* d_extra, c
     if (variant == 3 && d_res) variant = 0;      // (round 2, with the spilling 1024 x 12 form: the two-pass form was faster with a d_res stream)
 #endif
     if (variant) {
-#define NF_PLANE_BWD(NT, EPT, KEEP)                                                                                            \
-    hipLaunchKernelGGL((k_plane_bwd<NT, EPT, KEEP>), dim3((unsigned)planes), dim3(NT), 0, st, dy_padded, d_extra, y_padded, x, C, H, W, \
-                       gamma, mean, rstd, act, pad, d_res, dx, from_x ? beta : nullptr, dy_n_stride, d_extra_sub)
-        if (variant == 1) NF_PLANE_BWD(256, 3, true);
-        else if (variant == 2) NF_PLANE_BWD(1024, 3, true);
-        else NF_PLANE_BWD(768, 16, false);
+#define NF_PLANE_BWD(NT, EPT, KEEP, XL)                                                                                                       \
+    hipLaunchKernelGGL((k_plane_bwd<NT, EPT, KEEP, XL>), dim3((unsigned)planes), dim3(NT), (size_t)(XL) * NT * 16, st, dy_padded, d_extra, y_padded, \
+                       x, C, H, W, gamma, mean, rstd, act, pad, d_res, dx, from_x ? beta : nullptr, dy_n_stride, d_extra_sub)
+        if (variant == 1) NF_PLANE_BWD(256, 3, true, 0);
+        else if (variant == 2) NF_PLANE_BWD(1024, 3, true, 0);
+        else {
+            constexpr int XL = NF_PLANE3_XL;        // XL x 768 x 16 bytes of LDS (one workgroup of 12 waves per CU either way)
+            static bool once_on[NF_MAX_DEVICES] = {};
+            bool& once = once_on[nf_current_device()];
+            if (!once) {
+                if (XL * 768 * 16 > 64 * 1024 &&
+                    hipFuncSetAttribute((const void*)k_plane_bwd<768, 16, false, XL>, hipFuncAttributeMaxDynamicSharedMemorySize, XL * 768 * 16) !=
+                        hipSuccess) {
+                    nf_set_error("nf_in_act_pad_bwd: cannot reserve %d bytes of LDS", XL * 768 * 16);
+                    return 1;
+                }
+                once = true;
+            }
+            NF_PLANE_BWD(768, 16, false, XL);
+        }
 #undef NF_PLANE_BWD
         NF_LAUNCH_CHECK("nf_in_act_pad_bwd (plane)");
         return 0;
