@@ -101,6 +101,9 @@ __device__ __forceinline__ unsigned wb_split_pair(float& x0, float& x1) {
 #endif
 }
 
+#ifndef WB_PIPE_E
+#define WB_PIPE_E 1       // the next chunk's window values are read under the last steps of the current chunk
+#endif
 #define NF_LAUNDER_WB(x) asm volatile("" : "+v"(x))
 #ifdef WB_PHASE_TIMERS
 // TUNING BUILD ONLY (NF_VARIANT_SRC=nf_wino_bf.hip tools/build_variant.sh <name> -DWB_PHASE_TIMERS; tools/experimental/wino_phases.py):
@@ -263,40 +266,67 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
     WB_T(t_pro);
     WB_ACC(7, t_pro - t_begin);
 
+    // ---- a chunk's window rows -> the four row-combined values E[j][0..3] of the lane's 8 channels (channel 2 j + hh).  The values of
+    //      chunk c + 1 are read UNDER the last KB steps of chunk c (WB_PIPE_E): E is dead once column 3 has been split, so its registers take
+    //      the next chunk's values -- four channels per step, raw window values in flight while the step's six products run -- and the
+    //      hand-over (commit + barrier) moves in front of those steps.  (Read at the top of the chunk, right behind the barrier, they were
+    //      17 % of a chunk with nothing of the wave's own to overlap: profiles/r04_wino_phase_timers.txt.)
+    constexpr bool PIPE = WB_PIPE_E != 0;
+    constexpr int HAND = PIPE ? NSTEP - 1 - KB : NSTEP - 1;        // the step the hand-over sits in front of
+    float E[8][4];
+    struct RawE { w2a a0, a1, b0, b1; };
+    auto e_load = [&](const float* pbuf, int j, RawE& r) {
+#ifdef WB_EXP_NO_E
+        const float* pa = pbuf + hh * WN_CH;          // TIMING EXPERIMENT (wrong results): one channel's rows for all eight
+#else
+        const float* pa = pbuf + (2 * j + hh) * WN_CH;
+#endif
+        r.a0 = *reinterpret_cast<const w2a*>(pa + ra * WN_PS), r.a1 = *reinterpret_cast<const w2a*>(pa + ra * WN_PS + 2);
+        r.b0 = *reinterpret_cast<const w2a*>(pa + rb * WN_PS), r.b1 = *reinterpret_cast<const w2a*>(pa + rb * WN_PS + 2);
+    };
+    auto e_combine = [&](int j, const RawE& r) {      // sb = +-1: the fused form is exact
+        E[j][0] = fmaf(sb, r.b0[0], r.a0[0]), E[j][1] = fmaf(sb, r.b0[1], r.a0[1]), E[j][2] = fmaf(sb, r.b1[0], r.a1[0]), E[j][3] = fmaf(sb, r.b1[1], r.a1[1]);
+    };
+    if (PIPE) {
+        const float* pbuf = smem + lbase;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            RawE r;
+            e_load(pbuf, j, r);
+            e_combine(j, r);
+        }
+    }
+
     auto run_chunk = [&](auto last_c, int chunk) {
         constexpr bool last = decltype(last_c)::value;
         const float* pbuf = smem + (chunk & 1) * WN_BUF + lbase;
+        const float* pnext = smem + ((chunk + 1) & 1) * WN_BUF + lbase;
         WB_T(t_c0);
         {
             WB_T(t_c0b);
             WB_ACC(6, t_c0b - t_c0);
         }
-        // ---- this chunk's window rows -> the four row-combined values of the lane's 8 channels (channel 2 j + hh)
-        float E[8][4];
+        if (!PIPE) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-#ifdef WB_EXP_NO_E
-            const float* pa = pbuf + hh * WN_CH;          // TIMING EXPERIMENT (wrong results): one channel's rows for all eight
-#else
-            const float* pa = pbuf + (2 * j + hh) * WN_CH;
-#endif
-            const w2a a0 = *reinterpret_cast<const w2a*>(pa + ra * WN_PS), a1 = *reinterpret_cast<const w2a*>(pa + ra * WN_PS + 2);
-            const w2a b0 = *reinterpret_cast<const w2a*>(pa + rb * WN_PS), b1 = *reinterpret_cast<const w2a*>(pa + rb * WN_PS + 2);
-            // sb = +-1: the fused form is exact
-            E[j][0] = fmaf(sb, b0[0], a0[0]), E[j][1] = fmaf(sb, b0[1], a0[1]), E[j][2] = fmaf(sb, b1[0], a1[0]), E[j][3] = fmaf(sb, b1[1], a1[1]);
-        }
+            for (int j = 0; j < 8; ++j) {
+                RawE r;
+                e_load(pbuf, j, r);
+                e_combine(j, r);
+            }
 #ifdef WB_PHASE_TIMERS
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) NF_LAUNDER_WB(E[j][i]);
+                for (int i = 0; i < 4; ++i) NF_LAUNDER_WB(E[j][i]);
 #endif
+        }
         WB_T(t_e);
         WB_ACC(2, t_e - t_c0);
-        // the next chunk's window travels global -> registers under this chunk's products, -> LDS in front of the last step
+        // the next chunk's window travels global -> registers under this chunk's products, -> LDS in front of step HAND
 #ifndef WB_EXP_NO_FETCH
         if (!last) fetch(chunk + 1);
 #endif
+        RawE nx[4];          // (PIPE) raw window values of four channels of the next chunk, in flight under a step's products
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
             // column nu of B^T d B for the 8 channels, split into bf16 parts: part p of channel pair (2 q, 2 q + 1) -> bv[p][q]
@@ -319,8 +349,8 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 const int s = nu * KB + kb;           // compile-time after unrolling
-                // the chunk hand-over sits in front of the last step, as in nf_wino.hip
-                if (s == NSTEP - 1 && !last) {
+                // the chunk hand-over: in front of the last step (as in nf_wino.hip), or in front of column 3's steps (PIPE)
+                if (s == HAND && !last) {
                     WB_T(t_h0);
 #ifndef WB_EXP_NO_FETCH
                     commit(chunk + 1);
@@ -359,6 +389,23 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                     // [D] next step's A parts
                     read_a(opa[(s + 1) & 1], s + 1);
                 }
+                if (PIPE && !last && nu == 3) {
+                    // column 3 is split: E is free.  The raw values read under the previous step have arrived (the wait above): combine
+                    // them, then start this step's four channels (KB = 1: all eight in two batches under the one step)
+                    constexpr int per = 8 / KB;                    // channels per step
+                    if (kb > 0) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) e_combine(per * (kb - 1) + jj, nx[jj]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) e_load(pnext, per * kb + jj, nx[jj]);
+                    if (per == 8) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) e_combine(jj, nx[jj]);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) e_load(pnext, 4 + jj, nx[jj]);
+                    }
+                }
                 // [E] this step's products: the cross terms of order <= 2^-16
                 const wu4* a = opa[s & 1];
 #define WB_PROD(pa, pb) acc[nu][kb] = WB_MFMA(__builtin_bit_cast(wb8, a[pa]), __builtin_bit_cast(wb8, bv[pb]), acc[nu][kb])
@@ -372,6 +419,10 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                 }
 #undef WB_PROD
             }
+        }
+        if (PIPE && !last) {         // the last four channels, read under the last step
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) e_combine(4 + jj, nx[jj]);
         }
         WB_T(t_c1);
         WB_ACC(1, t_c1 - t_c0);
