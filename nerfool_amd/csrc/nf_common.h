@@ -116,3 +116,32 @@ __device__ __forceinline__ float nf_half_sum(float x) {
     const NfHalves v = nf_halves(x);
     return v.lo + v.hi;
 }
+
+// ---- the bf16x3 operand split (DESIGN "fp32-grade products on the bf16 matrix cores"): two fp32 values -> their bf16 roundings, packed for
+//      the matrix instruction, and the exact remainders in place.  The packed result passes through an EMPTY asm statement: from the plain
+//      C++ form (`u << 16` / `u & 0xffff0000` of the packed pair) the compiler derived x0's rounding a second time with its own
+//      v_cvt_pk_bf16_f32 (6 vector instructions per pair and part instead of 5: 32 of a Winograd chunk's ~350).  (The conversion itself
+//      must stay the compiler's instruction: written as inline asm it reads accumulator registers of a matrix instruction still in flight
+//      -- the hazard recogniser does not look into asm -- and the sample-on-the-lane kernels, which split accumulators directly, were 3 %
+//      off on the hardware.)
+__device__ __forceinline__ unsigned nf_split_pair_bf16(float& x0, float& x1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __bf16 nf_bf16x2 __attribute__((ext_vector_type(2)));
+    const nf_bf16x2 pr = nf_bf16x2{(__bf16)x0, (__bf16)x1};          // v_cvt_pk_bf16_f32 (round to nearest even), x0 in the low half
+    unsigned u = __builtin_bit_cast(unsigned, pr);
+#if !defined(NF_SPLIT_CXX)
+    asm("" : "+v"(u));
+#endif
+    x0 -= __builtin_bit_cast(float, u << 16);
+    x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
+    return u;
+#else
+    const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
+    unsigned short s0, s1;
+    __builtin_memcpy(&s0, &b0, 2);
+    __builtin_memcpy(&s1, &b1, 2);
+    x0 -= (float)b0;
+    x1 -= (float)b1;
+    return (unsigned)s0 | ((unsigned)s1 << 16);
+#endif
+}

@@ -565,24 +565,7 @@ extern "C" int nf_conv_s2_x3_pack(const float* weight, int c_out, int c_in, int 
     return (reinterpret_cast<float*>(piece) - out) == nf_conv_s2_x3_pack_floats(c_out, c_in, 1) ? 0 : 2;
 }
 
-__device__ __forceinline__ unsigned s2_split_pair(float& x0, float& x1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __bf16 s2_bf2 __attribute__((ext_vector_type(2)));
-    const s2_bf2 p = s2_bf2{(__bf16)x0, (__bf16)x1};
-    const unsigned u = __builtin_bit_cast(unsigned, p);
-    x0 -= __builtin_bit_cast(float, u << 16);
-    x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
-    return u;
-#else
-    const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
-    unsigned short s0, s1;
-    memcpy(&s0, &b0, 2);
-    memcpy(&s1, &b1, 2);
-    x0 -= (float)b0;
-    x1 -= (float)b1;
-    return (unsigned)s0 | ((unsigned)s1 << 16);
-#endif
-}
+__device__ __forceinline__ unsigned s2_split_pair(float& x0, float& x1) { return nf_split_pair_bf16(x0, x1); }
 
 __global__ void __launch_bounds__(256, 2) k_conv_s2_bwd3_x3(const float* __restrict__ rec, const float* __restrict__ dy, S2Tensor di, int Ho, int Wo,
                                                             float* __restrict__ dx, S2Tensor xo, int Hi, int Wi, int C, int K, int groups,

@@ -371,24 +371,7 @@ __device__ __forceinline__ void gm_w_start(GmW& w, const float* blob, int depth,
     w.p = p + 2 * GM_CHUNK;
 }
 // two fp32 values -> their bf16 roundings (packed) and the exact remainders
-__device__ __forceinline__ unsigned gm_split_pair(float& x0, float& x1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __bf16 gm_bf2 __attribute__((ext_vector_type(2)));
-    const gm_bf2 pr = gm_bf2{(__bf16)x0, (__bf16)x1};                 // v_cvt_pk_bf16_f32 (round to nearest even)
-    const unsigned u = __builtin_bit_cast(unsigned, pr);
-    x0 -= __builtin_bit_cast(float, u << 16);
-    x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
-    return u;
-#else
-    const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
-    unsigned short s0, s1;
-    memcpy(&s0, &b0, 2);
-    memcpy(&s1, &b1, 2);
-    x0 -= (float)b0;
-    x1 -= (float)b1;
-    return (unsigned)s0 | ((unsigned)s1 << 16);
-#endif
-}
+__device__ __forceinline__ unsigned gm_split_pair(float& x0, float& x1) { return nf_split_pair_bf16(x0, x1); }
 // acc += (32 x 32 block) x (the lane's 16 activations of the k-tile): per k-block the six cross terms of order <= 2^-16
 __device__ __forceinline__ g16 gm_mfma16(const GmChunk& wv, const g16& x, g16 acc) {
 #pragma unroll

@@ -541,24 +541,7 @@ __device__ __forceinline__ f32x16 gemm_small(const float* lds, int rec, int lane
 #define X3_LDS_SHIFT (X3_TAB - MS_BASE)        // lds (table base) - shared-memory base, in floats
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // two fp32 values -> their bf16 roundings (one packed register) and, in place, the exact remainders
-__device__ __forceinline__ unsigned x3_split_pair(float& x0, float& x1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const bf16x2 p = bf16x2{(__bf16)x0, (__bf16)x1};          // v_cvt_pk_bf16_f32, round to nearest even
-    const unsigned u = __builtin_bit_cast(unsigned, p);
-    x0 -= __builtin_bit_cast(float, u << 16);
-    x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
-    return u;
-#else
-    const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
-    unsigned short s0, s1;
-    memcpy(&s0, &b0, 2);
-    memcpy(&s1, &b1, 2);
-    x0 -= (float)b0;
-    x1 -= (float)b1;
-    return (unsigned)s0 | ((unsigned)s1 << 16);
-#endif
-}
+__device__ __forceinline__ unsigned x3_split_pair(float& x0, float& x1) { return nf_split_pair_bf16(x0, x1); }
 // acc += W(group g) . (8 values), all six cross terms
 __device__ __forceinline__ f32x16 x3_group(const float* lds, int g, int lane, float (&v)[8], f32x16 acc) {
     u32x4 b[3];

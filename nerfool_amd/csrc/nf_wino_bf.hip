@@ -82,24 +82,7 @@ extern "C" int nf_wino_bf_pack(const float* weight, int c_out, int c_in, int bac
 }
 
 // two fp32 values -> their bf16 roundings (packed) and the exact remainders
-__device__ __forceinline__ unsigned wb_split_pair(float& x0, float& x1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __bf16 wb2 __attribute__((ext_vector_type(2)));
-    const wb2 p = wb2{(__bf16)x0, (__bf16)x1};                 // v_cvt_pk_bf16_f32 (round to nearest even)
-    const unsigned u = __builtin_bit_cast(unsigned, p);
-    x0 -= __builtin_bit_cast(float, u << 16);
-    x1 -= __builtin_bit_cast(float, u & 0xffff0000u);
-    return u;
-#else
-    const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
-    unsigned short s0, s1;
-    memcpy(&s0, &b0, 2);
-    memcpy(&s1, &b1, 2);
-    x0 -= (float)b0;
-    x1 -= (float)b1;
-    return (unsigned)s0 | ((unsigned)s1 << 16);
-#endif
-}
+__device__ __forceinline__ unsigned wb_split_pair(float& x0, float& x1) { return nf_split_pair_bf16(x0, x1); }
 
 #ifndef WB_PIPE_E
 #define WB_PIPE_E 1       // the next chunk's window values are read under the last steps of the current chunk
