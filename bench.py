@@ -110,7 +110,7 @@ def parse():
     ap.add_argument('--device', choices=('gpu', 'cpu-standin'), default='gpu',
                     help="'cpu-standin': FUNCTIONAL check of the launcher / sharding on a box without a GPU -- the kernels' CPU stand-in "
                          "build (tests/host_harness), gloo, shape-generic kernels; tiny sizes only, never a measurement")
-    ap.add_argument('--event-every', type=int, default=5,
+    ap.add_argument('--event-every', type=int, default=10,
                     help='HIP-event brackets around the roofline kernels on every N-th timed step (1 = every step, 0 = never)')
     return ap.parse_args()
 

@@ -52,7 +52,7 @@ def main():
     md.append('The `--stats` CSVs cover the whole process (warm-up steps included; the Winograd workgroup width is a rule on the shape since round 4, no\n'
               'timing runs); the steady-state tables are the TIMED region only: the kernel trace cut between the fused update kernels of\n'
               'the last warm-up step and of the last timed step.  In the traced runs the bench\'s HIP-event brackets are off (`--event-every 0`);\n'
-              'in the bench lines they are live on every 4th timed step (`roofline_sampling`).  FETCH_SIZE is doubled as MI355X_MICROARCH.md\n'
+              'in the bench lines they are live on every 10th timed step (`roofline_sampling`).  FETCH_SIZE is doubled as MI355X_MICROARCH.md\n'
               'prescribes for gfx950 (confirmed on the delta update: %.2f MB counted vs %.2f MB = 8 streams).\n'
               % (pmc['abi_kernels']['nf_pgd_adam_step']['hbm_bytes_per_launch'] / 1e6,
                  pmc['abi_kernels']['nf_pgd_adam_step']['algorithmic_bytes_per_launch'] / 1e6))
