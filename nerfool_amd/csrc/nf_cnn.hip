@@ -1,7 +1,7 @@
 // Fused "glue" of the ResUNet feature extractor (a14): InstanceNorm + affine + residual + ReLU/ELU + reflect padding in
-// ONE pass over a convolution output, writing the tensor the NEXT convolution consumes (pre-padded, so the vendor
-// convolution runs with padding 0); and the matching backward (fold of the padded gradient, activation derivative,
-// InstanceNorm backward).  The convolutions themselves stay on MIOpen in this round.
+// ONE pass over a convolution output, writing the tensor the NEXT convolution consumes (pre-padded, so the hand-written
+// convolutions -- nf_wino_bf.hip, nf_conv_s2.hip, nf_conv1x1.hip -- run with padding 0); and the matching backward (fold of
+// the padded gradient, activation derivative, InstanceNorm backward).
 //
 // ref: ibrnet/feature_network.py:38-78 (BasicBlock: conv3x3 reflect -> IN -> ReLU -> conv3x3 reflect -> IN -> +id -> ReLU),
 //      :127-140 (conv + IN + ELU), :28-36 (padding_mode='reflect').  PyTorch runs this as 4-5 memory-bound kernels per

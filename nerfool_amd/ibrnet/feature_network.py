@@ -97,8 +97,10 @@ class ResUNet(nn.Module):
         self.upconv2 = _Up(128, 64)
         self.iconv2 = _ConvNormELU(64 + 64, out_ch, 3)
         self.out_conv = nn.Conv2d(out_ch, out_ch, 1, 1)
-        # operand form of the stride-1 3x3 convolutions' Winograd products: None = the module default WINO_OPERANDS (fp32-grade);
-        # 'bf16' = plain bf16 operands, set by IBRNetModel for args.ibrnet_precision == 'bf16' (BASELINE config 5) -- never silently
+        # operand form of the stride-1 3x3 convolutions' Winograd products: None = the module default WINO_OPERANDS (fp32-grade).
+        # DIAGNOSTIC ONLY: nothing in the package sets it -- plain 'bf16' operands were measured for BASELINE config 5 and REJECTED
+        # for the CNN (d loss / d delta cosine 0.78 to the reference's, profiles/r04_plain_bf16_cnn_rejected.txt); config 5's bf16
+        # path is the IBRNet row network only.  tools/diag_bf16_cnn.py sets it to reproduce that measurement.
         self.conv_precision = None
 
     def describe_output(self, H, W):
@@ -160,11 +162,10 @@ class ResUNet(nn.Module):
 # ----------------------------------------------------------------------------------------------------------------------
 # Fused executor: same network, same parameters, explicit forward tape + backward-data pass.
 # Per convolution the module graph launches reflection_pad2d, conv, batch_norm (instance norm), add, relu (and their five
-# backward kernels); here it is conv (padding 0, MIOpen) + ONE fused kernel per direction (csrc/nf_cnn.hip).
+# backward kernels); here it is ONE hand-written convolution on a pre-padded input (padding 0: csrc/nf_wino_bf.hip, nf_conv_s2.hip,
+# nf_conv1x1.hip -- no vendor library on this path) + ONE fused kernel per direction (csrc/nf_cnn.hip).
 # Convolution biases in front of an InstanceNorm are dropped: the norm subtracts the plane mean, so they cancel exactly.
 # ----------------------------------------------------------------------------------------------------------------------
-_aten = torch.ops.aten
-
 
 class _Slot:
     """a plain tensor with a gradient accumulator"""
@@ -368,15 +369,12 @@ def _conv(tape, inp, w, stride, sink, bias=None, operands=None):
         return _conv3x3(tape, inp, w, sink, operands)
     if stride == 2 and bias is None and tuple(w.shape[2:]) in ((3, 3), (7, 7)) and (w.shape[2] == 3 or w.shape[1] <= 3):
         return _conv_s2(tape, inp, w, sink, operands)
-    out = _Slot(_aten.convolution(inp, w, bias, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1))
-
-    def bwd():
-        g = _aten.convolution_backward(out.g, inp, w, None, [stride, stride], [0, 0], [1, 1], False, [0, 0], 1,
-                                       [True, False, False])[0]
-        sink(g)
-        out.g = None
-    tape.append(bwd)
-    return out
+    # no vendor-library fallback on the product path: the reference network (and every checkpoint that loads into it) has only the
+    # shapes above -- anything else is a different network and must say so
+    raise NotImplementedError('ResUNet fused executor: no hand-written kernel for a %dx%d stride-%d convolution %d -> %d%s '
+                              '(3x3 stride-1 needs C_out %% 32 == 0; stride-2 is 3x3, or 7x7 on <= 3 input channels); '
+                              "feature_network.CNN_PATH = 'torch' runs the plain nn.Module graph for comparison"
+                              % (w.shape[2], w.shape[3], stride, w.shape[1], w.shape[0], ' with bias' if bias is not None else ''))
 
 
 def _conv1x1(tape, inp, conv, sink, channels_last_out=False):
@@ -452,15 +450,13 @@ def _upsample_pad(tape, a, pad):
     src = a.interior()
     up = _Act(ops.upsample2x_pad_fwd(src, pad), pad)
     in_size = list(src.shape)
-    out_hw = [2 * in_size[2], 2 * in_size[3]]
 
     def bwd():
-        if up.gi is None:           # the only consumer is the convolution: fold + transposed interpolation in one kernel
-            a.add_i(ops.upsample2x_pad_bwd(up.gp, in_size[2], in_size[3], pad))
-        else:
-            g, _ = ops.in_act_pad_bwd(up.gp, up.gi, up.yp, None, None, None, None, ops.ACT_NONE, pad, False)
-            a.add_i(_aten.upsample_bilinear2d_backward(g, out_hw, in_size, True, None, None))
-        up.gp = up.gi = None
+        # the only consumer of the upsampled tensor is the convolution (feature_network.py:143-151): fold + transposed
+        # interpolation in one kernel; an interior consumer would be another network
+        assert up.gi is None, 'upsampled activation has a second consumer: not the ResUNet graph'
+        a.add_i(ops.upsample2x_pad_bwd(up.gp, in_size[2], in_size[3], pad))
+        up.gp = None
     tape.append(bwd)
     return up
 

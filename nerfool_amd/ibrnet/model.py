@@ -35,8 +35,8 @@ class IBRNetModel(object):
                 self.start_step = 0
 
     def freeze(self):
-        """The attack differentiates w.r.t. the perturbation only: without weight gradients MIOpen runs backward-data
-        convolutions only (the reference accumulates weight gradients that nobody reads, eval_adv.py:805-810)."""
+        """The attack differentiates w.r.t. the perturbation only: the fused executor runs backward-DATA passes only and
+        requires frozen weights (the reference accumulates weight gradients that nobody reads, eval_adv.py:805-810)."""
         for net in (self.net_coarse, self.net_fine, self.feature_net):
             if net is not None:
                 for p in net.parameters():

@@ -74,36 +74,36 @@ def parse_camera(params):
 _content_memo = {}      # id(tensor) -> (weak reference that drops the entry when the tensor dies, data_ptr, _version, content key)
 
 
-def _content_key(t, full=True):
-    """shape + the exact bytes (small tensors: cameras, depth range) or a checksum of the image's bit pattern -- over EVERY element
-    (`full`), or over every 61st 64-bit word when the batch also names the image by its path.  Memoised per tensor object and
-    storage version, so a PGD loop that hands over the same batch dict pays on the first step only; and a MISS stays cheap (a
-    DataLoader hands out fresh tensors every step of the universal loop): wrapping integer sums of the 64-bit words, first and second
-    half separately, on ONE host thread -- 12 ms for 10 x 756 x 1008 x 3 floats, 0.4 ms for the strided form (a multi-threaded torch
-    reduction costs more than that to wake its workers, and the float64 / arange form this replaces ~100 ms per call)."""
+def _content_key(t):
+    """shape + the exact bytes (small tensors: cameras, depth range) or a checksum of the image's bit pattern over EVERY element
+    (an in-place edit of any pixel changes the key, whatever the batch calls the image).  Memoised per tensor object and storage
+    version, so a PGD loop that hands over the same batch dict pays on the first step only; a MISS stays cheap (a DataLoader hands
+    out fresh tensors every step of the universal loop): wrapping integer sums of the 32-bit words, first and second half
+    separately, on ONE host thread -- ~4 ms for 4 x 756 x 1008 x 3 floats (a multi-threaded torch reduction costs more than that to
+    wake its workers).  32-bit words because every element of a float32 tensor is 4-byte aligned, whatever its storage offset
+    (a slice starting at an odd float offset cannot be viewed as 64-bit words)."""
     if t is None:
         return None
     memo = _content_memo.get(id(t))
-    if memo is not None and memo[0]() is t and memo[1] == t.data_ptr() and memo[2] == t._version and memo[4] == full:
+    if memo is not None and memo[0]() is t and memo[1] == t.data_ptr() and memo[2] == t._version:
         return memo[3]
     flat = t.detach().reshape(-1)
     if flat.numel() <= 4096:
         key = (tuple(t.shape), flat.cpu().numpy().tobytes())
     else:
         raw = flat.view(torch.uint8)
-        n8 = raw.numel() // 8 * 8
-        words = raw[:n8].view(torch.int64)
-        if not full:
-            words = words[::61]
+        step = 4 if (raw.storage_offset() % 4 == 0 and raw.numel() >= 4) else 1      # (sub-word dtypes at an odd byte offset: bytes)
+        n4 = raw.numel() // step * step
+        words = raw[:n4].view(torch.int32) if step == 4 else raw[:n4]
         half = words.numel() // 2
         if words.is_cuda:
-            sums = (int(words[:half].sum()), int(words[half:].sum()))
+            sums = (int(words[:half].sum(dtype=torch.int64)), int(words[half:].sum(dtype=torch.int64)))
         else:
             w = words.numpy()
-            sums = (int(w[:half].sum()), int(w[half:].sum()))
-        key = (tuple(t.shape), str(t.dtype), full) + sums + (raw[n8:].cpu().numpy().tobytes(),)
+            sums = (int(w[:half].sum(dtype=np.int64)), int(w[half:].sum(dtype=np.int64)))
+        key = (tuple(t.shape), str(t.dtype)) + sums + (raw[n4:].cpu().numpy().tobytes(),)
     ident = id(t)
-    _content_memo[ident] = (weakref.ref(t, lambda _r, ident=ident: _content_memo.pop(ident, None)), t.data_ptr(), t._version, key, full)
+    _content_memo[ident] = (weakref.ref(t, lambda _r, ident=ident: _content_memo.pop(ident, None)), t.data_ptr(), t._version, key)
     return key
 
 
@@ -138,16 +138,14 @@ class RaySamplerSingleImage(object):
         """Same object for the same target view: the attack loop calls this every iteration, and a DataLoader hands out a
         fresh dict (fresh tensors) for the same view every epoch.  The key is therefore CONTENT: the image path, the exact
         camera / depth-range bytes and checksums of the images (`_content_key`: memoised per tensor object, so the steady state
-        of a loop costs a few dictionary look-ups; a batch that names its image by `rgb_path`, as the reference's loaders do, is
-        checksummed on a stride, one without a path in full) -- not object identity, and the cached sampler holds no reference
-        to the batch dict."""
+        of a loop costs a few dictionary look-ups; every image element enters the checksum, with or without an `rgb_path`) -- not
+        object identity, and the cached sampler holds no reference to the batch dict."""
         path = data.get('rgb_path')
         if isinstance(path, str):
             path = (path,)
-        full = not path
         key = (tuple(path or ()), str(device), tuple(sorted(kw.items())),
                _content_key(data['camera']), _content_key(data['depth_range']), _content_key(data.get('src_cameras')),
-               _content_key(data.get('rgb'), full), _content_key(data.get('src_rgbs'), full))
+               _content_key(data.get('rgb')), _content_key(data.get('src_rgbs')))
         hit = cls._cache.pop(key, None)           # small LRU: the universal loop cycles over the training views
         if hit is None:
             hit = cls(data, device, **kw)

@@ -739,7 +739,7 @@ def _wino_launch(records, kpg, n_split, x, xs, Hi, Wi, pad, y_ptr, ys, Ho, Wo, N
                 ys[0], ys[1], ys[2], Ho, Wo, N, c_in, c_out, 0)
 
 
-def conv3x3_wino(records, x, c_out, pad, tile_blocks=0, k_per_group=None, n_split=0):
+def conv3x3_wino(records, x, c_out, pad, k_per_group=None, n_split=0):
     """3x3 stride-1 convolution of x [N, c_in, Hi, Wi] (unit column stride) with zero padding `pad` (0: the network's
     forward on pre-padded activations, 2: its backward-data on the gradient) -> [N, c_out, Hi - 2 + 2 pad, Wi - 2 + 2 pad].
     k_per_group / n_split must be the values the records were packed with."""

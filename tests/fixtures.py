@@ -107,3 +107,49 @@ def second_target_view(data, shift=(0.12, -0.05, 0.03), seed=77):
     out['rgb'] = _smooth_image(torch.Generator().manual_seed(seed), H, W)[None]
     out['rgb_path'] = ['golden_view_b']
     return out
+
+
+# whole-attack outcome cases (tests/golden/attack100_<tag>.npz, made by tests/golden/make_golden_r05.py): every input is regenerated
+# from seeds; the reference's settings are its defaults (config.py:119-169: adv_iters 100, epsilon 8, lr_step_size 100, lr_gamma 0.5)
+# with README.md:64's --use_adam --adam_lr 1e-3.  c1 = BASELINE config 1's shape (V 4, 16 + 16 = 32 samples per ray, 100 iterations),
+# c2 = config 2's sampling (64 + 64 samples, N_rand 512) on a half-size LLFF frame so that the reference's float64 run fits an hour.
+ATTACK100 = {
+    'c1': dict(H=96, W=128, V=4, S=16, N_imp=16, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
+               lr_gamma=0.5, seed=8, chunk_size=4096, delta_stride=1),
+    'c2': dict(H=378, W=504, V=4, S=64, N_imp=64, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
+               lr_gamma=0.5, seed=9, chunk_size=4096, delta_stride=5),
+}
+
+
+def attack100_inputs(c):
+    """(data, ResUNet state, coarse params, fine params, delta0) of a whole-attack case; the same call is made by
+    tests/golden/make_golden_r05.py in front of the reference."""
+    from nerfool_amd.synthetic import make_scene
+    from oracle.feature_net_ref import random_resunet_state
+    from oracle.ibrnet_ref import random_ibrnet_params
+    data = make_scene(c['H'], c['W'], c['V'], seed=c['seed'], tilt=0.3)
+    cnn_sd = random_resunet_state(c['seed'] + 100)
+    pc = random_ibrnet_params(c['S'], seed=30 + c['seed'])
+    pf = random_ibrnet_params(c['S'] + c['N_imp'], seed=40 + c['seed'])
+    gen = torch.Generator().manual_seed(c['seed'] + 5)
+    eps = c['epsilon'] / 255.
+    delta0 = torch.zeros_like(data['src_rgbs']).uniform_(-eps, eps, generator=gen)
+    delta0 = torch.max(torch.min(delta0, 1 - data['src_rgbs']), 0 - data['src_rgbs'])
+    return data, cnn_sd, pc, pf, delta0
+
+
+def attack_outcome_stats(a, b, eps):
+    """Distances between the outcomes of two runs of one attack (dicts with losses [T], delta (flat or strided sample), image
+    [H,W,3], psnr): the quantities the whole-attack parity test bounds by multiples of the reference's own fp32-vs-float64 values."""
+    la, lb = np.asarray(a['losses'], dtype=np.float64), np.asarray(b['losses'], dtype=np.float64)
+    da, db = np.asarray(a['delta'], dtype=np.float64).reshape(-1), np.asarray(b['delta'], dtype=np.float64).reshape(-1)
+    ia, ib = np.asarray(a['image'], dtype=np.float64), np.asarray(b['image'], dtype=np.float64)
+    at = lambda d: float((np.abs(d) >= eps * (1 - 1e-5)).mean())
+    return dict(loss_rel_max=float(np.max(np.abs(la - lb) / lb)),
+                loss_rel_mean=float(np.mean(np.abs(la - lb) / lb)),
+                loss_last10_rel=float(abs(la[-10:].mean() - lb[-10:].mean()) / lb[-10:].mean()),
+                delta_mean_abs_over_eps=float(np.mean(np.abs(da - db)) / eps),
+                delta_sign_disagree=float(np.mean(np.sign(da) != np.sign(db))),
+                frac_at_eps_diff=abs(at(da) - at(db)),
+                image_rms=float(np.sqrt(np.mean((ia - ib) ** 2))),
+                psnr_diff=abs(float(a['psnr']) - float(b['psnr'])))

@@ -633,6 +633,101 @@ def check_attack_loops(dev):
     assert float((moved - expect)[inside].abs().max()) <= 1e-7
 
 
+# stat -> (multiple of the reference's own run-to-run floor, absolute allowance): the bars of the whole-attack outcome test.  The
+# floors are MEASURED on the reference (tests/golden/make_golden_r05.py: its float32 loop, its float64 loop and its float32 loop with
+# another summation order, pairwise); after 100 Adam-ascent iterations they are large -- a third of the perturbation's entries sit a
+# quarter of eps apart between the reference's own fp32 and float64 runs -- so what the test bounds is that the HIP trajectory is not
+# FURTHER from the reference's float64 run than twice what the reference's own float32 runs are.
+ATTACK100_BARS = {'loss_rel_max': (2.0, 0.0), 'loss_rel_mean': (2.0, 0.0), 'loss_last10_rel': (2.0, 5e-3),
+                  'delta_mean_abs_over_eps': (2.0, 0.0), 'delta_sign_disagree': (2.0, 0.0), 'frac_at_eps_diff': (2.0, 1e-2),
+                  'image_rms': (2.0, 0.0), 'psnr_diff': (2.0, 0.1)}
+
+
+def attack100_floor(g):
+    """the reference's own floor per statistic: the largest of its three run-to-run distances"""
+    pairs = ('ref32_vs_ref64', 'alt32_vs_ref64', 'ref32_vs_alt32')
+    return {k: max(float(g.np('floor/%s/%s' % (p, k))) for p in pairs) for k in ATTACK100_BARS}
+
+
+def attack100_compare(tag, name, mine, g, eps, log=None):
+    """outcome statistics of a run (`mine`: losses, delta sample, image, psnr) against the reference's float64 and float32 runs;
+    asserts the bars against float64"""
+    from fixtures import attack_outcome_stats
+    floor = attack100_floor(g)
+    lines = []
+    for ref in ('ref64', 'ref32'):
+        want = dict(losses=g.np(ref + '/losses'), delta=g.np(ref + '/delta'), image=g.np(ref + '/image'), psnr=float(g.np(ref + '/psnr')))
+        st = attack_outcome_stats(mine, want, eps)
+        lines.append('[attack100 %s] %s vs reference %s: %s' % (tag, name, ref, '  '.join('%s %.3e (floor %.3e)' % (k, st[k], floor[k])
+                                                                                     for k in sorted(st))))
+        if ref == 'ref64':
+            st64 = st
+    lines.append('[attack100 %s] PSNR of the attacked render: %s %.3f dB | reference float64 %.3f float32 %.3f (clean %.3f) | entries at +-eps: '
+                 '%s %.4f | reference %.4f / %.4f' % (tag, name, mine['psnr'], float(g.np('ref64/psnr')), float(g.np('ref32/psnr')),
+                                                      float(g.np('ref64/psnr_clean')), name,
+                                                      float((np.abs(np.asarray(mine['delta'])) >= eps * (1 - 1e-5)).mean()),
+                                                      float(g.np('ref64/frac_at_eps')), float(g.np('ref32/frac_at_eps'))))
+    for ln in lines:
+        print(ln)
+        if log is not None:
+            log.append(ln)
+    for k, (mult, allow) in ATTACK100_BARS.items():
+        assert st64[k] <= mult * floor[k] + allow, '%s %s: %s = %.3e against %.1f x the reference floor %.3e (+ %.1e)' % (
+            tag, name, k, st64[k], mult, floor[k], allow)
+    # the first iterations, before the trajectories part: the reference's losses to rounding
+    assert_close(np.asarray(mine['losses'][:3]), g.np('ref64/losses')[:3], 2e-3, 1e-6, 'first free-running losses')
+    return st64
+
+
+def check_attack100(dev, tag='c1', log=None):
+    """A WHOLE view-specific attack, free-running, against the reference's own runs of it (tests/golden/attack100_<tag>.npz):
+    eval_adv.py:781-843 (100 Adam-ascent iterations on the RandomState(234) pixel stream) -> :863-886 (render of the attacked
+    sources) -> PSNR.  Compared: loss trajectory, final perturbation (mean distance in units of eps, sign agreement, share of
+    entries at +-eps), attacked image, PSNR -- each bounded by twice the reference's own float32-vs-float64 distance."""
+    from fixtures import ATTACK100, attack100_inputs
+    g = Golden('attack100_' + tag)
+    c = ATTACK100[tag]
+    data, cnn_sd, p_coarse, p_fine, delta0 = attack100_inputs(c)
+    eps = c['epsilon'] / 255.0
+    feature_net = ResUNet(coarse_out_ch=32, fine_out_ch=32)
+    feature_net.load_state_dict(cnn_sd, strict=True)
+    for p in feature_net.parameters():
+        p.requires_grad_(False)
+    model = SimpleNamespace(net_coarse=make_net(p_coarse, c['S'], True, dev), net_fine=make_net(p_fine, c['S'] + c['N_imp'], True, dev),
+                            feature_net=feature_net.to(dev).eval())
+    args = SimpleNamespace(N_rand=c['N_rand'], sample_mode='uniform', center_ratio=0.8, N_samples=c['S'], N_importance=c['N_imp'],
+                           inv_uniform=True, det=True, white_bkgd=False, epsilon=c['epsilon'], adv_lr=2, use_adam=True,
+                           adam_lr=c['adam_lr'], lr_step_size=c['lr_step_size'], lr_gamma=c['lr_gamma'], adv_iters=c['adv_iters'],
+                           chunk_size=c['chunk_size'])
+    sampler = RaySamplerSingleImage(data, dev)
+    src = sampler.get_all()
+    product_sample_ray.rng.seed(234)
+    attack = EA.PGDAttack(args, model, Projector(dev), src, delta=delta0.to(dev).clone().requires_grad_(True))
+    losses = [attack.step(data) for _ in range(c['adv_iters'])]
+    # the pixel stream the loop consumed is the reference's
+    rs, pick_sum = np.random.RandomState(234), 0
+    for it in range(c['adv_iters']):
+        pick_sum += int(rs.choice(c['H'] * c['W'], size=(c['N_rand'],), replace=False).astype(np.int64).sum()) * (it + 1)
+    assert pick_sum == int(g.np('pick_checksum'))
+    nxt = rs.choice(c['H'] * c['W'], size=(c['N_rand'],), replace=False)
+    assert np.array_equal(sampler.sample_random_pixel(c['N_rand'], 'uniform'), nxt), 'the loop left the RandomState(234) stream elsewhere'
+    losses = np.array([float(x) for x in losses])
+    d = attack.delta.detach()
+    assert float(d.abs().max()) <= eps + 1e-7
+    x = src['src_rgbs'] + d
+    assert float(x.min()) >= -1e-6 and float(x.max()) <= 1 + 1e-6
+    with torch.no_grad():
+        featmaps = model.feature_net(x.squeeze(0).permute(0, 3, 1, 2))
+        ret = render_single_image(ray_sampler=sampler, ray_batch=sampler.get_all(), model=model, projector=Projector(dev),
+                                  chunk_size=c['chunk_size'], det=True, N_samples=c['S'], inv_uniform=True, N_importance=c['N_imp'],
+                                  white_bkgd=False, featmaps=featmaps, args=None, src_ray_batch=src)
+    image = ret['outputs_fine']['rgb'].double().numpy()
+    gt = data['rgb'][0].double().numpy()
+    mine = dict(losses=losses, delta=d.cpu().double().numpy().reshape(-1)[::c['delta_stride']], image=image,
+                psnr=float(-10. * np.log10(np.mean((image - gt) ** 2))))
+    return attack100_compare(tag, 'HIP path', mine, g, eps, log)
+
+
 def check_evaluate_view(dev):
     """eval_views.evaluate_view (the evaluation loop of eval.py / eval_adv.py:861-905) on the attack fixture: adversarial
     render with the reference's final delta -> the reference's fine PSNR; delta = 0 equals the clean render."""
@@ -1250,11 +1345,11 @@ def check_eval_views_gnt_and_frames(dev):
 def check_bf16_config5(dev):
     """BASELINE config 5 ("bf16 MFMA path"): the per-(sample, view) row network of IBRNet on bf16 matrix-core operands with fp32
     accumulation (nf_ibrnet_fwd/bwd_mfma_bf16), V = 8, 128 coarse + 256 fine samples, against the reference's fp32 capture.
-    STATED TOLERANCE of the bf16 path (an fp32 figure of 1e-3 cannot hold with 8-bit mantissas at the matrix-core inputs):
-    rendered colour within 2e-2 of full scale, loss within 3e-2 relative, d loss / d feature maps within 1.5e-1 relative L2 of the
-    fp32 kernels' gradient (measured on the MI355X: colour 2e-3 .. 5e-3, loss 3.5e-3, gradient 5e-2 .. 1e-1 -- a PGD step only
-    uses the Adam-normalised / sign of the gradient); the achieved numbers are printed.  The fp32 kernels on the same fixture meet 1e-3
-    (test_render_rays[ibrnet_c5_v8])."""
+    STATED TOLERANCE of the bf16 path (an fp32 figure of 1e-3 cannot hold with 8-bit mantissas at the matrix-core inputs), round 5:
+    three times what is measured on the MI355X (profiles/r04_parity_numbers.txt, r05_parity_numbers.txt) -- rendered colour within
+    1.5e-2 of full scale (measured 4.7e-3 / 2.0e-3), loss within 1e-2 relative (3.3e-3), d loss / d feature maps within 7e-2 relative
+    L2 of the fp32 kernels' gradient (2.2e-2 / 1.1e-2); the achieved numbers are printed.  The fp32 kernels on the same fixture meet
+    1e-3 (test_render_rays[ibrnet_c5_v8])."""
     g = Golden('ibrnet_c5_v8')
     cfg = g.stage_cfg()
     rb = g.ray_batch(dev)
@@ -1298,23 +1393,23 @@ def check_bf16_config5(dev):
         e32 = float(np.abs(res['fp32'][0][level]['rgb'].detach().cpu().numpy() - want).max())
         e16 = float(np.abs(res['bf16'][0][level]['rgb'].detach().cpu().numpy() - want).max())
         print('[config 5] %s rgb max abs error vs the reference: fp32 kernels %.2e, bf16 kernels %.2e' % (level, e32, e16))
-        assert e32 <= 1e-3 and e16 <= 2e-2
+        assert e32 <= 1e-3 and e16 <= 1.5e-2
     l32, l16 = res['fp32'][1], res['bf16'][1]
     print('[config 5] loss: reference %.6f fp32 kernels %.6f bf16 kernels %.6f' % (ref_loss, l32, l16))
-    assert abs(l32 - ref_loss) <= 1e-3 * ref_loss and abs(l16 - ref_loss) <= 3e-2 * ref_loss
+    assert abs(l32 - ref_loss) <= 1e-3 * ref_loss and abs(l16 - ref_loss) <= 1e-2 * ref_loss
     for name, a, b in zip(('coarse', 'fine'), res['fp32'][2], res['bf16'][2]):
         err = float((b - a).norm() / a.norm())
         print('[config 5] d loss / d featmap_%s: bf16 vs fp32 kernels rel-L2 %.3e' % (name, err))
-        assert err <= 1.5e-1
+        assert err <= 7e-2
 
 
 def check_bf16_attack(dev):
     """The ATTACK with args.ibrnet_precision = 'bf16' (BASELINE config 5 names a universal attack on the bf16 path): PGD steps of the
     view-specific loop and the reference's universal loop over two target views, teacher-forced from the reference's fp32 captures
-    (attack_tiny.npz, attack_extra.npz).  STATED TOLERANCES of the bf16 path, as in check_bf16_config5: loss within 3e-2 relative of
-    the reference's (measured on the MI355X: 1e-5 .. 2e-3); d loss / d delta within 2e-1 relative L2 of the reference's fp32 gradient
-    and pointing the same way (cosine >= 0.98; measured 1.5e-2 .. 1.4e-1, cosine 0.990 .. 0.9999: the CNN backward amplifies the 5e-2
-    .. 1e-1 error of d feature maps on some steps) -- the update only uses the Adam-normalised gradient / its sign; the fused update
+    (attack_tiny.npz, attack_extra.npz).  STATED TOLERANCES of the bf16 path, three times what is measured on the MI355X: loss within
+    6e-3 relative of the reference's (measured 2e-5 .. 1.9e-3); d loss / d delta within 2e-1 relative L2 of the reference's fp32
+    gradient and pointing the same way (cosine >= 0.995; measured 1.3e-2 .. 7.0e-2, cosine 0.9986 .. 0.9999: the CNN backward
+    amplifies the error of d feature maps on some steps) -- the update only uses the Adam-normalised gradient / its sign; the fused update
     itself is fp32 and must reproduce torch-Adam on the bf16 path's OWN gradient to 2e-7.  Achieved numbers are printed."""
     from fixtures import second_target_view
     g, args, model, data, sampler, dims = _attack_setup(dev)
@@ -1330,8 +1425,8 @@ def check_bf16_attack(dev):
         cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
         lerr = abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))
         print('[bf16 attack] %s: loss rel err %.2e | d loss / d delta vs the reference fp32: rel-L2 %.3e, cosine %.5f' % (tag, lerr, rel, cos))
-        assert lerr <= 3e-2, tag
-        assert rel <= 2e-1 and cos >= 0.98, tag
+        assert lerr <= 6e-3, tag
+        assert rel <= 2e-1 and cos >= 0.995, tag
 
     # view-specific loop: three teacher-forced Adam steps + the update on the path's own gradient
     deltas = [g.t('in/delta0', dev)] + [g.t('adam/delta_%d' % i, dev) for i in (1, 2, 3)]

@@ -146,6 +146,18 @@ def test_universal_trajectory():
     pc.check_universal_trajectory('cuda')
 
 
+@pytest.mark.parametrize('tag', ['c1', 'c2'])
+def test_whole_attack_outcome(tag):
+    """a whole free-running view-specific attack (100 Adam-ascent iterations, attacked render, PSNR) against the reference's own
+    float32 / float64 runs of it: tests/golden/attack100_<tag>.npz, bars = twice the reference's own run-to-run distance"""
+    log = []
+    pc.check_attack100('cuda', tag, log)
+    out = os.environ.get('NERFOOL_PARITY_LOG')
+    if out:
+        with open(out, 'a') as f:
+            f.write('\n'.join(log) + '\n')
+
+
 def test_eval_views_gnt_and_frames():
     pc.check_eval_views_gnt_and_frames('cuda')
 
@@ -304,14 +316,15 @@ def test_c5_full_size_properties():
     """BASELINE config 5 at its full sizes (512x512 sources, V = 8, 128 coarse + 128 importance = 256 fine samples, 512 rays, white
     background, DeepVoxels depth range, row network on bf16 matrix-core operands: configs/ibrnet/eval_deepvoxels.txt,
     ibrnet/mlp_network.py:222-274): the invariants of the fp32 test, and the bf16 path against the fp32 kernels on the same inputs at
-    the tolerance DESIGN section 2 states for it (colour 2e-2 of full scale, feature-map gradient 1.5e-1 relative L2)."""
+    the tolerance DESIGN section 2 states for it, three times what is measured (colour 7e-3 of full scale against 2.3e-3 / 1.7e-3
+    measured, feature-map gradients 2.5e-2 relative L2 against 7.0e-3 / 5.9e-3: profiles/r04_parity_numbers.txt)."""
     shape = dict(H=512, W=512, V=8, R=512, S=128, N=128, depth_range=(3.2, 4.8), white_bkgd=True)
     b = _full_size_render_properties(precision='bf16', **shape)
     f = _full_size_render_properties(precision='fp32', **shape)
     for k in ('rgb_c', 'rgb_f'):
         err = float((b[k] - f[k]).abs().max())
         print('[config 5 full size] %s: bf16 rows vs fp32 rows max abs %.2e' % (k, err))
-        assert err <= 2e-2, (k, err)
+        assert err <= 7e-3, (k, err)
     # the fine depths are a continuous function of the coarse weights (inverse CDF), so they move a little everywhere and by a bin
     # where a bf16-moved weight tips a draw across a cdf edge: most within 1e-3 of the depth range, few beyond 5 % of it
     dz = (b['z_f'] - f['z_f']).abs() / (4.8 - 3.2)
@@ -321,7 +334,7 @@ def test_c5_full_size_properties():
     for k in ('g_c', 'g_f'):
         rel = float((b[k] - f[k]).norm() / f[k].norm())
         print('[config 5 full size] %s: bf16 rows vs fp32 rows rel-L2 %.2e' % (k, rel))
-        assert rel <= (1.5e-1 if k == 'g_c' else 3e-1), (k, rel)
+        assert rel <= 2.5e-2, (k, rel)
 
 
 def test_full_size_properties():

@@ -23,8 +23,8 @@ def _scene(seed=0, H=40, W=56, V=3, path=None):
 def test_sampler_cache_keys_on_content_not_identity(with_path):
     """RaySamplerSingleImage.cached: a DataLoader hands out FRESH tensors for the same view every step of the reference's universal
     loop (eval/ibrnet/eval_adv.py:652-740 `for data in train_loader`) -- equal content must hit, an edit anywhere in an image must
-    miss (without a path: full checksum; with `rgb_path`: path + cameras + a strided checksum, so an edit is caught when the path or
-    a camera changes with it, which is what distinguishes two views of a scene)."""
+    miss, with or without an `rgb_path` (every element enters the checksum; round 4's strided form under a path let a sparse
+    in-place edit return the stale sampler)."""
     from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage
     RaySamplerSingleImage._cache.clear()
     path = 'scene/images/007.png' if with_path else None
@@ -37,17 +37,30 @@ def test_sampler_cache_keys_on_content_not_identity(with_path):
     moved['camera'][0, 20] += 1e-3                                           # another target pose
     assert RaySamplerSingleImage.cached(moved, 'cpu') is not s0
     edited = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
-    edited['src_rgbs'][0, 1, 5, 5, 1] += 1e-3                                # one element
-    if with_path:
-        edited['rgb_path'] = ['scene/images/008.png']
+    edited['src_rgbs'][0, 1, 5, 5, 1] += 1e-3                                # one element, same path
     assert RaySamplerSingleImage.cached(edited, 'cpu') is not s0
     dense = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
     dense['src_rgbs'] += 1e-3                                                # a perturbation of the whole image: seen on the stride too
     assert RaySamplerSingleImage.cached(dense, 'cpu') is not s0
     # an in-place edit of a tensor already seen bumps its version counter: no stale memo
     a['src_rgbs'][0, 0].mul_(0.5)
-    if not with_path:
-        assert RaySamplerSingleImage.cached(a, 'cpu') is not s0
+    assert RaySamplerSingleImage.cached(a, 'cpu') is not s0
+    RaySamplerSingleImage._cache.clear()
+
+
+def test_sampler_cache_key_accepts_slices_at_odd_float_offsets():
+    """a contiguous slice whose storage offset is an odd number of floats (imgs[1:] with an odd number of floats per image) is a
+    valid batch tensor: the checksum reads 32-bit words, which every float32 element is aligned to"""
+    from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage, _content_key
+    RaySamplerSingleImage._cache.clear()
+    a = _scene(H=41, W=57, V=3)                       # 41 * 57 * 3 = 7011 floats per image: odd
+    stack = torch.cat([torch.zeros(1, 1, 41, 57, 3), a['rgb'][None], a['src_rgbs']], dim=1)      # [1, 5, H, W, 3]
+    view = dict(a, rgb=stack[:, 1], src_rgbs=stack[:, 2:])
+    assert (view['src_rgbs'].storage_offset() * 4) % 8 == 4 and view['src_rgbs'].is_contiguous()
+    k = _content_key(view['src_rgbs'])
+    assert k == _content_key(view['src_rgbs'].clone())
+    s0 = RaySamplerSingleImage.cached(view, 'cpu')
+    assert RaySamplerSingleImage.cached(a, 'cpu') is s0                      # same content, other storage
     RaySamplerSingleImage._cache.clear()
 
 

@@ -262,3 +262,39 @@ def test_oracle_float64_gradient_matches_reference_float64(case):
     assert abs(rel(g64.np(case + '/grad32').astype(np.float64), ref64) - floor) < 1e-6
     loss32, grad32 = run(torch.float32)
     assert rel(grad32, ref64) < 3 * floor, 'oracle fp32 %.3e vs floor %.3e' % (rel(grad32, ref64), floor)
+
+
+def test_oracle_whole_attack_outcome_c1():
+    """The OUTCOME of a whole attack (tests/golden/attack100_c1.npz: the reference's eval_adv.py:781-843 loop, 100 Adam-ascent
+    iterations at BASELINE config 1's shape, then :863-886's render of the attacked sources and its PSNR -- run by the reference in
+    float32, in float64 and in float32 with another summation order).  The oracle's free-running loop on the same seeded inputs must
+    end no further from the reference's float64 run than twice the reference's own run-to-run distance, statistic by statistic
+    (tests/parity_cases.py:ATTACK100_BARS); the GPU test asserts the same of the HIP path."""
+    import parity_cases as pcases
+    from fixtures import ATTACK100, attack100_inputs
+    g = Golden('attack100_c1')
+    c = ATTACK100['c1']
+    data, cnn, pc, pf, delta0 = attack100_inputs(c)
+    cam = data['camera']
+    ro, rd = ib.rays_single_image(c['H'], c['W'], cam[:, 2:18].reshape(-1, 4, 4), cam[:, 18:34].reshape(-1, 4, 4))
+    gt = data['rgb'].reshape(-1, 3)
+    src = {'src_rgbs': data['src_rgbs'], 'src_cameras': data['src_cameras']}
+    rng = atk.new_pixel_rng()
+    cfg = dict(N_samples=c['S'], N_importance=c['N_imp'], inv_uniform=True, white_bkgd=False)
+
+    def batch(_):
+        idx = torch.from_numpy(atk.pick_pixels(rng, c['H'] * c['W'], c['N_rand']))
+        return {'ray_o': ro[idx], 'ray_d': rd[idx], 'rgb': gt[idx], 'camera': cam, 'depth_range': data['depth_range'],
+                'src_rgbs': src['src_rgbs'], 'src_cameras': src['src_cameras']}
+    delta, losses, _, _ = atk.pgd_attack(delta0, cnn, pc, pf, src, batch, cfg, c['adv_iters'], use_adam=True, adam_lr=c['adam_lr'],
+                                         lr_step_size=c['lr_step_size'], lr_gamma=c['lr_gamma'], epsilon=float(c['epsilon']))
+    with torch.no_grad():
+        featmaps = fnet.resunet_forward(cnn, (src['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
+        rb = {'ray_o': ro, 'ray_d': rd, 'rgb': gt, 'camera': cam, 'depth_range': data['depth_range'],
+              'src_rgbs': src['src_rgbs'], 'src_cameras': src['src_cameras']}
+        ret = ib.render_single_image(c['H'], c['W'], rb, pc, pf, featmaps, c['chunk_size'], c['S'], inv_uniform=True,
+                                     N_importance=c['N_imp'], det=True)
+    image = ret['outputs_fine']['rgb'].double().numpy()
+    mine = dict(losses=np.array(losses), delta=delta.double().numpy().reshape(-1)[::c['delta_stride']], image=image,
+                psnr=float(-10. * np.log10(np.mean((image - data['rgb'][0].double().numpy()) ** 2))))
+    pcases.attack100_compare('c1', 'oracle (PyTorch-CPU restatement)', mine, g, c['epsilon'] / 255.0)
