@@ -37,7 +37,15 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3      # MI355X fp32 MFMA / vector peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec peak
-PMC_PROFILE = 'profiles/r04_pmc_traffic.json'
+PMC_PROFILE = 'profiles/r05_pmc_traffic.json'
+# kernels whose matrix products run on the bf16 pipe with every fp32 operand split in three (round 4): priced against the bf16 peak
+X3_KERNELS = {
+    'nf_conv3x3_wino': 'achieved = 6 x the Winograd-domain products (each counted once in fp32_grade_tflops); direct-form rate in direct_form_equivalent_tflops',
+    'nf_ibrnet_fwd_mfma': 'sample-on-the-lane forward: achieved = 6 x the algorithmic FLOPs of IBRNet.forward -- an UPPER bound on the executed '
+                          'bf16 FLOPs (this form multiplies the view-invariant part of base_fc.0 once per sample; the per-ray attention runs in fp32)',
+    'nf_gnt_fwd_mfma': 'achieved = 6 x the algorithmic FLOPs: upper bound (the streamed GEMMs run split, the attention products in fp32)',
+    'nf_gnt_bwd_mfma': 'achieved = 6 x the algorithmic FLOPs: upper bound (the streamed GEMMs run split, the attention products in fp32)',
+}
 ROOFLINE_KERNELS = ('nf_ibrnet_fwd', 'nf_ibrnet_bwd', 'nf_ibrnet_fwd_mfma', 'nf_ibrnet_bwd_mfma', 'nf_ibrnet_fwd_mfma_bf16',
                     'nf_ibrnet_bwd_mfma_bf16', 'nf_project_gather_fwd',
                     'nf_project_gather_bwd', 'nf_gnt_fwd', 'nf_gnt_fwd_mfma', 'nf_gnt_bwd', 'nf_gnt_bwd_mfma', 'nf_pgd_adam_step',
@@ -60,7 +68,7 @@ def pmc_traffic(kernel, a):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     in their own runs of this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the
     profile does not cover this workload: counters cannot be read from inside the benchmark process."""
-    for rel in (PMC_PROFILE, 'profiles/r03_pmc_traffic.json', 'profiles/r02_pmc_traffic.json'):
+    for rel in (PMC_PROFILE, 'profiles/r04_pmc_traffic.json', 'profiles/r03_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 prof = json.load(f)
@@ -103,6 +111,8 @@ def parse():
                     help='N > 1: --n-rand rays per rank (weak) or split over the ranks (strong)')
     ap.add_argument('--cpu-iters', type=int, default=10, help='timed CPU-oracle PGD iterations for cpu_baseline after 2 warm-ups (0 = skip)')
     ap.add_argument('--extras', type=int, default=1, help='0 = only the headline timed region (profiling runs)')
+    ap.add_argument('--attack-iters', type=int, default=1000,
+                    help='iterations of the MEASURED whole-attack leg (extra.attack_<N>_iters_wall_s; single GPU, config 2; 0 = skip)')
     ap.add_argument('--conv-operands', choices=('bf16x3', 'fp32'), default='bf16x3',
                     help="operand form of the 3x3 convolutions' Winograd products: 'bf16x3' (default of the package: every fp32 operand as "
                          "three bf16 parts on the bf16 matrix cores, six cross terms, error at fp32 rounding level) or 'fp32' "
@@ -354,6 +364,7 @@ def spawn_ranks(n):
                                       stdout=out0 if r == 0 else sys.stderr))
     rc = 0
     alive = list(procs)
+    deadline = None           # set when a rank failed: the survivors get 10 s to honour SIGTERM, then SIGKILL (exact PIDs)
     while alive:
         time.sleep(0.2)
         for p in list(alive):
@@ -365,6 +376,11 @@ def spawn_ranks(n):
                 rc = code if code > 0 else 1
                 for q in alive:         # a dead rank leaves the others waiting in a collective: stop them, by PID
                     q.terminate()
+                deadline = time.monotonic() + 10.0
+        if deadline is not None and alive and time.monotonic() > deadline:
+            for q in alive:             # stuck inside a collective / kernel that ignores SIGTERM
+                q.kill()
+            deadline = time.monotonic() + 10.0
     out0.seek(0)
     for line in out0:            # the JSON line to stdout; anything else a library printed on rank 0's stdout (gloo does) to stderr
         (sys.stdout if line.lstrip().startswith('{') else sys.stderr).write(line)
@@ -521,6 +537,22 @@ def main():
     if a.extras and a.render_chunks > 0:
         render = render_leg(model, projector, sampler, src_ray_batch, featmaps, a.render_chunks, a.samples, a.importance,
                             a.model == 'gnt', prof, par)
+    if a.extras and a.attack_iters > 0 and world == 1 and a.model == 'ibrnet' and a.config == 'c2':
+        # BASELINE.json's second figure, MEASURED: wall-clock of a whole view-specific attack of `attack_iters` (1000) iterations on a
+        # fresh perturbation -- PGDAttack.run_view_specific (eval_adv.py:796-843), pixel picks from the RandomState(234) stream
+        # included, between barrier + synchronize brackets
+        run1k = make_attack(a.cnn_shard, a.scaling)
+        run1k.step(data)
+        barrier()
+        t0 = time.perf_counter()
+        run1k.run_view_specific(data, n_iters=a.attack_iters)
+        barrier()
+        dt = time.perf_counter() - t0
+        extra_legs['attack_%d_iters_wall_s' % a.attack_iters] = round(dt, 4)
+        extra_legs['attack_%d_iters' % a.attack_iters] = {'wall_s': round(dt, 4), 'ms_per_iter': round(1e3 * dt / a.attack_iters, 4),
+                                                          'rays_per_s': a.n_rand * a.attack_iters / dt, 'final_loss': float(run1k.last_loss),
+                                                          'measured': True}
+        del run1k
     if a.extras and world == 1 and a.model == 'ibrnet' and a.config == 'c2':
         # N_rand = 4096 attack step (SURVEY 8d asks for 512 and 4096)
         big = make_attack(a.cnn_shard, a.scaling, n_rand=4096)
@@ -612,20 +644,23 @@ def main():
             bound = per_launch[0][0]
             ach = float(np.mean([x[1] for x in per_launch]))
             peak = {'mfma': PEAK_F32_TFLOPS, 'mfma_bf16': PEAK_BF16_TFLOPS, 'hbm': PEAK_HBM_GBS}[bound]
-            if bound == 'mfma_bf16':
-                bound = 'mfma'          # priced against the dense bf16 matrix peak
-            table[name] = {'bound': bound, 'achieved': round(ach, 4), 'peak': peak, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
-                           'frac': round(ach / peak, 5), 'launches': k['launches'], 'mean_ms': round(k['mean_ms'], 4),
-                           'total_ms': round(k['total_ms'], 3)}
+            entry = {'launches': k['launches'], 'mean_ms': round(k['mean_ms'], 4), 'total_ms': round(k['total_ms'], 3)}
+            x3 = X3_KERNELS.get(name)
+            if x3 is not None and (name != 'nf_conv3x3_wino' or a.conv_operands == 'bf16x3'):
+                # a kernel whose products ISSUE ON THE BF16 MATRIX PIPE -- every fp32-accurate product as six bf16 products of the
+                # three-way operand split -- is priced against THAT pipe's dense peak: achieved = executed bf16 TFLOP/s
+                entry.update(bound='mfma', achieved=round(6.0 * ach, 3), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                             frac=round(6.0 * ach / PEAK_BF16_TFLOPS, 5), pipe='bf16 matrix cores, operands split 3 x bf16 (six products per fp32-grade product)',
+                             fp32_grade_tflops=round(ach, 4), fp32_grade_frac_of_fp32_peak=round(ach / PEAK_F32_TFLOPS, 5), note=x3)
+            else:
+                if bound == 'mfma_bf16':
+                    bound = 'mfma'          # priced against the dense bf16 matrix peak
+                entry.update(bound=bound, achieved=round(ach, 4), peak=peak, unit='TFLOP/s' if bound == 'mfma' else 'GB/s',
+                             frac=round(ach / peak, 5))
+            table[name] = entry
     if 'nf_conv3x3_wino' in table:
         table['nf_conv3x3_wino']['direct_form_equivalent_tflops'] = round(float(np.mean(wino_direct)), 2)
         table['nf_conv3x3_wino']['operands'] = a.conv_operands
-        if a.conv_operands == 'bf16x3':
-            # `achieved` counts every Winograd-domain product ONCE (an fp32-accurate product, priced against the fp32 matrix peak: what the
-            # hardware offers natively for that accuracy); the kernel executes it as six bf16 products on the bf16 matrix pipe
-            ex = 6.0 * table['nf_conv3x3_wino']['achieved']
-            table['nf_conv3x3_wino']['executed_bf16_tflops'] = round(ex, 2)
-            table['nf_conv3x3_wino']['executed_frac_of_bf16_peak'] = round(ex / PEAK_BF16_TFLOPS, 4)
     if 'nf_ibrnet_bwd_mfma' in table and 'nf_project_gather_bwd' not in table:
         table['nf_ibrnet_bwd_mfma']['includes'] = ('the scatter of d rgb_feat into the feature-map gradient (float atomics, formerly '
                                                    'nf_project_gather_bwd: 0.11 ms per launch) -- not counted in the FLOPs')
@@ -686,7 +721,7 @@ def main():
                               'note': 'per-launch durations from HIP events on the launch stream, live inside the timed region on every '
                                       'N-th step (an event pair costs the GPU ~11 us around the launch it brackets)'},
         'cpu_baseline': None,
-        'extra': {'attack_s_per_1000_iters': ms_step, 'final_loss': final_loss, 'kernels': table, 'whole_step': whole,
+        'extra': {'attack_s_per_1000_iters_from_ms_per_step': ms_step, 'final_loss': final_loss, 'kernels': table, 'whole_step': whole,
                   'hand_written_kernel_ms_per_step': None if hand_written_ms is None else round(hand_written_ms, 4),
                   'conv3x3_choice': {'%s %s' % (k[0], 'x'.join(map(str, k[1:]))): v for k, v in feature_network._CONV_CHOICE.items()},
                   'render': render, 'multi_gpu': multi, **extra_legs},

@@ -323,6 +323,10 @@ int nf_conv3x3_bwd_ring(const float* ring_records, const float* dy, int64_t ds_n
  *   nf_pgd_adam_step   : g = -grad; torch.optim.Adam single-tensor update with neg_step_size = -(lr/bias_corr1),
  *                        bc2_sqrt = sqrt(bias_corr2), one_minus_beta{1,2} = 1 - beta (all computed in HOST double and
  *                        rounded to float once, exactly as torch does); then both clamps
+ *   nf_pgd_adam_step_dev: the same update with {neg_step_size, bc2_sqrt} read from DEVICE memory (hyper_dev[2]; the host writes
+ *                        them per iteration with a stream-ordered copy): the one launch of a PGD step whose scalar arguments change
+ *                        with the iteration count, so that a whole step captured into a hipGraph (PGDAttack.step, INTEGRATION.md
+ *                        section 4) can be replayed unchanged
  *   nf_pgd_sign_step   : delta += alpha * sign(grad); then both clamps
  * ---------------------------------------------------------------------------------------------------------------- */
 int nf_project_perturb(float* delta, const float* src, int64_t n, float epsilon, float lower, float upper,
@@ -330,6 +334,9 @@ int nf_project_perturb(float* delta, const float* src, int64_t n, float epsilon,
 int nf_pgd_adam_step(float* delta, const float* grad, float* exp_avg, float* exp_avg_sq, const float* src, int64_t n,
                      float neg_step_size, float one_minus_beta1, float beta2, float one_minus_beta2, float bc2_sqrt,
                      float adam_eps, float epsilon, float lower, float upper, nf_stream_t stream);
+int nf_pgd_adam_step_dev(float* delta, const float* grad, float* exp_avg, float* exp_avg_sq, const float* src, int64_t n,
+                         const float* hyper_dev, float one_minus_beta1, float beta2, float one_minus_beta2, float adam_eps,
+                         float epsilon, float lower, float upper, nf_stream_t stream);
 int nf_pgd_sign_step(float* delta, const float* grad, const float* src, int64_t n, float alpha, float epsilon,
                      float lower, float upper, nf_stream_t stream);
 

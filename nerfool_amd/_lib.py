@@ -118,6 +118,7 @@ _PROTOTYPES = {
     'nf_project_perturb': (c_int, [_P, _P, c_int64, c_float, c_float, c_float, _P]),
     'nf_pgd_adam_step': (c_int, [_P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float,
                                  c_float, c_float, c_float, _P]),
+    'nf_pgd_adam_step_dev': (c_int, [_P, _P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_float, c_float, _P]),
     'nf_pgd_sign_step': (c_int, [_P, _P, _P, c_int64, c_float, c_float, c_float, c_float, _P]),
 }
 

@@ -36,6 +36,29 @@ __global__ void __launch_bounds__(256) k_pgd_adam_step(float* __restrict__ delta
     }
 }
 
+// The same update with the two per-iteration scalars read from DEVICE memory: hyper = {neg_step_size, bc2_sqrt} (computed on the
+// host in double and rounded to float exactly as for nf_pgd_adam_step, then copied stream-ordered).  A PGD step captured into a
+// hipGraph replays the identical launch every iteration; only these two numbers (Adam's bias corrections and the StepLR rate)
+// change with the iteration count.
+__global__ void __launch_bounds__(256) k_pgd_adam_step_dev(float* __restrict__ delta, const float* __restrict__ grad,
+                                                           float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                           const float* __restrict__ src, int64_t n, const float* __restrict__ hyper,
+                                                           float w1, float beta2, float w2, float adam_eps, float eps, float lo, float hi) {
+    const float neg_step_size = hyper[0], bc2_sqrt = hyper[1];
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float g = -grad[i];
+        float m = exp_avg[i];
+        m = m + w1 * (g - m);
+        float v = exp_avg_sq[i] * beta2 + w2 * (g * g);
+        float denom = sqrtf(v) / bc2_sqrt + adam_eps;
+        float d = delta[i] + neg_step_size * (m / denom);
+        exp_avg[i] = m;
+        exp_avg_sq[i] = v;
+        delta[i] = nf_project_delta(d, src[i], eps, lo, hi);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_pgd_sign_step(float* __restrict__ delta, const float* __restrict__ grad,
                                                        const float* __restrict__ src, int64_t n, float alpha, float eps,
                                                        float lo, float hi) {
@@ -72,6 +95,17 @@ extern "C" int nf_pgd_adam_step(float* delta, const float* grad, float* exp_avg,
                        exp_avg_sq, src, n, neg_step_size, one_minus_beta1, beta2, one_minus_beta2, bc2_sqrt, adam_eps, epsilon, lower,
                        upper);
     NF_LAUNCH_CHECK("nf_pgd_adam_step");
+    return 0;
+}
+
+extern "C" int nf_pgd_adam_step_dev(float* delta, const float* grad, float* exp_avg, float* exp_avg_sq, const float* src,
+                                    int64_t n, const float* hyper_dev, float one_minus_beta1, float beta2, float one_minus_beta2,
+                                    float adam_eps, float epsilon, float lower, float upper, nf_stream_t stream) {
+    NF_REQUIRE(n >= 0 && hyper_dev != nullptr, "nf_pgd_adam_step_dev: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_pgd_adam_step_dev, dim3(nf_stream_grid(n)), dim3(256), 0, (hipStream_t)stream, delta, grad, exp_avg,
+                       exp_avg_sq, src, n, hyper_dev, one_minus_beta1, beta2, one_minus_beta2, adam_eps, epsilon, lower, upper);
+    NF_LAUNCH_CHECK("nf_pgd_adam_step_dev");
     return 0;
 }
 

@@ -316,7 +316,9 @@ class PGDAttack:
     state: delta [1,V,H,W,3] (requires_grad), Adam moments, iteration counter.  `step(data)` = loss forward, backward to
     delta, optional gradient all-reduce, fused update + eps-ball + [0,1]-box projection."""
 
-    def __init__(self, args, model, projector, src_ray_batch, shard=None, delta=None):
+    def __init__(self, args, model, projector, src_ray_batch, shard=None, delta=None, graph=None):
+        """graph: None (default) -- on a GPU, single process, the steps of one target view are captured into a hipGraph after two
+        eager steps and replayed (`_graph_step`); False -- every step is enqueued launch by launch."""
         _reject_out_of_scope(args)
         self.args, self.model, self.projector, self.src = args, model, projector, src_ray_batch
         self.shard = shard
@@ -333,6 +335,11 @@ class PGDAttack:
         self.iters = 0
         self.last_loss = None
         self._featmaps_clean = None
+        self.use_graph = (graph is None or bool(graph)) and shard is None and self.delta.is_cuda
+        self._graphs = {}           # (target view, draw) -> (CUDAGraph, static picks, static {neg_step_size, bc2_sqrt}, loss, gradient, sampler)
+        self._g_warm = {}           # key -> eager steps taken on it so far
+        self._g_pool = None         # one activation pool for all captured views (replays never overlap; the loss is copied out)
+        self.graph_replays = 0
 
     def lr(self):
         step_size = getattr(self.args, 'lr_step_size', 100)
@@ -366,8 +373,80 @@ class PGDAttack:
     def step(self, data, select_inds=None, lookahead=True):
         """lookahead: prepare the next step's pixel pick off-thread (harmless if no next step follows: the RandomState(234)
         stream only advances when a pick is consumed)."""
+        if self._graph_eligible(select_inds):
+            return self._graph_step(data, lookahead)
         self.apply(self.gradient(data, select_inds, lookahead))
         return self.last_loss
+
+    # ---- the step as ONE hipGraph launch ------------------------------------------------------------------------------------
+    # A PGD step is ~250 kernel launches of fixed shapes on fixed buffers; enqueued one by one from Python they cost the host
+    # 4.5 ms against 8 ms of GPU time (BENCH_r04 host_issue_ms_per_step).  The iteration-dependent inputs are exactly two: the pixel
+    # picks (host RNG stream -> a static int64 device buffer, refreshed by a stream-ordered copy before each replay) and Adam's
+    # {neg_step_size, bc2_sqrt} (nf_pgd_adam_step_dev reads them from a 2-float device buffer).  Everything else -- feature CNN on
+    # src + delta, render, loss, backward, fused update on the persistent delta / moment tensors -- is captured once per target view
+    # (torch.cuda.CUDAGraph = hipStreamBeginCapture / hipGraphLaunch, activations in a pool shared by the views of a universal loop,
+    # at most MAX_GRAPHS views, further ones run eagerly) after two eager steps on that view have warmed every lazy initialisation,
+    # and replayed: the same kernels on the same arguments in the same order, so an eager step and a replayed one are
+    # interchangeable (bench.py interleaves them: HIP-event brackets need eager launches).
+    MAX_GRAPHS = 64
+
+    def _graph_eligible(self, select_inds):
+        if not self.use_graph or select_inds is not None or getattr(self.args, 'use_pseudo_gt', False):
+            return False
+        from . import prof
+        from .ibrnet import feature_network
+        return prof._active is None and feature_network.TRACE_RELU is None and torch.is_grad_enabled()
+
+    def _graph_step(self, data, lookahead):
+        import numpy as np
+        device = self.delta.device
+        sampler = RaySamplerSingleImage.cached(data, device)
+        n_rand = self.args.N_rand
+        mode, ratio = getattr(self.args, 'sample_mode', 'uniform'), getattr(self.args, 'center_ratio', 0.8)
+        key = (id(sampler), n_rand, mode, ratio, self.use_adam)
+        picks = sampler.sample_random_pixel(n_rand, mode, ratio, lookahead=lookahead)
+        if key not in self._graphs:
+            if self._g_warm.get(key, 0) < 2 or len(self._graphs) >= self.MAX_GRAPHS:
+                # eager: warms allocator, record packing, per-device kernel attributes
+                self._g_warm[key] = self._g_warm.get(key, 0) + 1
+                self.apply(self.gradient(data, picks, False))
+                return self.last_loss
+            self._capture(key, data, sampler, n_rand)
+        graph, g_idx, g_hyper, g_loss = self._graphs[key][:4]
+        g_idx.copy_(torch.from_numpy(np.ascontiguousarray(picks, dtype=np.int64)).pin_memory(), non_blocking=True)
+        if self.use_adam:
+            lr = self.lr()
+            self.iters += 1
+            g_hyper.copy_(torch.tensor(ops.adam_hyper(lr, self.iters), dtype=torch.float32).pin_memory(), non_blocking=True)
+        else:
+            self.iters += 1
+        graph.replay()
+        self.graph_replays += 1
+        self.last_loss = g_loss.clone()          # the graph's loss buffer is overwritten by the next replay
+        return self.last_loss
+
+    def _capture(self, key, data, sampler, n_rand):
+        device = self.delta.device
+        g_idx = torch.zeros(n_rand, dtype=torch.int64, device=device)
+        g_hyper = torch.ones(2, dtype=torch.float32, device=device)
+        graph = torch.cuda.CUDAGraph()
+        self.delta.grad = None
+        torch.cuda.synchronize(device)
+        if self._g_pool is None:
+            self._g_pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(graph, pool=self._g_pool):
+            loss, total = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data, return_loss=True,
+                                               select_inds=g_idx, lookahead=False)
+            loss.backward()
+            grad = self.delta.grad
+            if self.use_adam:
+                ops.pgd_adam_step_dev_(self.delta.data, grad, self.exp_avg, self.exp_avg_sq, self.src['src_rgbs'], g_hyper, self.epsilon)
+            else:
+                ops.pgd_sign_step_(self.delta.data, grad, self.src['src_rgbs'], self.alpha, self.epsilon)
+            g_loss = total['rgb'].detach()
+        self.delta.grad = None
+        # (the sampler is held so that its ray tensors -- and its id(), part of the key -- outlive the graph that reads them)
+        self._graphs[key] = (graph, g_idx, g_hyper, g_loss, grad, sampler)
 
     def run_view_specific(self, data, n_iters=None):
         """eval_adv.py:796-843: adv_iters steps on one target view."""

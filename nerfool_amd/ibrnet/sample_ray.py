@@ -194,11 +194,17 @@ class RaySamplerSingleImage(object):
         return self.select(select_inds)
 
     def select(self, select_inds):
-        host = torch.from_numpy(np.ascontiguousarray(select_inds, dtype=np.int64))
-        if self.device.type == 'cuda':      # pinned staging + stream-ordered copy: the host does not wait for the GPU queue
-            idx = host.pin_memory().to(self.device, non_blocking=True)
+        """the ray batch of the given flat pixel indices: a numpy array / list (host picks, as the reference draws them) or an int64
+        tensor already on the sampler's device (a captured PGD step reads its picks from a static device buffer)"""
+        if torch.is_tensor(select_inds):
+            idx = select_inds
+            assert idx.dtype == torch.int64 and idx.device == self.rays_o.device, 'device picks: int64 on %s' % self.rays_o.device
         else:
-            idx = host.to(self.device)
+            host = torch.from_numpy(np.ascontiguousarray(select_inds, dtype=np.int64))
+            if self.device.type == 'cuda':      # pinned staging + stream-ordered copy: the host does not wait for the GPU queue
+                idx = host.pin_memory().to(self.device, non_blocking=True)
+            else:
+                idx = host.to(self.device)
         ret = {'ray_o': self.rays_o[idx], 'ray_d': self.rays_d[idx], 'rgb': None if self.rgb is None else self.rgb[idx],
                'selected_inds': select_inds, 'depth': None}
         ret.update(self._common())

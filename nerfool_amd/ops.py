@@ -441,6 +441,25 @@ def pgd_adam_step_(delta, grad, exp_avg, exp_avg_sq, src, lr, step, epsilon, bet
     return delta
 
 
+def adam_hyper(lr, step, beta1=0.9, beta2=0.999):
+    """(neg_step_size, bc2_sqrt) of torch.optim.Adam's single-tensor step `step` (1-based) at rate `lr`: HOST doubles, rounded to
+    float by the consumer -- the two scalars of the fused update that change with the iteration count"""
+    return -(lr / (1.0 - beta1 ** step)), (1.0 - beta2 ** step) ** 0.5
+
+
+def pgd_adam_step_dev_(delta, grad, exp_avg, exp_avg_sq, src, hyper, epsilon, beta1=0.9, beta2=0.999, adam_eps=1e-8, lower=0.0, upper=1.0):
+    """pgd_adam_step_ with the per-iteration scalars in a 2-float DEVICE tensor `hyper` = adam_hyper(lr, step): the launch a captured
+    PGD step replays (eval_adv.PGDAttack)"""
+    for t, n in ((delta, 'delta'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+        _flat_inplace(t, n)
+    grad, src = _c(grad, 'grad'), _c(src, 'src')
+    assert hyper.dtype == torch.float32 and hyper.numel() == 2 and hyper.device == delta.device and hyper.is_contiguous()
+    with prof.launch('nf_pgd_adam_step', delta, n=delta.numel()):
+        _launch(_lib.lib().nf_pgd_adam_step_dev, 'nf_pgd_adam_step_dev', delta, _ptr(delta), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                _ptr(src), delta.numel(), _ptr(hyper), 1.0 - beta1, beta2, 1.0 - beta2, adam_eps, float(epsilon), float(lower), float(upper))
+    return delta
+
+
 def pgd_sign_step_(delta, grad, src, alpha, epsilon, lower=0.0, upper=1.0):
     _flat_inplace(delta, 'delta')
     grad, src = _c(grad, 'grad'), _c(src, 'src')

@@ -728,6 +728,34 @@ def check_attack100(dev, tag='c1', log=None):
     return attack100_compare(tag, 'HIP path', mine, g, eps, log)
 
 
+def check_step_graph(dev):
+    """PGDAttack.step as ONE hipGraph launch (eval_adv.PGDAttack._graph_step) against the launch-by-launch step: same kernels, same
+    arguments, same order -- with the sorted (bitwise reproducible) feature-map scatter the perturbation, both Adam moments and the
+    losses must be IDENTICAL after six steps (two eager warm-ups, the capture, three replays), for the Adam and the sign update; the
+    RandomState(234) stream advances one pick per step either way."""
+    g, args, model, data, sampler, dims = _attack_setup(dev)
+    src = sampler.get_all()
+    saved, ops.GATHER_BWD = ops.GATHER_BWD, 'deterministic'
+    try:
+        for use_adam in (True, False):
+            a = SimpleNamespace(**dict(vars(args), use_adam=use_adam))
+            runs = []
+            for graph in (None, False):
+                product_sample_ray.rng.seed(234)
+                atk_ = EA.PGDAttack(a, model, Projector(dev), src, delta=g.t('in/delta0', dev).clone().requires_grad_(True), graph=graph)
+                losses = [atk_.step(data) for _ in range(6)]
+                runs.append((atk_, [float(x) for x in losses], product_sample_ray.rng.get_state()[2]))
+            (ga, gl, gpos), (ea, el, epos) = runs
+            assert ga.graph_replays == 4 and ea.graph_replays == 0, (ga.graph_replays, ea.graph_replays)
+            assert ga.iters == ea.iters == 6 and gpos == epos
+            assert gl == el, ('losses', gl, el)
+            assert torch.equal(ga.delta.data, ea.delta.data), 'delta: graph replay vs eager launches (use_adam=%s)' % use_adam
+            if use_adam:
+                assert torch.equal(ga.exp_avg, ea.exp_avg) and torch.equal(ga.exp_avg_sq, ea.exp_avg_sq)
+    finally:
+        ops.GATHER_BWD = saved
+
+
 def check_evaluate_view(dev):
     """eval_views.evaluate_view (the evaluation loop of eval.py / eval_adv.py:861-905) on the attack fixture: adversarial
     render with the reference's final delta -> the reference's fine PSNR; delta = 0 equals the clean render."""

@@ -146,6 +146,10 @@ def test_universal_trajectory():
     pc.check_universal_trajectory('cuda')
 
 
+def test_step_graph_equals_eager_step():
+    pc.check_step_graph('cuda')
+
+
 @pytest.mark.parametrize('tag', ['c1', 'c2'])
 def test_whole_attack_outcome(tag):
     """a whole free-running view-specific attack (100 Adam-ascent iterations, attacked render, PSNR) against the reference's own

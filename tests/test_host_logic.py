@@ -54,8 +54,8 @@ def test_sampler_cache_key_accepts_slices_at_odd_float_offsets():
     from nerfool_amd.ibrnet.sample_ray import RaySamplerSingleImage, _content_key
     RaySamplerSingleImage._cache.clear()
     a = _scene(H=41, W=57, V=3)                       # 41 * 57 * 3 = 7011 floats per image: odd
-    stack = torch.cat([torch.zeros(1, 1, 41, 57, 3), a['rgb'][None], a['src_rgbs']], dim=1)      # [1, 5, H, W, 3]
-    view = dict(a, rgb=stack[:, 1], src_rgbs=stack[:, 2:])
+    stack = torch.cat([torch.zeros(1, 1, 41, 57, 3), a['src_rgbs'], a['rgb'][None]], dim=1)      # [1, 5, H, W, 3]
+    view = dict(a, rgb=stack[:, 4], src_rgbs=stack[:, 1:4])
     assert (view['src_rgbs'].storage_offset() * 4) % 8 == 4 and view['src_rgbs'].is_contiguous()
     k = _content_key(view['src_rgbs'])
     assert k == _content_key(view['src_rgbs'].clone())
