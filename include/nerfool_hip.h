@@ -297,8 +297,9 @@ int nf_conv3x3_wino(const float* records, int k_per_group, const float* x, int64
 /* The same convolutions with the Winograd-domain products on the BF16 matrix cores (csrc/nf_wino_bf.hip; ref: the same lines,
  * ibrnet/feature_network.py:28-36, 38-78, 127-151).  n_split = 3: every fp32 operand is the sum of three bf16 parts (8 significant
  * bits each) and the product is the six cross terms of order <= 2^-16 -- dropped terms <= 2^-24 of the product, i.e. fp32 rounding
- * level: a drop-in for nf_conv3x3_wino at 6 / 16 of its matrix-pipe time.  n_split = 1: plain bf16 operands (BASELINE config 5's
- * opt-in precision; 8 significant bits per operand, tolerance stated in DESIGN.md).  records = nf_wino_bf_pack(weight, ...,
+ * level: a drop-in for nf_conv3x3_wino at 6 / 16 of its matrix-pipe time.  n_split = 2 (round 5; the executor's choice for the
+ * BACKWARD-DATA passes): hi + mid, three cross terms, operands of 16 significant bits (dropped terms <= 3 x 2^-16 of a product).
+ * n_split = 1: plain bf16 operands (diagnostic: 8 significant bits per operand, measured and rejected for the CNN).  records = nf_wino_bf_pack(weight, ...,
  * k_per_group in {32, 64}, n_split) (HOST pointers); tensors, geometry and strides as nf_conv3x3_wino. */
 int64_t nf_wino_bf_pack_floats(int c_out, int c_in, int k_per_group, int n_split);
 int nf_wino_bf_pack(const float* weight_host, int c_out, int c_in, int backward, int k_per_group, int n_split, float* records_host);

@@ -10,6 +10,12 @@
 //         hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid          (fp32 accumulation inside the matrix instruction)
 //     The dropped terms are <= 2^-24 of the product -- fp32 rounding level -- so this form is a drop-in for the fp32 kernel (the
 //     float64 layer tests hold at the same 5e-6) at 6/16 of its matrix-pipe time;
+//   * NS = 2 ("bf16x2", round 5 -- the BACKWARD-DATA passes only): hi + mid, the three cross terms of order <= 2^-8
+//         hi.hi + hi.mid + mid.hi
+//     i.e. operands of 16 significant bits; the dropped terms (hi.lo, lo.hi, mid.mid) are <= 3 x 2^-16 of a product, zero-mean.  The
+//     forward pass decides ReLU signs and feeds the renderer, so it stays at NS = 3; the gradient has no discontinuity to flip and its
+//     parity bar (1e-3 of the float64 gradient, measured 4e-5 .. 5e-4 before) absorbs 1e-5 per layer: half the matrix instructions,
+//     two thirds of the streamed records, 7 instead of 11 vector instructions per split pair;
 //   * NS = 1 ("bf16"): plain bf16 operands, one instruction per 16 channels: BASELINE config 5's opt-in precision
 //     (ibrnet_precision = 'bf16'), 8 significant bits per operand, stated tolerance in DESIGN.md.
 // Work split: wave w owns row w of the 4x4 transformed tile as in nf_wino.hip.  A chunk of 16 input channels is ONE k-block of the
@@ -49,7 +55,7 @@ extern "C" int64_t nf_wino_bf_pack_floats(int c_out, int c_in, int k_per_group, 
 extern "C" int nf_wino_bf_pack(const float* weight, int c_out, int c_in, int backward, int k_per_group, int n_split, float* out) {
     static const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
     const int N = backward ? c_in : c_out, C = backward ? c_out : c_in;
-    if (k_per_group % 32 != 0 || k_per_group < 32 || (n_split != 1 && n_split != 3)) return 1;
+    if (k_per_group % 32 != 0 || k_per_group < 32 || n_split < 1 || n_split > 3) return 1;
     const int KB = k_per_group / 32, groups = (N + k_per_group - 1) / k_per_group, chunks = (C + WN_CC - 1) / WN_CC;
     const int64_t total = nf_wino_bf_pack_floats(N, C, k_per_group, n_split);
     for (int64_t i = total - 4096; i < total; ++i) out[i] = 0.f;
@@ -228,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                          : "v"(lane * 16), "s"(lds), "s"(wnext)
                          : "memory");
         else
-            wn_dma16(wnext, dst, lane);
+            wn_dma16xn<PCS>(wnext, dst, lane);
 #else
         for (int j = 0; j < 4 * NS; ++j) dst[(j >> 2) * 256 + 4 * lane + (j & 3)] = wnext[(j >> 2) * 256 + 4 * lane + (j & 3)];
 #endif
@@ -393,9 +399,11 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                 const wu4* a = opa[s & 1];
 #define WB_PROD(pa, pb) acc[nu][kb] = WB_MFMA(__builtin_bit_cast(wb8, a[pa]), __builtin_bit_cast(wb8, bv[pb]), acc[nu][kb])
                 WB_PROD(0, 0);
-                if (NS == 3) {
+                if (NS >= 2) {
                     WB_PROD(0, 1);
                     WB_PROD(1, 0);
+                }
+                if (NS == 3) {
                     WB_PROD(0, 2);
                     WB_PROD(2, 0);
                     WB_PROD(1, 1);
@@ -497,16 +505,18 @@ extern "C" int nf_conv3x3_wino_bf(const float* records, int k_per_group, int n_s
                                   int Hi, int Wi, int pad, float* y, int64_t ys_n, int64_t ys_c, int64_t ys_h, int Ho, int Wo, int n_img,
                                   int c_in, int c_out, nf_stream_t stream) {
     NF_REQUIRE(n_img >= 1 && c_in >= 1 && c_out >= 1 && Hi >= 1 && Wi >= 2 && Ho >= 1 && Wo >= 1 && (k_per_group == 64 || k_per_group == 32) &&
-                   (n_split == 1 || n_split == 3),
+                   n_split >= 1 && n_split <= 3,
                "nf_conv3x3_wino_bf: bad arguments (k_per_group %d, n_split %d)", k_per_group, n_split);
     const int groups = (c_out + k_per_group - 1) / k_per_group;
     const WnTensor xi = {xs_n, xs_c, xs_h}, yo = {ys_n, ys_c, ys_h};
     hipStream_t st = (hipStream_t)stream;
     if (k_per_group == 32) {
         if (n_split == 3) wb_launch<1, 3>(records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, n_img, c_in, c_out, groups, st);
+        else if (n_split == 2) wb_launch<1, 2>(records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, n_img, c_in, c_out, groups, st);
         else wb_launch<1, 1>(records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, n_img, c_in, c_out, groups, st);
     } else {
         if (n_split == 3) wb_launch<2, 3>(records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, n_img, c_in, c_out, groups, st);
+        else if (n_split == 2) wb_launch<2, 2>(records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, n_img, c_in, c_out, groups, st);
         else wb_launch<2, 1>(records, x, xi, Hi, Wi, pad, y, yo, Ho, Wo, n_img, c_in, c_out, groups, st);
     }
     NF_LAUNCH_CHECK("nf_conv3x3_wino_bf");

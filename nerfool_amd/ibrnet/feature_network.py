@@ -238,22 +238,28 @@ def _pick(key, candidates, rule):
 # level -- same parity bars as 'fp32'); 'bf16' = plain bf16 operands (BASELINE config 5's opt-in precision, never the default).
 # WINO_OPERANDS is the default for networks that do not ask for 'bf16' (ResUNet.conv_precision); test / diagnostic hook.
 WINO_OPERANDS = 'bf16x3'
-_N_SPLIT = {'fp32': 0, 'bf16x3': 3, 'bf16': 1}
+# Operand form of the BACKWARD-DATA passes when the forward runs 'bf16x3' (round 5): 'bf16x2' = two bf16 parts per operand (16
+# significant bits), the three cross terms of order <= 2^-8 -- half the matrix instructions of 'bf16x3'.  The gradient has no ReLU
+# decision to flip (the masks are the forward's) and d loss / d delta stays inside its 1e-3 bar against float64 (measured in
+# profiles/r05_parity_numbers.txt); 'bf16x3' keeps the backward at the forward's precision.  Test / diagnostic hook like WINO_OPERANDS.
+WINO_BWD_OPERANDS = 'bf16x2'
+_N_SPLIT = {'fp32': 0, 'bf16x3': 3, 'bf16x2': 2, 'bf16': 1}
 
 
-def _wino_records(conv_w, k_per_group, n_split=0):
-    """(forward records, backward-data records) of a weight for one workgroup width and operand form; packed on first use.  The
-    records hang on the weight tensor itself (like conv._nf_records of the 1x1 convolutions), so they die with it and can never be taken
-    for another weight's; they are re-packed when the weight's storage, version or device changed."""
+def _wino_records(conv_w, k_per_group, n_split=0, backward=False):
+    """forward (or backward-data) records of a weight for one workgroup width and operand form; packed on first use.  The records hang
+    on the weight tensor itself (like conv._nf_records of the 1x1 convolutions), so they die with it and can never be taken for
+    another weight's; they are re-packed when the weight's storage, version or device changed."""
     key = (conv_w.data_ptr(), conv_w._version, str(conv_w.device))
     store = getattr(conv_w, '_nf_wino', None)
     if store is None:
         store = conv_w._nf_wino = {}
-    cache = store.get((k_per_group, n_split))
+    slot = (k_per_group, n_split, bool(backward))
+    cache = store.get(slot)
     if cache is None or cache[0] != key:
-        cache = (key, ops.wino_pack(conv_w, False, conv_w.device, k_per_group, n_split), ops.wino_pack(conv_w, True, conv_w.device, k_per_group, n_split))
-        store[(k_per_group, n_split)] = cache
-    return cache[1], cache[2]
+        cache = (key, ops.wino_pack(conv_w, bool(backward), conv_w.device, k_per_group, n_split))
+        store[slot] = cache
+    return cache[1]
 
 
 def _wino_ring_records(conv_w):
@@ -272,10 +278,11 @@ def _conv3x3(tape, inp, w, sink, operands=None):
     c_out, c_in = w.shape[0], w.shape[1]
     N, Hi, Wi = inp.shape[0], inp.shape[2], inp.shape[3]
     ns = _N_SPLIT[operands or WINO_OPERANDS]
-    fwd = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out), ns)[0], inp, c_out, 0, k_per_group=ops.wino_group(c_out),
+    ns_b = _N_SPLIT[WINO_BWD_OPERANDS] if ns == 3 else ns         # the backward-data pass of a 'bf16x3' forward
+    fwd = {'wino': lambda: ops.conv3x3_wino(_wino_records(w, ops.wino_group(c_out), ns), inp, c_out, 0, k_per_group=ops.wino_group(c_out),
                                             n_split=ns)}
     if c_out > 64:                      # narrower workgroups only matter when they add workgroups to a thin grid
-        fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32, ns)[0], inp, c_out, 0, k_per_group=32, n_split=ns)
+        fwd['wino32'] = lambda: ops.conv3x3_wino(_wino_records(w, 32, ns), inp, c_out, 0, k_per_group=32, n_split=ns)
     rule = 'wino32' if _wino_width(c_out, N, Hi - 2, Wi - 2, ns) == 32 and c_out > 64 else 'wino'
     out = _Slot(fwd[_pick(('f', c_in, c_out) + tuple(inp.shape), fwd, rule)]())
 
@@ -290,15 +297,15 @@ def _conv3x3(tape, inp, w, sink, operands=None):
             plan = ops.wino_bwd_split_plan(g_out.shape[2], g_out.shape[3])
 
         def bwd_data(kpg):
-            rec = _wino_records(w, kpg, ns)[1]
+            rec = _wino_records(w, kpg, ns_b, backward=True)
             if plan is None:
-                return ops.conv3x3_wino(rec, g_out, c_in, 2, k_per_group=kpg, n_split=ns)
-            return ops.conv3x3_wino_bwd_split(rec, _wino_ring_records(w), g_out, c_in, plan, k_per_group=kpg, n_split=ns)
+                return ops.conv3x3_wino(rec, g_out, c_in, 2, k_per_group=kpg, n_split=ns_b)
+            return ops.conv3x3_wino_bwd_split(rec, _wino_ring_records(w), g_out, c_in, plan, k_per_group=kpg, n_split=ns_b)
         cand = {'wino': lambda: bwd_data(ops.wino_group(c_in))}
         if c_in > 64:
             cand['wino32'] = lambda: bwd_data(32)
         ho, wo = (g_out.shape[2] + 2, g_out.shape[3] + 2) if plan is None else (plan[0], plan[1])
-        rule_b = 'wino32' if _wino_width(c_in, N, ho, wo, ns) == 32 and c_in > 64 else 'wino'
+        rule_b = 'wino32' if _wino_width(c_in, N, ho, wo, ns_b) == 32 and c_in > 64 else 'wino'
         sink(cand[_pick(('b', c_in, c_out) + tuple(inp.shape), cand, rule_b)]())
         out.g = None
     tape.append(bwd)

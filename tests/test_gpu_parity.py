@@ -97,14 +97,20 @@ def test_winograd_full_size_layers_repeated():
         wgt, x, gy = wgt_c.cuda(), x_c.cuda(), gy_c.cuda()
         # both workgroup widths the shape rule chooses from, fp32 operands (csrc/nf_wino.hip) and the three-way bf16 split
         # (csrc/nf_wino_bf.hip: the default of the executor; the same float64 bar)
-        for kg, ns in ((64, 0), (32, 0), (64, 3), (32, 3)):
+        # (+ round 5: two bf16 parts per operand -- the executor's backward-data form -- at its own bar: 16-bit operands)
+        for kg, ns in ((64, 0), (32, 0), (64, 3), (32, 3), (64, 2), (32, 2)):
             rf, rb = ops.wino_pack(wgt, False, 'cuda', kg, ns), ops.wino_pack(wgt, True, 'cuda', kg, ns)
             first = None
-            for _ in range(6):
+            bar = 5e-5 if ns == 2 else 5e-6
+            for rep in range(6):
                 got = ops.conv3x3_wino(rf, x, co, 0, k_per_group=kg, n_split=ns)
                 ggot = ops.conv3x3_wino(rb, gy, ci, 2, k_per_group=kg, n_split=ns)
-                assert float((got[1:2].cpu().double() - ref).abs().max()) <= 5e-6 * float(ref.abs().max()), (ci, co, H, W, kg, ns)
-                assert float((ggot[1:2].cpu().double() - gref).abs().max()) <= 5e-6 * float(gref.abs().max()), (ci, co, H, W, kg, ns)
+                ef = float((got[1:2].cpu().double() - ref).abs().max()) / float(ref.abs().max())
+                eb = float((ggot[1:2].cpu().double() - gref).abs().max()) / float(gref.abs().max())
+                if rep == 0:
+                    print('[winograd full size] %d -> %d %dx%d, %d per group, n_split %d: forward %.2e backward-data %.2e of the largest output vs float64'
+                          % (ci, co, H, W, kg, ns, ef, eb))
+                assert ef <= bar and eb <= bar, (ci, co, H, W, kg, ns, ef, eb)
                 if first is None:
                     first = (got.clone(), ggot.clone())
                 else:            # every launch, every image: bit for bit the first launch (no atomics, no race)
