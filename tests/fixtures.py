@@ -117,7 +117,7 @@ ATTACK100 = {
     'c1': dict(H=96, W=128, V=4, S=16, N_imp=16, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
                lr_gamma=0.5, seed=8, chunk_size=4096, delta_stride=1),
     'c2': dict(H=378, W=504, V=4, S=64, N_imp=64, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
-               lr_gamma=0.5, seed=9, chunk_size=4096, delta_stride=5),
+               lr_gamma=0.5, seed=9, chunk_size=4096, delta_stride=10, image_dtype='float16'),
 }
 
 

@@ -140,8 +140,9 @@ def run_case(tag):
         out[name + '/frac_at_eps'] = np.array(float((np.abs(r['delta']) >= eps * (1 - 1e-5)).mean()))
     for name, r in (('ref32', r32), ('ref64', r64)):
         out[name + '/delta'] = r['delta'].reshape(-1)[::st].astype(np.float32)
-        out[name + '/image'] = r['image'].astype(np.float32)
-    out['ref64/image_clean'] = r64['image_clean'].astype(np.float32)
+        out[name + '/image'] = r['image'].astype(c.get('image_dtype', 'float32'))       # (the larger case: half precision, 1e-3 of full scale)
+    if tag == 'c1':
+        out['ref64/image_clean'] = r64['image_clean'].astype(np.float32)
     for name, a, b in (('ref32_vs_ref64', r32, r64), ('alt32_vs_ref64', alt, r64), ('ref32_vs_alt32', r32, alt)):
         s = attack_outcome_stats(a, b, eps)
         for k, v in s.items():
