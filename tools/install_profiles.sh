@@ -1,5 +1,5 @@
 # gpurun_out/final (written by tools/profile_round.sh on the GPU box) -> profiles/rNN_*, then the summary
-ROUND=${1:-r03}
+ROUND=${1:-r05}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final; P=profiles
 cp $F/bench_ibrnet.json $P/${ROUND}_bench_ibrnet.json; cp $F/bench_1000iters_ibrnet.json $P/${ROUND}_bench_1000iters_ibrnet.json

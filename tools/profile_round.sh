@@ -2,7 +2,7 @@
 # in its own run), steady-state kernel table and step timeline -- for BASELINE config 2 (headline) and, with trace + PMC as well,
 # configs 4 and 5.  Writes gpurun_out/final; copy what is to be judged into profiles/.
 set -x
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/final
