@@ -10,7 +10,8 @@ import sys
 ABI = {'nf_ibrnet_fwd_mfma': ('k_ibr_rows_fwd', 'k_ibr_sol_fwd', 'k_ibr_ray_fwd'),
        'nf_ibrnet_bwd_mfma': ('k_ibr_rows_bwd', 'k_ibr_ray_bwd'),
        'nf_project_gather_fwd': ('k_project_gather_fwd',), 'nf_project_gather_bwd': ('k_project_gather_bwd',),
-       'nf_pgd_adam_step': ('k_pgd_adam_step',), 'nf_conv3x3_wino': ('k_wino3x3',),
+       'nf_pgd_adam_step': ('k_pgd_adam_step',), 'nf_conv3x3_wino': ('k_wino3x3<', 'k_wino3x3_bf<2, 3>', 'k_wino3x3_bf<1, 3>', 'k_wino3x3_bf<2, 1>', 'k_wino3x3_bf<1, 1>'),
+       'nf_conv3x3_wino_bwd': ('k_wino3x3_bf<2, 2>', 'k_wino3x3_bf<1, 2>'),
        'nf_conv_s2_fwd': ('k_conv_s2_fwd',), 'nf_conv_s2_bwd': ('k_conv_s2_bwd',)}
 
 
@@ -53,7 +54,7 @@ def main():
             if name.startswith(prefixes):
                 tot += k['hbm_bytes_per_launch'] * k['launches_per_step']
         calls = 1 if entry == 'nf_pgd_adam_step' else 2          # coarse + fine level per step
-        if entry in ('nf_conv3x3_wino', 'nf_conv_s2_fwd', 'nf_conv_s2_bwd'):     # one kernel launch per call
+        if entry in ('nf_conv3x3_wino', 'nf_conv3x3_wino_bwd', 'nf_conv_s2_fwd', 'nf_conv_s2_bwd'):     # one kernel launch per call
             calls = sum(k['launches_per_step'] for name, k in kernels.items() if name.startswith(prefixes)) or 1
         if tot == 0.0:          # not launched in this configuration (fused into another entry point)
             continue
