@@ -362,9 +362,14 @@ def spawn_ranks(n):
     import socket
     import subprocess
     import tempfile
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
+    if os.environ.get('MASTER_PORT'):          # the caller chose it (a driver that runs several benches side by side)
+        port = int(os.environ['MASTER_PORT'])
+    else:
+        # bind-then-close leaves a window in which another process could take the port; rank 0's rendezvous then fails loudly (address in
+        # use) and the parent exits non-zero -- a retry is the caller's call, never a silent second attempt with other ranks half started
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
     base = dict(os.environ)
     base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC only on this pool (RCCL needs it)

@@ -292,8 +292,10 @@ def _conv3x3(tape, inp, w, sink, operands=None):
         # images: 560 workgroups against 384): the Winograd kernel on the interior-aligned region + the 1-D border ring kernel (a rule on
         # the launch's shape, ops.wino_bwd_split_pays, not a timing: the two forms round differently)
         plan = None
+        # (the rounds estimate uses the workgroup width the shape rule gives the one-launch form of this pass)
+        kpg_est = _wino_width(c_in, N, g_out.shape[2] + 2, g_out.shape[3] + 2, ns_b) if c_in > 64 else ops.wino_group(c_in)
         if g_out.shape[1] <= ops.WINO_RING_MAX_CHANNELS and ops.wino_bwd_split_pays(g_out.shape[2], g_out.shape[3], g_out.shape[0],
-                                                                                   g_out.shape[1], c_in):
+                                                                                   g_out.shape[1], c_in, k_per_group=kpg_est):
             plan = ops.wino_bwd_split_plan(g_out.shape[2], g_out.shape[3])
 
         def bwd_data(kpg):
