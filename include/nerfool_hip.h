@@ -357,6 +357,19 @@ int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, 
                float* alpha, float* workspace, nf_stream_t stream);
 int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
                int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
+/* The same pair in TRAINING mode (round 5): the reference's universal GNT loop runs before model.switch_to_eval()
+ * (eval/gnt/eval_adv.py:739-878 vs :959), i.e. with the eight nn.Dropout(p = 0.1) sites of every layer live
+ * (gnt/transformer_network.py:45-48 feed-forward hidden / output, :85-88 view-attention probabilities / output, :162-166 ray-attention
+ * probabilities / output; with ret_alpha the returned attention is the dropped one).  The masks come from a counter-based generator --
+ * keep(seed, site = 8 layer + {0..7}, flat index of the element in the tensor the reference hands to nn.Dropout), a 32-bit integer hash
+ * (csrc/nf_gnt.h: gnt_keep) -- so nf_gnt_bwd_train regenerates the masks of its forward from the same (seed, p), and the CPU oracle
+ * and the reference itself (masks injected into its modules, tests/golden/make_golden_gnt_train.py) evaluate identical ones.  A new
+ * seed per call is the host's job (nerfool_amd/gnt/transformer_network.py). */
+int nf_gnt_fwd_train(const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+                     const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
+                     float* alpha, float* workspace, uint32_t seed, double p, nf_stream_t stream);
+int nf_gnt_bwd_train(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
+                     int n_views, int depth, float* d_rgb_feat, float* workspace, uint32_t seed, double p, nf_stream_t stream);
 
 /* GNT forward on the matrix cores (S in {32, 64, 96, 128}): same arguments and workspace size as nf_gnt_fwd, with the weights
  * re-ordered by nf_gnt_pack_mfma (HOST pointers: natural blob -> MFMA-order blob of nf_gnt_mfma_blob_floats(depth) floats: the fp32

@@ -7,7 +7,7 @@ The test-suite points the same bindings at the CPU stand-in build of the kernel 
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint32, c_void_p
 
 # torch first: it ships its own libamdhip64 / libhsa-runtime64, and the library below must bind to THAT runtime (same SONAME:
 # whichever is loaded first serves both).  Loading the system runtime first leaves torch without a visible device.
@@ -67,6 +67,8 @@ _PROTOTYPES = {
     'nf_gnt_workspace_floats': (c_int64, [c_int64, c_int, c_int, c_int, c_int]),
     'nf_gnt_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     'nf_gnt_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_gnt_fwd_train': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, c_uint32, c_double, _P]),
+    'nf_gnt_bwd_train': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, c_uint32, c_double, _P]),
     'nf_gnt_mfma_blob_floats': (c_int64, [c_int]),
     'nf_gnt_pack_mfma': (c_int, [c_int, _P, _P]),
     'nf_gnt_mfma_supported': (c_int, [c_int, c_int]),

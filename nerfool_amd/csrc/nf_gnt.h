@@ -48,6 +48,46 @@ static constexpr int GNT_FINAL_FLOATS = 128 + 192 + 192 + 3 + 1;
 NF_HD constexpr int64_t gnt_layer_base(int i) { return (int64_t)GNT_STEM_FLOATS + (int64_t)i * GNT_LAYER_FLOATS; }
 
 // ---------------------------------------------------------------------------------------------------------------
+// training-mode Dropout (round 5).  The reference's universal GNT loop runs before model.switch_to_eval()
+// (eval/gnt/eval_adv.py:739-878 vs :959): the eight nn.Dropout(0.1) sites of every layer are live
+// (gnt/transformer_network.py:45-48 feed-forward hidden / output, :85-88 view-attention probabilities / output, :162-166 ray-attention
+// probabilities / output).  torch's generator cannot be matched on a GPU; the masks come from a counter-based generator instead --
+// keep(seed, site, idx), a 32-bit integer hash (murmur3 finaliser rounds) of the call's seed, the site 8 * layer + {0 view probabilities
+// [R,S,V,64], 1 view output [R,S,64], 2 view hidden [R,S,256], 3 view feed-forward output [R,S,64], 4 ray probabilities [R,4,S,S],
+// 5 ray output, 6 ray hidden, 7 ray feed-forward output} and the element's flat index in the tensor the reference hands to nn.Dropout --
+// so the forward and the backward regenerate the same mask, and the oracle (oracle/gnt_ref.py:keep_mask) and the reference itself
+// (tests/golden/make_golden_gnt_train.py injects the function into its modules) evaluate identical masks.
+// ---------------------------------------------------------------------------------------------------------------
+struct GntDrop {
+    unsigned seed, thr;       // keep when (hash >> 8) >= thr, thr = p * 2^24
+    float scale;              // 1 / (1 - p)
+    int on;
+};
+NF_HD unsigned gnt_mix32(unsigned x) {
+    x ^= x >> 16;
+    x *= 0x85ebca6bu;
+    x ^= x >> 13;
+    x *= 0xc2b2ae35u;
+    x ^= x >> 16;
+    return x;
+}
+NF_HD float gnt_keep(const GntDrop& d, unsigned site, unsigned long long idx) {
+    if (!d.on) return 1.f;
+    unsigned a = gnt_mix32(d.seed ^ (site * 0x9e3779b9u));
+    a = gnt_mix32(a ^ (unsigned)(idx & 0xffffffffull));
+    a = gnt_mix32(a + (unsigned)(idx >> 32) * 0x7f4a7c15u + 0x165667b1u);
+    return (a >> 8) >= d.thr ? d.scale : 0.f;
+}
+static inline GntDrop gnt_drop_make(int train, unsigned seed, double p) {
+    GntDrop d;
+    d.on = train ? 1 : 0;
+    d.seed = seed;
+    d.thr = (unsigned)(p * 16777216.0);
+    d.scale = 1.0f / (float)(1.0 - p);
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // workspace slots
 // ---------------------------------------------------------------------------------------------------------------
 enum { RW_R1 = 0, RW_X = 64, RW_DX = 128, RW_T = 192, RW_T2 = 256, RW_T3 = 320, RW_R1H = 384, RW_BASE = 392, RWL_VP = 0, RWL_H = 64, RWL_PROB = 72, RW_LAYER = 136 };

@@ -176,28 +176,40 @@ __device__ __forceinline__ float gnt_score(const float* __restrict__ base, size_
 
 // ---- shared stages -------------------------------------------------------------------------------------------------
 // feed-forward 64 -> 256 -> 64 with residual: y at SW_T, hidden saved at f_slot, CUR += FF(y).  Two barriers inside.
-#define GNT_FF(L, l1, l2, f_slot)                                                                              \
+// (training mode: the hidden units and the output pass through Dropout sites `site` and `site + 1`, transformer_network.py:47-48; the
+//  hidden units are SAVED dropped -- they are what fc2 multiplies)
+#define GNT_FF(L, l1, l2, f_slot, site)                                                                        \
     STAGE_BEGIN                                                                                                \
     for (int ch = 0; ch < 4; ++ch) {                                                                           \
         float f[16];                                                                                           \
         gnt_slice((L) + gnt_wt(l1), 256, ch * 64 + P0, (L) + gnt_b(l1), 64, SMPP(SW_T), (size_t)c.S, f);       \
-        for (int j = 0; j < 16; ++j) SMP(f_slot, ch * 64 + P0 + j) = fmaxf(f[j], 0.f);                         \
+        for (int j = 0; j < 16; ++j)                                                                           \
+            SMP(f_slot, ch * 64 + P0 + j) = fmaxf(f[j], 0.f) * gnt_keep(dr, (site), smp_idx * 256 + ch * 64 + P0 + j); \
     }                                                                                                          \
     STAGE_END                                                                                                  \
     STAGE_BEGIN                                                                                                \
     float o[16];                                                                                               \
     gnt_slice((L) + gnt_wt(l2), 64, P0, (L) + gnt_b(l2), 256, SMPP(f_slot), (size_t)c.S, o);                   \
-    for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j];                                                  \
+    for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j] * gnt_keep(dr, (site) + 1, smp_idx * 64 + P0 + j); \
     STAGE_END
 
 // backward of FF + its LayerNorm: DCUR holds d(q2) on entry, d(q1) on exit
-#define GNT_FF_BWD(L, l1, l2, f_slot, ln_idx, xh_slot, rstd_slot)                                              \
+// (training mode: the output's Dropout mask scales the incoming gradient -- a masked copy at SW_U, which this macro overwrites only
+//  behind the next barrier -- and a hidden unit that survived both ReLU and Dropout, i.e. whose SAVED value is positive, passes its
+//  gradient scaled by 1 / (1 - p))
+#define GNT_FF_BWD(L, l1, l2, f_slot, ln_idx, xh_slot, rstd_slot, site)                                        \
+    if (dr.on) {                                                                                               \
+        STAGE_BEGIN                                                                                            \
+        for (int j = 0; j < 16; ++j) SMP(SW_U, P0 + j) = SMP(SW_DCUR, P0 + j) * gnt_keep(dr, (site) + 1, smp_idx * 64 + P0 + j); \
+        STAGE_END                                                                                              \
+    }                                                                                                          \
     STAGE_BEGIN                                                                                                \
     for (int ch = 0; ch < 4; ++ch) {                                                                           \
         float df[16];                                                                                          \
         for (int j = 0; j < 16; ++j) df[j] = 0.f;                                                              \
-        gnt_slice_bwd((L) + gnt_w(l2), 64, 256, ch * 64 + P0, SMPP(SW_DCUR), (size_t)c.S, df);                 \
-        for (int j = 0; j < 16; ++j) SMP(SW_T, ch * 64 + P0 + j) = SMP(f_slot, ch * 64 + P0 + j) > 0.f ? df[j] : 0.f; \
+        gnt_slice_bwd((L) + gnt_w(l2), 64, 256, ch * 64 + P0, SMPP(dr.on ? SW_U : SW_DCUR), (size_t)c.S, df);  \
+        for (int j = 0; j < 16; ++j)                                                                           \
+            SMP(SW_T, ch * 64 + P0 + j) = SMP(f_slot, ch * 64 + P0 + j) > 0.f ? df[j] * (dr.on ? dr.scale : 1.f) : 0.f; \
     }                                                                                                          \
     STAGE_END                                                                                                  \
     STAGE_BEGIN                                                                                                \
@@ -217,10 +229,13 @@ __global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob
                                                   const float* __restrict__ ray_diff, const float* __restrict__ mask,
                                                   const float* __restrict__ pts, const float* __restrict__ ray_d, int S, int V,
                                                   int depth, int save, float* __restrict__ rgb_out, float* __restrict__ ws,
-                                                  int64_t row_floats, int64_t smp_floats, float* __restrict__ alpha_out) {
+                                                  int64_t row_floats, int64_t smp_floats, float* __restrict__ alpha_out, GntDrop dr,
+                                                  int64_t ray0) {
     __shared__ float mean_h[64];
     GNT_SETUP()
     c.rgb_feat = rgb_feat_all + ray * S * V * 35;
+    const unsigned long long gray = (unsigned long long)(ray0 + ray);          // the ray's index in the whole batch: Dropout indices
+    const unsigned long long smp_idx = gray * (unsigned long long)S + (unsigned long long)c.s;
     // ---- stem: X_v = W2 relu(W1 rgb_feat_v + b1) + b2 ; q = max over views (first maximum wins, like torch.max)
     for (int v = 0; v < V; ++v) {
         STAGE_BEGIN
@@ -329,20 +344,20 @@ __global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob
         for (int v = 0; v < V; ++v)
             for (int j = 0; j < 16; ++j) {
                 float pr = ROW(lr + RWL_PROB, P0 + j) / sum[j];
-                ROW(lr + RWL_PROB, P0 + j) = pr;
-                u[j] = fmaf(ROW(lr + RWL_VP, P0 + j), pr, u[j]);
+                ROW(lr + RWL_PROB, P0 + j) = pr;           // saved BEFORE Dropout site 0 (:85); the backward regenerates the mask
+                u[j] = fmaf(ROW(lr + RWL_VP, P0 + j), pr * gnt_keep(dr, 8 * i + 0, (smp_idx * V + v) * 64 + P0 + j), u[j]);
             }
         for (int j = 0; j < 16; ++j) SMP(SW_U, P0 + j) = u[j];
         STAGE_END
         STAGE_BEGIN
         float o[16];
         gnt_slice(L + gnt_wt(GV_OUT), 64, P0, L + gnt_b(GV_OUT), 64, SMPP(SW_U), (size_t)c.S, o);
-        for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j];
+        for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j] * gnt_keep(dr, 8 * i + 1, smp_idx * 64 + P0 + j);       // :88
         STAGE_END
         STAGE_BEGIN
         gnt_ln_slice(c, SW_CUR, L + gnt_ln_w(1), L + gnt_ln_b(1), 1e-6f, ls + SL_XH2, ls + SL_RSTD2, SW_T);
         STAGE_END
-        GNT_FF(L, GV_FF1, GV_FF2, ls + SL_F)
+        GNT_FF(L, GV_FF1, GV_FF2, ls + SL_F, 8 * i + 2)
         // ================= positional MLP on even layers =================
         if ((i & 1) == 0) {
             STAGE_BEGIN
@@ -379,9 +394,11 @@ __global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob
             for (int k = 0; k < S; ++k) mx = fmaxf(mx, gnt_score(Kb, (size_t)S, k, q));
             float l = 0.f, acc[16];
             for (int d = 0; d < 16; ++d) acc[d] = 0.f;
+            const unsigned long long arow = ((gray * 4 + (unsigned long long)c.part) * S + (unsigned long long)c.s) * S;     // [R,4,S,S]
             for (int k = 0; k < S; ++k) {
                 float p = expf(gnt_score(Kb, (size_t)S, k, q) - mx);
-                l += p;
+                l += p;                                            // the softmax normalises BEFORE Dropout site 4 (:162)
+                p *= gnt_keep(dr, 8 * i + 4, arow + k);
                 for (int d = 0; d < 16; ++d) acc[d] = fmaf(p, Vb[(size_t)d * S + k], acc[d]);
             }
             for (int d = 0; d < 16; ++d) {
@@ -394,7 +411,8 @@ __global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob
             // ret_alpha (transformer_network.py:196-200, :303-309): attention of the LAST ray transformer, row of sample 0,
             // averaged over the heads -- head `part` parks its row at SW_T + part, summed below
             if (alpha_out && i == depth - 1 && c.s == 0)
-                for (int k = 0; k < S; ++k) c.ws_smp[(size_t)(SW_T + c.part) * S + k] = expf(gnt_score(Kb, (size_t)S, k, q) - mx) / l;
+                for (int k = 0; k < S; ++k)          // (the attention returned with ret_attn is the dropped one, :162-169)
+                    c.ws_smp[(size_t)(SW_T + c.part) * S + k] = expf(gnt_score(Kb, (size_t)S, k, q) - mx) / l * gnt_keep(dr, 8 * i + 4, arow + k);
         }
         STAGE_END
         if (alpha_out && i == depth - 1) {
@@ -409,12 +427,12 @@ __global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob
         STAGE_BEGIN
         float o[16];
         gnt_slice(L + gnt_wt(GR_OUT), 64, P0, L + gnt_b(GR_OUT), 64, SMPP(SW_U), (size_t)c.S, o);
-        for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j];
+        for (int j = 0; j < 16; ++j) SMP(SW_CUR, P0 + j) += o[j] * gnt_keep(dr, 8 * i + 5, smp_idx * 64 + P0 + j);       // :166
         STAGE_END
         STAGE_BEGIN
         gnt_ln_slice(c, SW_CUR, L + gnt_ln_w(3), L + gnt_ln_b(3), 1e-6f, ls + SL_RXH2, ls + SL_RRSTD2, SW_T);
         STAGE_END
-        GNT_FF(L, GR_FF1, GR_FF2, ls + SL_F2)
+        GNT_FF(L, GR_FF1, GR_FF2, ls + SL_F2, 8 * i + 6)
     }
     // ---- final LayerNorm (eps 1e-5), mean over the samples, rgb_fc
     const float* Fp = blob + gnt_layer_base(depth);
@@ -441,9 +459,11 @@ __global__ void __launch_bounds__(1024) k_gnt_fwd(const float* __restrict__ blob
 __global__ void __launch_bounds__(1024) k_gnt_bwd(const float* __restrict__ blob, const float* __restrict__ ray_diff,
                                                   const float* __restrict__ mask, const float* __restrict__ d_rgb, int S, int V,
                                                   int depth, float* __restrict__ d_rgb_feat, float* __restrict__ ws,
-                                                  int64_t row_floats, int64_t smp_floats) {
+                                                  int64_t row_floats, int64_t smp_floats, GntDrop dr) {
     GNT_SETUP()
     c.rgb_feat = nullptr;
+    const unsigned long long gray = (unsigned long long)ray;
+    const unsigned long long smp_idx = gray * (unsigned long long)S + (unsigned long long)c.s;
     const float* Fp = blob + gnt_layer_base(depth);
     // ---- rgb_fc, mean over samples, final LayerNorm
     STAGE_BEGIN
@@ -464,11 +484,16 @@ __global__ void __launch_bounds__(1024) k_gnt_bwd(const float* __restrict__ blob
         const int ls = SW_BASE + i * SW_LAYER;
         const int lr = RW_BASE + i * RW_LAYER;
         // ================= ray transformer backward =================
-        GNT_FF_BWD(L, GR_FF1, GR_FF2, ls + SL_F2, 3, ls + SL_RXH2, ls + SL_RRSTD2)        // DCUR = d q1
+        GNT_FF_BWD(L, GR_FF1, GR_FF2, ls + SL_F2, 3, ls + SL_RXH2, ls + SL_RRSTD2, 8 * i + 6)        // DCUR = d q1
+        if (dr.on) {         // Dropout site 5 on out_fc's output: a masked copy of the incoming gradient
+            STAGE_BEGIN
+            for (int j = 0; j < 16; ++j) SMP(SW_T, P0 + j) = SMP(SW_DCUR, P0 + j) * gnt_keep(dr, 8 * i + 5, smp_idx * 64 + P0 + j);
+            STAGE_END
+        }
         STAGE_BEGIN
         float d_out[16];
         for (int j = 0; j < 16; ++j) d_out[j] = 0.f;
-        gnt_slice_bwd(L + gnt_w(GR_OUT), 64, 64, P0, SMPP(SW_DCUR), (size_t)c.S, d_out);
+        gnt_slice_bwd(L + gnt_w(GR_OUT), 64, 64, P0, SMPP(dr.on ? SW_T : SW_DCUR), (size_t)c.S, d_out);
         float D = 0.f;
         for (int d = 0; d < 16; ++d) {
             SMP(SW_GO, P0 + d) = d_out[d];
@@ -493,9 +518,12 @@ __global__ void __launch_bounds__(1024) k_gnt_bwd(const float* __restrict__ blob
                     dq[d] = 0.f;
                 }
                 float mx = Mb[c.s], rl = 1.f / Lb[c.s], D = Db[c.s];
+                // Dropout site 4 on the probabilities: O = sum_k P_k m_k V_k, so d P_k = m_k (go . V_k) and D = sum_k P_k d P_k = go . O
+                // with the DROPPED output O the forward saved
+                const unsigned long long arow = ((gray * 4 + (unsigned long long)c.part) * S + (unsigned long long)c.s) * S;
                 for (int k = 0; k < S; ++k) {
                     float p = expf(gnt_score(Kb, (size_t)S, k, q) - mx) * rl;
-                    float dS = p * (gnt_score(Vb, (size_t)S, k, go) - D);
+                    float dS = p * (gnt_score(Vb, (size_t)S, k, go) * gnt_keep(dr, 8 * i + 4, arow + k) - D);
                     for (int d = 0; d < 16; ++d) dq[d] = fmaf(dS, Kb[(size_t)d * S + k], dq[d]);
                 }
                 for (int d = 0; d < 16; ++d) SMP(SW_DQ, P0 + d) = dq[d] * 0.25f;
@@ -514,9 +542,11 @@ __global__ void __launch_bounds__(1024) k_gnt_bwd(const float* __restrict__ blob
                         dA = fmaf(Gb[(size_t)d * S + qi], vv[d], dA);
                     }
                     float p = expf(sc - Mb[qi]) / Lb[qi];
+                    const float mk = gnt_keep(dr, 8 * i + 4, ((gray * 4 + (unsigned long long)c.part) * S + (unsigned long long)qi) * S + c.s);
+                    dA *= mk;
                     float dS = p * (dA - Db[qi]);
                     for (int d = 0; d < 16; ++d) {
-                        dv[d] = fmaf(p, Gb[(size_t)d * S + qi], dv[d]);
+                        dv[d] = fmaf(p * mk, Gb[(size_t)d * S + qi], dv[d]);
                         dk[d] = fmaf(dS, Qb[(size_t)d * S + qi] * 0.25f, dk[d]);
                     }
                 }
@@ -554,21 +584,29 @@ __global__ void __launch_bounds__(1024) k_gnt_bwd(const float* __restrict__ blob
             STAGE_END
         }
         // ================= view transformer backward =================
-        GNT_FF_BWD(L, GV_FF1, GV_FF2, ls + SL_F, 1, ls + SL_XH2, ls + SL_RSTD2)           // DCUR = d q1
+        GNT_FF_BWD(L, GV_FF1, GV_FF2, ls + SL_F, 1, ls + SL_XH2, ls + SL_RSTD2, 8 * i + 2)           // DCUR = d q1
         float du[16], sp[16], dqs[16];
+        if (dr.on) {         // Dropout site 1 on out_fc's output
+            STAGE_BEGIN
+            for (int j = 0; j < 16; ++j) SMP(SW_T, P0 + j) = SMP(SW_DCUR, P0 + j) * gnt_keep(dr, 8 * i + 1, smp_idx * 64 + P0 + j);
+            STAGE_END
+        }
         STAGE_BEGIN
         for (int j = 0; j < 16; ++j) du[j] = sp[j] = dqs[j] = 0.f;
-        gnt_slice_bwd(L + gnt_w(GV_OUT), 64, 64, P0, SMPP(SW_DCUR), (size_t)c.S, du);
+        gnt_slice_bwd(L + gnt_w(GV_OUT), 64, 64, P0, SMPP(dr.on ? SW_T : SW_DCUR), (size_t)c.S, du);
+        // Dropout site 0 on the probabilities: u = sum_v (V_v + pos_v) pr_v m_v, so d pr_v = m_v (V_v + pos_v) du
         for (int v = 0; v < V; ++v)
-            for (int j = 0; j < 16; ++j) sp[j] = fmaf(ROW(lr + RWL_PROB, P0 + j) * ROW(lr + RWL_VP, P0 + j), du[j], sp[j]);
+            for (int j = 0; j < 16; ++j)
+                sp[j] = fmaf(ROW(lr + RWL_PROB, P0 + j) * gnt_keep(dr, 8 * i + 0, (smp_idx * V + v) * 64 + P0 + j) * ROW(lr + RWL_VP, P0 + j), du[j], sp[j]);
         STAGE_END
         for (int v = 0; v < V; ++v) {
             STAGE_BEGIN
             const float mk = c.mask[(size_t)c.s * V + v];
             for (int j = 0; j < 16; ++j) {
                 float pr = ROW(lr + RWL_PROB, P0 + j);
-                ROW(RW_T2, P0 + j) = mk == 0.f ? 0.f : pr * (ROW(lr + RWL_VP, P0 + j) * du[j] - sp[j]);    // d logit
-                ROW(RW_T, P0 + j) = pr * du[j];                                                               // d Vv
+                const float dm = gnt_keep(dr, 8 * i + 0, (smp_idx * V + v) * 64 + P0 + j);
+                ROW(RW_T2, P0 + j) = mk == 0.f ? 0.f : pr * (ROW(lr + RWL_VP, P0 + j) * du[j] * dm - sp[j]);    // d logit
+                ROW(RW_T, P0 + j) = pr * dm * du[j];                                                              // d Vv
             }
             STAGE_END
             STAGE_BEGIN
@@ -646,10 +684,10 @@ static int gnt_check(const char* who, int64_t R, int S, int V, int depth) {
 
 /* rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V], pts [R,S,3], ray_d [R,3] -> rgb [R,3].
  * save != 0 keeps the activations of ALL rays in `workspace` (nf_gnt_workspace_floats(R,S,V,depth,1)) for nf_gnt_bwd. */
-extern "C" int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
-                          const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
-                          float* alpha, float* workspace, nf_stream_t stream) {
-    if (gnt_check("nf_gnt_fwd", n_rays, n_samples, n_views, depth)) return 1;
+static int gnt_fwd_impl(const char* who, const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+                        const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
+                        float* alpha, float* workspace, const GntDrop& dr, nf_stream_t stream) {
+    if (gnt_check(who, n_rays, n_samples, n_views, depth)) return 1;
     const int S = n_samples, V = n_views;
     const int threads = GNT_PARTS * (((S + 15) / 16) * 16);       // 4 lanes per sample, multiple of 64
     const int64_t rf = gnt_row_floats(depth, save), sf = gnt_smp_floats(depth, save);
@@ -659,20 +697,52 @@ extern "C" int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float*
         int64_t nr = n_rays - r0 < step ? n_rays - r0 : step;
         hipLaunchKernelGGL(k_gnt_fwd, dim3((unsigned)nr), dim3(threads), 0, (hipStream_t)stream, blob, rgb_feat + r0 * S * V * 35,
                            ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, S, V, depth, save ? 1 : 0,
-                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf, alpha ? alpha + r0 * S : nullptr);
+                           rgb + r0 * 3, workspace + (save ? r0 * per_ray : 0), rf, sf, alpha ? alpha + r0 * S : nullptr, dr, r0);
         NF_LAUNCH_CHECK("nf_gnt_fwd");
     }
     return 0;
 }
 
+extern "C" int nf_gnt_fwd(const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+                          const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
+                          float* alpha, float* workspace, nf_stream_t stream) {
+    return gnt_fwd_impl("nf_gnt_fwd", blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_samples, n_views, depth, save, rgb, alpha,
+                        workspace, gnt_drop_make(0, 0u, 0.0), stream);
+}
+
+/* nf_gnt_fwd in TRAINING mode: the eight Dropout(p) sites of every layer live, masks from the counter-based generator of nf_gnt.h
+ * (seed = the call's seed; the backward of this forward must be given the same seed and p). */
+extern "C" int nf_gnt_fwd_train(const float* blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+                                const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
+                                float* alpha, float* workspace, uint32_t seed, double p, nf_stream_t stream) {
+    NF_REQUIRE(p >= 0.0 && p < 1.0, "nf_gnt_fwd_train: dropout rate %g outside [0, 1)", p);
+    return gnt_fwd_impl("nf_gnt_fwd_train", blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_samples, n_views, depth, save, rgb, alpha,
+                        workspace, gnt_drop_make(1, seed, p), stream);
+}
+
 /* d_rgb [R,3] -> d_rgb_feat [R,S,V,35]; `workspace` is the buffer a forward with save = 1 filled */
-extern "C" int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays,
-                          int n_samples, int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream) {
-    if (gnt_check("nf_gnt_bwd", n_rays, n_samples, n_views, depth)) return 1;
+static int gnt_bwd_impl(const char* who, const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays,
+                        int n_samples, int n_views, int depth, float* d_rgb_feat, float* workspace, const GntDrop& dr, nf_stream_t stream) {
+    if (gnt_check(who, n_rays, n_samples, n_views, depth)) return 1;
     if (n_rays == 0) return 0;
     const int threads = GNT_PARTS * (((n_samples + 15) / 16) * 16);
     hipLaunchKernelGGL(k_gnt_bwd, dim3((unsigned)n_rays), dim3(threads), 0, (hipStream_t)stream, blob, ray_diff, mask, d_rgb,
-                       n_samples, n_views, depth, d_rgb_feat, workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1));
+                       n_samples, n_views, depth, d_rgb_feat, workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1), dr);
     NF_LAUNCH_CHECK("nf_gnt_bwd");
     return 0;
+}
+
+extern "C" int nf_gnt_bwd(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays,
+                          int n_samples, int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream) {
+    return gnt_bwd_impl("nf_gnt_bwd", blob, ray_diff, mask, d_rgb, n_rays, n_samples, n_views, depth, d_rgb_feat, workspace,
+                        gnt_drop_make(0, 0u, 0.0), stream);
+}
+
+/* backward of nf_gnt_fwd_train(save = 1, seed, p): regenerates the forward's masks */
+extern "C" int nf_gnt_bwd_train(const float* blob, const float* ray_diff, const float* mask, const float* d_rgb, int64_t n_rays,
+                                int n_samples, int n_views, int depth, float* d_rgb_feat, float* workspace, uint32_t seed, double p,
+                                nf_stream_t stream) {
+    NF_REQUIRE(p >= 0.0 && p < 1.0, "nf_gnt_bwd_train: dropout rate %g outside [0, 1)", p);
+    return gnt_bwd_impl("nf_gnt_bwd_train", blob, ray_diff, mask, d_rgb, n_rays, n_samples, n_views, depth, d_rgb_feat, workspace,
+                        gnt_drop_make(1, seed, p), stream);
 }

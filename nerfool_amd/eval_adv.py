@@ -395,6 +395,8 @@ class PGDAttack:
             return False
         from . import prof
         from .ibrnet import feature_network
+        if getattr(getattr(self.model, 'net_coarse', None), 'training', False) and _is_gnt(self.model):
+            return False        # GNT in training mode: every forward takes a new Dropout seed -- a kernel argument a replay would freeze
         return prof._active is None and feature_network.TRACE_RELU is None and torch.is_grad_enabled()
 
     def _graph_step(self, data, lookahead):

@@ -1,12 +1,16 @@
 """GNT as an nn.Module whose forward and backward are HIP kernels.  The module tree reproduces the parameter names of
 gnt/transformer_network.py:205-268 (rgbfeat_fc, view_crosstrans.N.{attn_norm, ff_norm, ff.fc1/fc2, attn.{q_fc,k_fc,v_fc,
 pos_fc.0/2, attn_fc.0/2, out_fc}}, view_selftrans.N.{...}, q_fcs.N.0/2 on even N, norm, rgb_fc) so that the public GNT
-checkpoints load by key.  Eval-mode semantics (Dropout = identity); the parameters are constants of the attack.
+checkpoints load by key.  The parameters are constants of the attack.
 
-Train mode is REJECTED, loudly: the reference's universal GNT loop runs before `model.switch_to_eval()` (eval/gnt/eval_adv.py:739-878
-vs :959), i.e. with the `Dropout(0.1)` of every attention / feed-forward block active (gnt/transformer_network.py:45,72,136) -- a
-stochastic forward whose masks come from torch's global generator.  The kernels implement no dropout, so a module left in training
-mode raises instead of silently computing something else than the reference would."""
+Eval mode (`.eval()` / `model.switch_to_eval()`): Dropout = identity, matrix-core kernels where the shape allows -- the view-specific
+attack, rendering.  TRAINING mode (round 5): the reference's universal GNT loop runs before `model.switch_to_eval()`
+(eval/gnt/eval_adv.py:739-878 vs :959), i.e. with the `Dropout(0.1)` of every attention / feed-forward block live
+(gnt/transformer_network.py:45-48, :85-88, :162-166) -- a stochastic forward.  torch's generator cannot be reproduced on a GPU, so a
+module in training mode runs the shape-generic kernels with masks from a counter-based generator (csrc/nf_gnt.h: gnt_keep; pinned
+against the reference with the same masks injected into its modules, and statistically against the reference's own Dropout --
+tests/golden/make_golden_gnt_train.py): every forward call takes the next seed of `self.dropout_seed` (initialised from
+`torch.initial_seed()`, so `torch.manual_seed` makes an attack reproducible), its backward regenerates the same masks."""
 import torch
 import torch.nn as nn
 
@@ -55,19 +59,21 @@ class _TransformerParams(nn.Module):
 
 class _GNTFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, mfma_blob, depth, ret_alpha):
+    def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, mfma_blob, depth, ret_alpha, dropout=None):
         need_grad = rgb_feat.requires_grad
-        if mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2]):
+        ctx.dropout = dropout
+        use_mfma = dropout is None and mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])
+        if use_mfma:
             # (each backward reads what ITS forward saved: ctx.use_mfma picks the matching one below)
             out = ops.gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha)
-        else:
-            out = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha)
+        else:       # shape-generic kernels; training mode (dropout = (seed, p)) exists in this pair only
+            out = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha, dropout=dropout)
         rgb, ws = out[0], out[1]
         alpha = out[2] if ret_alpha else rgb.new_zeros(0)
         ctx.depth = depth
         ctx.shape = tuple(rgb_feat.shape[:3])
         ctx.have_ws = ws is not None
-        ctx.use_mfma = mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])
+        ctx.use_mfma = use_mfma
         if ws is not None:
             ctx.save_for_backward(ray_diff, mask, blob, ws, mfma_blob if ctx.use_mfma else None)
         # the attention-derived weights feed depth maps and the fine resampling only (both detached in the reference's rgb-loss
@@ -84,8 +90,8 @@ class _GNTFunction(torch.autograd.Function):
         if ctx.use_mfma:
             d_rgb_feat = ops.gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, ctx.shape, ctx.depth)
         else:
-            d_rgb_feat = ops.gnt_bwd(blob, ray_diff, mask, d_rgb, ws, ctx.shape, ctx.depth)
-        return d_rgb_feat, None, None, None, None, None, None, None, None
+            d_rgb_feat = ops.gnt_bwd(blob, ray_diff, mask, d_rgb, ws, ctx.shape, ctx.depth, dropout=ctx.dropout)
+        return d_rgb_feat, None, None, None, None, None, None, None, None, None
 
 
 class GNT(nn.Module):
@@ -109,6 +115,18 @@ class GNT(nn.Module):
         self._blob = None
         self._mfma_blob = None
         self._blob_key = None
+        # training mode: rate of the reference's nn.Dropout instances (transformer_network.py:222-233: ff_dp_rate = attn_dp_rate = 0.1)
+        # and the seed of the NEXT training-mode forward (None: taken from torch.initial_seed() at first use)
+        self.dropout_p = 0.1
+        self.dropout_seed = None
+
+    def next_dropout_seed(self):
+        """the seed of this training-mode forward; the following call gets the next one"""
+        if self.dropout_seed is None:
+            self.dropout_seed = torch.initial_seed() & 0xffffffff
+        seed = self.dropout_seed
+        self.dropout_seed = (seed + 1) & 0xffffffff
+        return seed
 
     def _packed(self, device):
         key = (str(device), KERNEL_PATH) + tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -120,12 +138,10 @@ class GNT(nn.Module):
 
     def forward(self, rgb_feat, ray_diff, mask, pts, ray_d):
         """rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V,1], pts [R,S,3], ray_d [R,3] -> rgb [R,3] (or [R,3+S])"""
-        if self.training:
-            raise RuntimeError('nerfool_amd GNT runs eval-mode semantics only (Dropout = identity): call model.switch_to_eval() / '
-                               '.eval() first.  The reference leaves Dropout(0.1) active in its universal GNT loop '
-                               '(eval/gnt/eval_adv.py:739-878 runs before switch_to_eval at :959); that stochastic variant is not built.')
         blob, mfma_blob = self._packed(rgb_feat.device)
+        # training mode = the reference's Dropout-active forward (its universal loop, eval/gnt/eval_adv.py:739-878)
+        dropout = (self.next_dropout_seed(), self.dropout_p) if self.training else None
         rgb, alpha = _GNTFunction.apply(rgb_feat, ray_diff, mask[..., 0], pts.detach(), ray_d.detach(), blob, mfma_blob,
-                                        self.trans_depth, bool(self.ret_alpha))
+                                        self.trans_depth, bool(self.ret_alpha), dropout)
         # ret_alpha: [R, 3 + S] = colour | attention of the first sample in the last ray transformer, mean over heads (:303-309)
         return torch.cat([rgb, alpha], dim=1) if self.ret_alpha else rgb

@@ -880,7 +880,9 @@ def pack_gnt_blob(state, depth, device):
     return blob.to(device)
 
 
-def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=False):
+def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=False, dropout=None):
+    """dropout = (seed, p): TRAINING mode -- the eight Dropout sites of every layer live, masks from the counter-based generator
+    (nf_gnt_fwd_train); the backward must be given the same pair"""
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     pts, ray_d = _c(pts, 'pts'), _c(ray_d, 'ray_d')
     R, S, V, F = rgb_feat.shape
@@ -891,8 +893,12 @@ def gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=
     rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
     alpha = torch.empty(R, S, dtype=torch.float32, device=rgb_feat.device) if want_alpha else None
     with prof.launch('nf_gnt_fwd', rgb, R=R, S=S, V=V, depth=depth):
-        _launch(L.nf_gnt_fwd, 'nf_gnt_fwd', rgb, _ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V, depth,
-                                int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws))
+        if dropout is not None:
+            _launch(L.nf_gnt_fwd_train, 'nf_gnt_fwd_train', rgb, _ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
+                    depth, int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws), int(dropout[0]) & 0xffffffff, float(dropout[1]))
+        else:
+            _launch(L.nf_gnt_fwd, 'nf_gnt_fwd', rgb, _ptr(blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V, depth,
+                    int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws))
     if want_alpha:
         return rgb, (ws if save else None), alpha
     return rgb, (ws if save else None)
@@ -938,11 +944,15 @@ def gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, shape, depth):
     return d_rgb_feat
 
 
-def gnt_bwd(blob, ray_diff, mask, d_rgb, ws, shape, depth):
+def gnt_bwd(blob, ray_diff, mask, d_rgb, ws, shape, depth, dropout=None):
     R, S, V = shape
     ray_diff, mask, d_rgb = _c(ray_diff, 'ray_diff'), _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
     d_rgb_feat = torch.empty(R, S, V, 35, dtype=torch.float32, device=d_rgb.device)
     with prof.launch('nf_gnt_bwd', d_rgb, R=R, S=S, V=V, depth=depth):
-        _launch(_lib.lib().nf_gnt_bwd, 'nf_gnt_bwd', d_rgb, _ptr(blob), _ptr(ray_diff), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat),
-                                         _ptr(ws))
+        if dropout is not None:
+            _launch(_lib.lib().nf_gnt_bwd_train, 'nf_gnt_bwd_train', d_rgb, _ptr(blob), _ptr(ray_diff), _ptr(mask), _ptr(d_rgb), R, S, V, depth,
+                    _ptr(d_rgb_feat), _ptr(ws), int(dropout[0]) & 0xffffffff, float(dropout[1]))
+        else:
+            _launch(_lib.lib().nf_gnt_bwd, 'nf_gnt_bwd', d_rgb, _ptr(blob), _ptr(ray_diff), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat),
+                    _ptr(ws))
     return d_rgb_feat

@@ -1137,6 +1137,63 @@ def check_gnt(case, dev, expect_mfma=False):
     assert err <= 1e-3, 'GNT d loss / d featmap rel-L2 %.3e vs float64' % err
 
 
+def check_gnt_train_mode(dev):
+    """GNT in TRAINING mode -- the reference's universal GNT loop runs with Dropout(0.1) live (eval/gnt/eval_adv.py:739-878 before
+    switch_to_eval at :959).  tests/golden/gnt_train_d2.npz: the reference network in train() mode with the counter-based masks injected
+    into its nn.Dropout instances.  The module in .train() with the same seed must reproduce output and d out / d rgb_feat (1e-3);
+    consecutive calls take consecutive seeds, .eval() is untouched, and over 200 seeds the outputs have the mean / spread of the
+    reference's OWN torch-generator Dropout (4.5 standard errors; spread within 25 %)."""
+    from nerfool_amd.gnt import transformer_network as tn
+    g = Golden('gnt_train_d2')
+    pd = float(g.np('p'))
+    for tag in ('plain', 'alpha'):
+        base, geo = Golden(str(g.np(tag + '/base'))), Golden(str(g.np(tag + '/geometry')))
+        depth = int(base.np('cfg')[5])
+        net = tn.GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=tag == 'alpha')
+        net.load_state_dict(base.params('net'), strict=True)
+        for p_ in net.parameters():
+            p_.requires_grad_(False)
+        net = net.to(dev)
+        assert abs(net.dropout_p - pd) < 1e-12
+        ins = [geo.t(k, dev) for k in ('net_in/ray_diff', 'net_in/mask', 'net_in/pts', 'in/ray_d')]
+        w = g.t(tag + '/w', dev)
+        net.train()
+        for seed in [int(x) for x in g.np(tag + '/seeds')]:
+            net.dropout_seed = seed
+            x = geo.t('net_in/rgb_feat', dev).requires_grad_(True)
+            y = net(x, *ins)
+            assert net.dropout_seed == seed + 1, 'every training-mode forward takes the next seed'
+            ref = g.np('%s/exact/%d/out' % (tag, seed))
+            assert_close(y, ref, 1e-3, 1e-3 * float(np.abs(ref).max()), 'train-mode output (%s, seed %d)' % (tag, seed))
+            grad, = torch.autograd.grad((y * w).sum(), x)
+            if tag == 'alpha':
+                # the module propagates no gradient through the returned attention (the rgb-loss path of the reference detaches it,
+                # gnt/render_ray.py:256): the expected gradient is the COLOUR columns' -- from the oracle with the same masks, which
+                # tests/test_oracle_golden_gnt.py pins to the reference's capture on all columns
+                from oracle import gnt_ref as gr
+                x64 = geo.t('net_in/rgb_feat').requires_grad_(True)
+                y64 = gr.gnt_forward(base.params('net'), x64, geo.t('net_in/ray_diff'), geo.t('net_in/mask'), geo.t('net_in/pts'),
+                                     geo.t('in/ray_d'), depth, ret_alpha=True, dropout=(seed, pd))
+                gref = torch.autograd.grad((y64[:, :3] * w.cpu()[:, :3]).sum(), x64)[0].numpy()
+            else:
+                gref = g.np('%s/exact/%d/d_rgb_feat' % (tag, seed))
+            assert_close(grad, gref, 2e-3, 1e-3 * float(np.abs(gref).max()), 'train-mode d out / d rgb_feat (%s, seed %d)' % (tag, seed), frac_ok=1e-3)
+        with torch.no_grad():
+            net.dropout_seed = 4000
+            draws = torch.stack([net(geo.t('net_in/rgb_feat', dev), *ins) for _ in range(200)]).cpu()
+            assert net.dropout_seed == 4200
+            net.eval()
+            ev = net(geo.t('net_in/rgb_feat', dev), *ins)
+        assert_close(ev, g.np(tag + '/eval'), 1e-3, 1e-3 * float(np.abs(g.np(tag + '/eval')).max()), 'eval-mode output after training-mode calls')
+        mean, std, n = g.np(tag + '/stat/mean'), g.np(tag + '/stat/std'), int(g.np(tag + '/stat/n'))
+        se = np.sqrt(std ** 2 / n + draws.std(0).numpy() ** 2 / draws.shape[0]) + 1e-6
+        zmax = float(np.abs((draws.mean(0).numpy() - mean) / se).max())
+        ratio = float(draws.std(0).numpy().mean() / std.mean())
+        print('[gnt train mode] %s: max |z| of the mean against the reference\'s own Dropout over %d elements %.2f; spread ratio %.3f'
+              % (tag, mean.size, zmax, ratio))
+        assert zmax <= 4.5 and 0.8 <= ratio <= 1.25
+
+
 def check_gnt_alpha(dev, kernel_path=None):
     """ret_alpha = True (attention weights, depth) and hierarchical sampling with one network, against the reference capture:
     both passes (32 and 32 + 32 samples) run through whichever forward the shape selects."""
@@ -1229,9 +1286,11 @@ def check_gnt_mfma_vs_generic(dev, shapes=((2, 32, 3, 2),)):
         assert_close(gc, ga, 1e-3, 2e-4 * float(ga.abs().max()), 'GNT d rgb_feat (matrix-core backward vs generic backward)')
 
 
-def check_gnt_attack_step(dev):
+def check_gnt_attack_step(dev, train=False):
     """One GNT PGD step (ResUNet single_net + GNT renderer + unmasked MSE + backward to delta + fused Adam update) against
-    the CPU oracle on the same weights and rays."""
+    the CPU oracle on the same weights and rays.  train=True: the model stays in TRAINING mode, as in the reference's universal GNT
+    loop (eval/gnt/eval_adv.py:739-878 runs before switch_to_eval at :959) -- Dropout(0.1) live with the counter-based masks, the
+    float64 oracle on the same (seed, p); then the universal loop itself runs a few steps (one seed per step, no graph replay)."""
     from nerfool_amd.gnt import eval_adv as GEA
     from nerfool_amd.gnt.model import GNTModel
     from nerfool_amd.synthetic import make_scene
@@ -1248,7 +1307,13 @@ def check_gnt_attack_step(dev):
             if isinstance(m, torch.nn.InstanceNorm2d):
                 m.weight.uniform_(0.5, 1.5)
                 m.bias.uniform_(-0.2, 0.2)
-    model.switch_to_eval()
+    if train:
+        model.switch_to_train()
+        assert model.net_coarse.training
+        model.net_coarse.dropout_seed = 24680
+    else:
+        model.switch_to_eval()
+    dropout = (24680, model.net_coarse.dropout_p) if train else None
     data = make_scene(H, W, V, seed=21, tilt=0.3)
     sampler = RaySamplerSingleImage(data, dev)
     src = sampler.get_all()
@@ -1277,7 +1342,7 @@ def check_gnt_attack_step(dev):
         tr = fnet.ReluTrace(masks)
         fm = fnet.resunet_forward(cnn, (src64['src_rgbs'] + d).squeeze(0).permute(0, 3, 1, 2), coarse_out_ch=32, fine_out_ch=32,
                                   trace=tr)[0]
-        ret = gr.render_rays(batch, p, (fm, fm), S, depth, inv_uniform=True, det=True, src_ray_batch=src64)
+        ret = gr.render_rays(batch, p, (fm, fm), S, depth, inv_uniform=True, det=True, src_ray_batch=src64, dropout=dropout)
         l = gr.criterion(ret['outputs_coarse'], batch)
         return float(l.detach()), torch.autograd.grad(l, d)[0], tr
     ref_loss, g_nat, tr_nat = oracle(None)
@@ -1285,13 +1350,35 @@ def check_gnt_attack_step(dev):
     ref_grad = oracle(masks)[1] if n_flip else g_nat
     assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-7, (loss, ref_loss)
     gerr = float((grad.cpu().double() - ref_grad).norm() / ref_grad.norm())
-    print('[grad parity] GNT step: d loss / d delta rel-L2 vs float64 oracle %.3e (ReLU units flipped: %d of %d, argument <= %.1e of the '
-          'plane rms)' % (gerr, n_flip, n_units, worst))
+    print('[grad parity] GNT step%s: d loss / d delta rel-L2 vs float64 oracle %.3e (ReLU units flipped: %d of %d, argument <= %.1e of the '
+          'plane rms)' % (' (training mode, Dropout 0.1)' if train else '', gerr, n_flip, n_units, worst))
     assert gerr <= 1e-3, 'GNT d loss / d delta: relative L2 error %.3e' % gerr
     assert worst <= 1e-4 and n_flip <= 3
     opt = atk.AdamAscent(delta0.shape, 1e-3, 100, 0.5)
     want = atk.project(opt.step(delta0.cpu(), grad.cpu()), data['src_rgbs'], 8.0 / 255.0)
     assert_close(atk_state.delta.detach(), want, 0, 2e-7, 'GNT delta after the fused Adam step')
+    if train:
+        # the universal loop in training mode (eval/gnt/eval_adv.py:739-878): adv_iters + 1 steps, a fresh Dropout seed per step,
+        # launch by launch (a graph replay would freeze the seed), projections intact, and a different seed gives another loss
+        assert model.net_coarse.dropout_seed == 24680 + 1          # (the ReLU-traced evaluation above ran once)
+        from fixtures import second_target_view
+        product_sample_ray.rng.seed(234)
+        uni = GEA.PGDAttack(args, model, Projector(dev), src, delta=delta0.clone().requires_grad_(True))
+        uni.run_universal([data, second_target_view(data)], n_iters=3)
+        assert uni.iters == 4 and uni.graph_replays == 0
+        assert model.net_coarse.dropout_seed == 24680 + 1 + 4
+        d = uni.delta.detach()
+        assert float(d.abs().max()) <= 8.0 / 255.0 + 1e-7
+        x = src['src_rgbs'] + d
+        assert float(x.min()) >= -1e-6 and float(x.max()) <= 1 + 1e-6
+        losses = []
+        for seed in (111, 111, 222):
+            model.net_coarse.dropout_seed = seed
+            a2 = GEA.PGDAttack(args, model, Projector(dev), src, delta=delta0.clone().requires_grad_(True))
+            a2.gradient(data, select_inds=picks)
+            losses.append(float(a2.last_loss))
+        assert losses[0] == losses[1] and losses[0] != losses[2], losses
+        model.switch_to_eval()
 
 
 def check_gnt_attack_gradient_kernel_paths(dev, shapes=((10, 32, 3, 2), (6, 64, 5, 2))):

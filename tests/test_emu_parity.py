@@ -229,3 +229,14 @@ def test_gnt_ret_alpha_and_hierarchical_sampling():
     # shape-generic kernels here (4 s); the matrix-core kernels take 4 minutes to emulate on this case: their ret_alpha output
     # is compared with the generic one in test_gnt_matrix_core_forward_matches_generic, the full case runs on the GPU
     pc.check_gnt_alpha('cpu', kernel_path='generic')
+
+
+def test_gnt_training_mode_dropout():
+    """the Dropout-active GNT forward / backward of the reference's universal loop, through the emulated shape-generic kernels"""
+    pc.check_gnt_train_mode('cpu')
+
+
+def test_gnt_universal_loop_in_training_mode():
+    """a GNT attack step and the universal loop with the model left in training mode (the reference's eval/gnt/eval_adv.py:739-878)"""
+    with wino_fp32_operands():
+        pc.check_gnt_attack_step('cpu', train=True)

@@ -152,6 +152,14 @@ def test_universal_trajectory():
     pc.check_universal_trajectory('cuda')
 
 
+def test_gnt_training_mode_dropout():
+    pc.check_gnt_train_mode('cuda')
+
+
+def test_gnt_universal_loop_in_training_mode():
+    pc.check_gnt_attack_step('cuda', train=True)
+
+
 def test_step_graph_equals_eager_step():
     pc.check_step_graph('cuda')
 

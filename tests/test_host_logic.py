@@ -64,15 +64,17 @@ def test_sampler_cache_key_accepts_slices_at_odd_float_offsets():
     RaySamplerSingleImage._cache.clear()
 
 
-def test_gnt_rejects_training_mode_loudly():
-    """the reference's universal GNT loop runs with Dropout(0.1) active (eval/gnt/eval_adv.py:739-878 before switch_to_eval at :959);
-    the kernels are eval-only, so a module in training mode raises instead of silently running eval semantics"""
+def test_gnt_training_mode_takes_consecutive_seeds():
+    """the reference's universal GNT loop runs with Dropout(0.1) active (eval/gnt/eval_adv.py:739-878 before switch_to_eval at :959):
+    a module in training mode runs the Dropout-active kernels, one seed per forward call, starting from torch's seed (the kernels
+    themselves: tests/test_emu_parity.py::test_gnt_training_mode_dropout)"""
     from nerfool_amd.gnt.transformer_network import GNT
+    torch.manual_seed(77)
     net = GNT(SimpleNamespace(netwidth=64, trans_depth=2), in_feat_ch=32, posenc_dim=63, viewenc_dim=63)
-    assert net.training
-    x = torch.zeros(2, 8, 3, 35)
-    with pytest.raises(RuntimeError, match='switch_to_eval'):
-        net(x, torch.zeros(2, 8, 3, 4), torch.ones(2, 8, 3, 1), torch.zeros(2, 8, 3), torch.zeros(2, 3))
+    assert net.training and net.dropout_p == 0.1 and net.dropout_seed is None
+    assert net.next_dropout_seed() == 77 and net.next_dropout_seed() == 78
+    net.dropout_seed = 0xffffffff
+    assert net.next_dropout_seed() == 0xffffffff and net.dropout_seed == 0
 
 
 def test_removed_environment_switches_warn_once():

@@ -51,3 +51,42 @@ def test_gnt_ret_alpha_and_hierarchical_sampling_match_reference():
     grad, = torch.autograd.grad(loss, fm)
     ref = g.np('grad/featmap')
     assert_close(grad, ref, 1e-3, 1e-4 * float(np.abs(ref).max()), 'd loss / d featmap')
+
+
+def gnt_train_inputs(g, tag, device='cpu'):
+    """(params, rgb_feat, ray_diff, mask, pts, ray_d, depth, upstream weights) of one case of gnt_train_d2.npz: the network weights of
+    its base fixture on the network-level capture of its geometry fixture"""
+    base, geo = Golden(str(g.np(tag + '/base'))), Golden(str(g.np(tag + '/geometry')))
+    depth = int(base.np('cfg')[5])
+    return (base.params('net', device), geo.t('net_in/rgb_feat', device), geo.t('net_in/ray_diff', device), geo.t('net_in/mask', device),
+            geo.t('net_in/pts', device), geo.t('in/ray_d', device), depth, g.t(tag + '/w', device))
+
+
+@pytest.mark.parametrize('tag', ['plain', 'alpha'])
+def test_gnt_training_mode_dropout_matches_reference(tag):
+    """The reference's universal GNT loop runs with Dropout(0.1) live (eval/gnt/eval_adv.py:739-878 before switch_to_eval at :959;
+    gnt/transformer_network.py:45-48, 72/85-88, 136/162-166).  (1) EXACT: the reference network in train() mode with its nn.Dropout
+    instances replaced by the counter-based masks (tests/golden/make_golden_gnt_train.py) against the oracle with the same (seed, site,
+    index) masks -- output and d out / d rgb_feat.  (2) STATISTICAL: over 400 seeds the oracle's outputs have the mean and the spread of
+    400 draws of the reference with its OWN torch-generator Dropout (4.5 standard errors per element; spread within 25 %)."""
+    g = Golden('gnt_train_d2')
+    p, rgb_feat, ray_diff, mask, pts, ray_d, depth, w = gnt_train_inputs(g, tag)
+    alpha = tag == 'alpha'
+    pd = float(g.np('p'))
+    for seed in [int(x) for x in g.np(tag + '/seeds')]:
+        x = rgb_feat.clone().requires_grad_(True)
+        y = gr.gnt_forward(p, x, ray_diff, mask, pts, ray_d, depth, ret_alpha=alpha, dropout=(seed, pd))
+        assert_close(y, g.np('%s/exact/%d/out' % (tag, seed)), 1e-4, 2e-5, 'train-mode output, seed %d' % seed)
+        grad, = torch.autograd.grad((y * w).sum(), x)
+        ref = g.np('%s/exact/%d/d_rgb_feat' % (tag, seed))
+        assert_close(grad, ref, 1e-3, 1e-4 * float(np.abs(ref).max()), 'train-mode d out / d rgb_feat, seed %d' % seed)
+    with torch.no_grad():
+        assert_close(gr.gnt_forward(p, rgb_feat, ray_diff, mask, pts, ray_d, depth, ret_alpha=alpha), g.np(tag + '/eval'), 1e-4, 2e-5, 'eval output')
+        draws = torch.stack([gr.gnt_forward(p, rgb_feat, ray_diff, mask, pts, ray_d, depth, ret_alpha=alpha, dropout=(1000 + s, pd))
+                             for s in range(400)])
+    mean, std, n = g.np(tag + '/stat/mean'), g.np(tag + '/stat/std'), int(g.np(tag + '/stat/n'))
+    se = np.sqrt(std ** 2 / n + draws.std(0).numpy() ** 2 / 400) + 1e-6
+    zmax = float(np.abs((draws.mean(0).numpy() - mean) / se).max())
+    ratio = float(draws.std(0).numpy().mean() / std.mean())
+    print('[gnt train mode] %s: max |z| of the mean over %d elements %.2f; spread ratio %.3f' % (tag, mean.size, zmax, ratio))
+    assert zmax <= 4.5 and 0.8 <= ratio <= 1.25
