@@ -1286,7 +1286,7 @@ def check_gnt_mfma_vs_generic(dev, shapes=((2, 32, 3, 2),)):
         assert_close(gc, ga, 1e-3, 2e-4 * float(ga.abs().max()), 'GNT d rgb_feat (matrix-core backward vs generic backward)')
 
 
-def check_gnt_attack_step(dev, train=False):
+def check_gnt_attack_step(dev, train=False, universal_iters=3):
     """One GNT PGD step (ResUNet single_net + GNT renderer + unmasked MSE + backward to delta + fused Adam update) against
     the CPU oracle on the same weights and rays.  train=True: the model stays in TRAINING mode, as in the reference's universal GNT
     loop (eval/gnt/eval_adv.py:739-878 runs before switch_to_eval at :959) -- Dropout(0.1) live with the counter-based masks, the
@@ -1364,9 +1364,9 @@ def check_gnt_attack_step(dev, train=False):
         from fixtures import second_target_view
         product_sample_ray.rng.seed(234)
         uni = GEA.PGDAttack(args, model, Projector(dev), src, delta=delta0.clone().requires_grad_(True))
-        uni.run_universal([data, second_target_view(data)], n_iters=3)
-        assert uni.iters == 4 and uni.graph_replays == 0
-        assert model.net_coarse.dropout_seed == 24680 + 1 + 4
+        uni.run_universal([data, second_target_view(data)], n_iters=universal_iters)
+        assert uni.iters == universal_iters + 1 and uni.graph_replays == 0
+        assert model.net_coarse.dropout_seed == 24680 + 1 + universal_iters + 1
         d = uni.delta.detach()
         assert float(d.abs().max()) <= 8.0 / 255.0 + 1e-7
         x = src['src_rgbs'] + d
