@@ -405,7 +405,13 @@ class PGDAttack:
         sampler = RaySamplerSingleImage.cached(data, device)
         n_rand = self.args.N_rand
         mode, ratio = getattr(self.args, 'sample_mode', 'uniform'), getattr(self.args, 'center_ratio', 0.8)
-        key = (id(sampler), n_rand, mode, ratio, self.use_adam)
+        # everything a replay would freeze: the target view (its sampler: rays, colours, cameras), the draw, the render settings, the
+        # projection radii, the buffers the captured kernels address (delta, moments, sources) and the state of the model's weights
+        # (parameter versions: an in-place edit re-packs the kernels' weight images at new addresses)
+        a = self.args
+        key = (id(sampler), n_rand, mode, ratio, self.use_adam, a.N_samples, a.N_importance, bool(a.inv_uniform), bool(getattr(a, 'det', True)),
+               bool(a.white_bkgd), bool(getattr(a, 'ret_alpha', False)), self.epsilon, self.alpha, self.delta.data_ptr(),
+               self.src['src_rgbs'].data_ptr(), self.exp_avg.data_ptr() if self.use_adam else 0, self._weights_version())
         picks = sampler.sample_random_pixel(n_rand, mode, ratio, lookahead=lookahead)
         if key not in self._graphs:
             if self._g_warm.get(key, 0) < 2 or len(self._graphs) >= self.MAX_GRAPHS:
@@ -426,6 +432,14 @@ class PGDAttack:
         self.graph_replays += 1
         self.last_loss = g_loss.clone()          # the graph's loss buffer is overwritten by the next replay
         return self.last_loss
+
+    def _weights_version(self):
+        v = 0
+        for net in (getattr(self.model, 'net_coarse', None), getattr(self.model, 'net_fine', None), getattr(self.model, 'feature_net', None)):
+            if net is not None:
+                for p in net.parameters():
+                    v = (v * 31 + p._version + p.data_ptr()) & 0xffffffffffff
+        return v
 
     def _capture(self, key, data, sampler, n_rand):
         device = self.delta.device
