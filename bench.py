@@ -764,7 +764,8 @@ def main():
                               'note': 'per-launch durations from HIP events on the launch stream, live inside the timed region on every '
                                       'N-th step (an event pair costs the GPU ~11 us around the launch it brackets)'},
         'cpu_baseline': None,
-        'extra': {'attack_s_per_1000_iters_from_ms_per_step': ms_step, 'final_loss': final_loss, 'kernels': table, 'whole_step': whole,
+        'extra': {'attack_s_per_1000_iters_from_ms_per_step': ms_step, 'final_loss': final_loss,
+                  'hbm_peak_allocated_gb': None if standin else round(torch.cuda.max_memory_allocated(dev) / 1e9, 3), 'kernels': table, 'whole_step': whole,
                   'hand_written_kernel_ms_per_step': None if hand_written_ms is None else round(hand_written_ms, 4),
                   'conv3x3_choice': {'%s %s' % (k[0], 'x'.join(map(str, k[1:]))): v for k, v in feature_network._CONV_CHOICE.items()},
                   'render': render, 'multi_gpu': multi, **extra_legs},
