@@ -116,6 +116,12 @@ def second_target_view(data, shift=(0.12, -0.05, 0.03), seed=77):
 ATTACK100 = {
     'c1': dict(H=96, W=128, V=4, S=16, N_imp=16, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
                lr_gamma=0.5, seed=8, chunk_size=4096, delta_stride=1),
+    # the two other loops of the reference at config 1's shape: sign-PGD (eval_adv.py:822-828, adv_lr 2 / 255: the perturbation saturates
+    # at +-eps within a few steps) and the UNIVERSAL loop over two target views (eval_adv.py:609-740: adv_iters + 1 steps) = config 3's loop
+    's1': dict(H=96, W=128, V=4, S=16, N_imp=16, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
+               lr_gamma=0.5, seed=8, chunk_size=4096, delta_stride=1, mode='sign', adv_lr=2),
+    'u1': dict(H=96, W=128, V=4, S=16, N_imp=16, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
+               lr_gamma=0.5, seed=8, chunk_size=4096, delta_stride=1, mode='universal'),
     'c2': dict(H=378, W=504, V=4, S=64, N_imp=64, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
                lr_gamma=0.5, seed=9, chunk_size=4096, delta_stride=10, image_dtype='float16'),
 }

@@ -647,7 +647,9 @@ def check_attack_loops(dev):
 # another summation order, pairwise); after 100 Adam-ascent iterations they are large -- a third of the perturbation's entries sit a
 # quarter of eps apart between the reference's own fp32 and float64 runs -- so what the test bounds is that the HIP trajectory is not
 # FURTHER from the reference's float64 run than twice what the reference's own float32 runs are.
-ATTACK100_BARS = {'loss_rel_max': (2.0, 0.0), 'loss_rel_mean': (2.0, 0.0), 'loss_last10_rel': (2.0, 5e-3),
+# (the floor is the largest of THREE pairwise distances -- a small sample of a noisy quantity: the mean of the last ten losses of the
+#  universal loop sits 0.4 % / 1.7 % / 2.1 % apart between the reference's own runs, hence its 3 % absolute allowance)
+ATTACK100_BARS = {'loss_rel_max': (2.0, 0.0), 'loss_rel_mean': (2.0, 0.0), 'loss_last10_rel': (2.0, 3e-2),
                   'delta_mean_abs_over_eps': (2.0, 0.0), 'delta_sign_disagree': (2.0, 0.0), 'frac_at_eps_diff': (2.0, 1e-2),
                   'image_rms': (2.0, 0.0), 'psnr_diff': (2.0, 0.1)}
 
@@ -683,8 +685,14 @@ def attack100_compare(tag, name, mine, g, eps, log=None):
     for k, (mult, allow) in ATTACK100_BARS.items():
         assert st64[k] <= mult * floor[k] + allow, '%s %s: %s = %.3e against %.1f x the reference floor %.3e (+ %.1e)' % (
             tag, name, k, st64[k], mult, floor[k], allow)
-    # the first iterations, before the trajectories part: the reference's losses to rounding
-    assert_close(np.asarray(mine['losses'][:3]), g.np('ref64/losses')[:3], 2e-3, 1e-6, 'first free-running losses')
+    # the first iterations, before the trajectories part: the reference's losses to rounding (sign-PGD moves every entry by a full
+    # +-2/255 on the sign of its gradient, entries with gradients at rounding level included: only the first loss is common there)
+    # Against the reference AS IT IS (float32): its float64 run already parts at the second step of the universal loop -- entries of
+    # delta whose gradient is exactly zero in float32 and 1e-20 in float64 take a full +-lr Adam step there, and the second target view
+    # sees them (0.11902 vs 0.12316).
+    from fixtures import ATTACK100
+    n_exact = 1 if ATTACK100[tag].get('mode') == 'sign' else 3
+    assert_close(np.asarray(mine['losses'][:n_exact]), g.np('ref32/losses')[:n_exact], 2e-3, 1e-6, 'first free-running losses')
     return st64
 
 
@@ -704,18 +712,28 @@ def check_attack100(dev, tag='c1', log=None):
         p.requires_grad_(False)
     model = SimpleNamespace(net_coarse=make_net(p_coarse, c['S'], True, dev), net_fine=make_net(p_fine, c['S'] + c['N_imp'], True, dev),
                             feature_net=feature_net.to(dev).eval())
+    mode = c.get('mode', 'adam')
     args = SimpleNamespace(N_rand=c['N_rand'], sample_mode='uniform', center_ratio=0.8, N_samples=c['S'], N_importance=c['N_imp'],
-                           inv_uniform=True, det=True, white_bkgd=False, epsilon=c['epsilon'], adv_lr=2, use_adam=True,
+                           inv_uniform=True, det=True, white_bkgd=False, epsilon=c['epsilon'], adv_lr=c.get('adv_lr', 2), use_adam=mode != 'sign',
                            adam_lr=c['adam_lr'], lr_step_size=c['lr_step_size'], lr_gamma=c['lr_gamma'], adv_iters=c['adv_iters'],
                            chunk_size=c['chunk_size'])
     sampler = RaySamplerSingleImage(data, dev)
     src = sampler.get_all()
     product_sample_ray.rng.seed(234)
     attack = EA.PGDAttack(args, model, Projector(dev), src, delta=delta0.to(dev).clone().requires_grad_(True))
-    losses = [attack.step(data) for _ in range(c['adv_iters'])]
+    if mode == 'universal':      # eval_adv.py:609-740 over two target views: adv_iters + 1 steps
+        from fixtures import second_target_view
+        losses, inner = [], attack.step
+        attack.step = lambda d, select_inds=None, lookahead=True: losses.append(inner(d, select_inds, lookahead)) or losses[-1]
+        attack.run_universal([data, second_target_view(data)], n_iters=c['adv_iters'])
+        n_steps = c['adv_iters'] + 1
+        assert len(losses) == n_steps and attack.iters == n_steps
+    else:
+        n_steps = c['adv_iters']
+        losses = [attack.step(data) for _ in range(n_steps)]
     # the pixel stream the loop consumed is the reference's
     rs, pick_sum = np.random.RandomState(234), 0
-    for it in range(c['adv_iters']):
+    for it in range(n_steps):
         pick_sum += int(rs.choice(c['H'] * c['W'], size=(c['N_rand'],), replace=False).astype(np.int64).sum()) * (it + 1)
     assert pick_sum == int(g.np('pick_checksum'))
     nxt = rs.choice(c['H'] * c['W'], size=(c['N_rand'],), replace=False)

@@ -264,7 +264,8 @@ def test_oracle_float64_gradient_matches_reference_float64(case):
     assert rel(grad32, ref64) < 3 * floor, 'oracle fp32 %.3e vs floor %.3e' % (rel(grad32, ref64), floor)
 
 
-def test_oracle_whole_attack_outcome_c1():
+@pytest.mark.parametrize('tag', ['c1', 's1', 'u1'])
+def test_oracle_whole_attack_outcome(tag):
     """The OUTCOME of a whole attack (tests/golden/attack100_c1.npz: the reference's eval_adv.py:781-843 loop, 100 Adam-ascent
     iterations at BASELINE config 1's shape, then :863-886's render of the attacked sources and its PSNR -- run by the reference in
     float32, in float64 and in float32 with another summation order).  The oracle's free-running loop on the same seeded inputs must
@@ -272,22 +273,32 @@ def test_oracle_whole_attack_outcome_c1():
     (tests/parity_cases.py:ATTACK100_BARS); the GPU test asserts the same of the HIP path."""
     import parity_cases as pcases
     from fixtures import ATTACK100, attack100_inputs
-    g = Golden('attack100_c1')
-    c = ATTACK100['c1']
+    from fixtures import second_target_view
+    g = Golden('attack100_' + tag)
+    c = ATTACK100[tag]
+    mode = c.get('mode', 'adam')
     data, cnn, pc, pf, delta0 = attack100_inputs(c)
+    views = [data, second_target_view(data)] if mode == 'universal' else [data]
     cam = data['camera']
-    ro, rd = ib.rays_single_image(c['H'], c['W'], cam[:, 2:18].reshape(-1, 4, 4), cam[:, 18:34].reshape(-1, 4, 4))
-    gt = data['rgb'].reshape(-1, 3)
+    rays = []
+    for v in views:
+        vc = v['camera']
+        o, d = ib.rays_single_image(c['H'], c['W'], vc[:, 2:18].reshape(-1, 4, 4), vc[:, 18:34].reshape(-1, 4, 4))
+        rays.append((o, d, v['rgb'].reshape(-1, 3), vc))
+    ro, rd, gt, _ = rays[0]
     src = {'src_rgbs': data['src_rgbs'], 'src_cameras': data['src_cameras']}
     rng = atk.new_pixel_rng()
     cfg = dict(N_samples=c['S'], N_importance=c['N_imp'], inv_uniform=True, white_bkgd=False)
 
-    def batch(_):
+    def batch(it):       # the universal loop cycles over the target views (eval_adv.py:646-740)
+        o, d, rgb, vc = rays[it % len(views)]
         idx = torch.from_numpy(atk.pick_pixels(rng, c['H'] * c['W'], c['N_rand']))
-        return {'ray_o': ro[idx], 'ray_d': rd[idx], 'rgb': gt[idx], 'camera': cam, 'depth_range': data['depth_range'],
+        return {'ray_o': o[idx], 'ray_d': d[idx], 'rgb': rgb[idx], 'camera': vc, 'depth_range': data['depth_range'],
                 'src_rgbs': src['src_rgbs'], 'src_cameras': src['src_cameras']}
-    delta, losses, _, _ = atk.pgd_attack(delta0, cnn, pc, pf, src, batch, cfg, c['adv_iters'], use_adam=True, adam_lr=c['adam_lr'],
-                                         lr_step_size=c['lr_step_size'], lr_gamma=c['lr_gamma'], epsilon=float(c['epsilon']))
+    n_steps = c['adv_iters'] + (1 if mode == 'universal' else 0)
+    delta, losses, _, _ = atk.pgd_attack(delta0, cnn, pc, pf, src, batch, cfg, n_steps, use_adam=mode != 'sign', adam_lr=c['adam_lr'],
+                                         lr_step_size=c['lr_step_size'], lr_gamma=c['lr_gamma'], adv_lr=float(c.get('adv_lr', 2)),
+                                         epsilon=float(c['epsilon']))
     with torch.no_grad():
         featmaps = fnet.resunet_forward(cnn, (src['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
         rb = {'ray_o': ro, 'ray_d': rd, 'rgb': gt, 'camera': cam, 'depth_range': data['depth_range'],
@@ -297,4 +308,4 @@ def test_oracle_whole_attack_outcome_c1():
     image = ret['outputs_fine']['rgb'].double().numpy()
     mine = dict(losses=np.array(losses), delta=delta.double().numpy().reshape(-1)[::c['delta_stride']], image=image,
                 psnr=float(-10. * np.log10(np.mean((image - data['rgb'][0].double().numpy()) ** 2))))
-    pcases.attack100_compare('c1', 'oracle (PyTorch-CPU restatement)', mine, g, c['epsilon'] / 255.0)
+    pcases.attack100_compare(tag, 'oracle (PyTorch-CPU restatement)', mine, g, c['epsilon'] / 255.0)
