@@ -122,6 +122,9 @@ ATTACK100 = {
                lr_gamma=0.5, seed=8, chunk_size=4096, delta_stride=1, mode='sign', adv_lr=2),
     'u1': dict(H=96, W=128, V=4, S=16, N_imp=16, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
                lr_gamma=0.5, seed=8, chunk_size=4096, delta_stride=1, mode='universal'),
+    # the GNT flavour (config 4's network family at fixture size: depth 2, single network, 32 samples = the matrix-core kernels' smallest shape, unmasked MSE), view-specific loop
+    'g1': dict(H=64, W=96, V=4, S=32, N_imp=0, N_rand=256, depth=2, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
+               lr_gamma=0.5, seed=12, chunk_size=2048, delta_stride=1, mode='adam', flavour='gnt'),
     'c2': dict(H=378, W=504, V=4, S=64, N_imp=64, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
                lr_gamma=0.5, seed=9, chunk_size=4096, delta_stride=10, image_dtype='float16'),
 }
@@ -159,3 +162,19 @@ def attack_outcome_stats(a, b, eps):
                 frac_at_eps_diff=abs(at(da) - at(db)),
                 image_rms=float(np.sqrt(np.mean((ia - ib) ** 2))),
                 psnr_diff=abs(float(a['psnr']) - float(b['psnr'])))
+
+
+def attack100_gnt_inputs(c):
+    """(data, single-network ResUNet state, GNT parameters, delta0) of the GNT whole-attack case; the same call is made by
+    tests/golden/make_golden_r05_gnt.py in front of the reference."""
+    from nerfool_amd.synthetic import make_scene
+    from oracle.feature_net_ref import random_resunet_state
+    from oracle.gnt_ref import random_gnt_params
+    data = make_scene(c['H'], c['W'], c['V'], seed=c['seed'], tilt=0.3)
+    cnn_sd = random_resunet_state(c['seed'] + 100, 32, 0)
+    params = random_gnt_params(c['depth'], seed=60 + c['seed'])
+    gen = torch.Generator().manual_seed(c['seed'] + 5)
+    eps = c['epsilon'] / 255.
+    delta0 = torch.zeros_like(data['src_rgbs']).uniform_(-eps, eps, generator=gen)
+    delta0 = torch.max(torch.min(delta0, 1 - data['src_rgbs']), 0 - data['src_rgbs'])
+    return data, cnn_sd, params, delta0

@@ -759,6 +759,54 @@ def check_attack100(dev, tag='c1', log=None, precision='fp32'):
                              early_rtol=2e-2 if precision == 'bf16' else 2e-3)
 
 
+def check_attack100_gnt(dev, log=None):
+    """The whole view-specific attack of the GNT flavour (eval/gnt/eval_adv.py:967-1054: 100 Adam-ascent iterations in eval mode, unmasked
+    MSE of the single-network render; :1119 render of the attacked sources; PSNR) against the reference's own float32 / float64 /
+    other-order runs (tests/golden/attack100_g1.npz, make_golden_r05_gnt.py): 32 samples per ray = the matrix-core GNT kernels."""
+    from fixtures import ATTACK100, attack100_gnt_inputs
+    from nerfool_amd.gnt import eval_adv as GEA
+    from nerfool_amd.gnt import transformer_network as tn
+    from nerfool_amd.gnt.render_image import render_single_image as gnt_render_single_image
+    g = Golden('attack100_g1')
+    c = ATTACK100['g1']
+    data, cnn_sd, params, delta0 = attack100_gnt_inputs(c)
+    eps = c['epsilon'] / 255.0
+    feature_net = ResUNet(coarse_out_ch=32, fine_out_ch=32, single_net=True)
+    feature_net.load_state_dict(cnn_sd, strict=True)
+    net = tn.GNT(SimpleNamespace(netwidth=64, trans_depth=c['depth']), in_feat_ch=32, posenc_dim=63, viewenc_dim=63)
+    net.load_state_dict(params, strict=True)
+    for m in (feature_net, net):
+        for p in m.parameters():
+            p.requires_grad_(False)
+    model = SimpleNamespace(net_coarse=net.to(dev).eval(), net_fine=None, feature_net=feature_net.to(dev).eval())
+    args = SimpleNamespace(netwidth=64, trans_depth=c['depth'], single_net=True, ret_alpha=False, N_rand=c['N_rand'], sample_mode='uniform',
+                           center_ratio=0.8, N_samples=c['S'], N_importance=0, inv_uniform=True, det=True, white_bkgd=False,
+                           epsilon=c['epsilon'], adv_lr=2, use_adam=True, adam_lr=c['adam_lr'], lr_step_size=c['lr_step_size'],
+                           lr_gamma=c['lr_gamma'], adv_iters=c['adv_iters'], chunk_size=c['chunk_size'])
+    sampler = RaySamplerSingleImage(data, dev)
+    src = sampler.get_all()
+    product_sample_ray.rng.seed(234)
+    attack = GEA.PGDAttack(args, model, Projector(dev), src, delta=delta0.to(dev).clone().requires_grad_(True))
+    losses = np.array([float(x) for x in [attack.step(data) for _ in range(c['adv_iters'])]])
+    rs, pick_sum = np.random.RandomState(234), 0
+    for it in range(c['adv_iters']):
+        pick_sum += int(rs.choice(c['H'] * c['W'], size=(c['N_rand'],), replace=False).astype(np.int64).sum()) * (it + 1)
+    assert pick_sum == int(g.np('pick_checksum'))
+    d = attack.delta.detach()
+    assert float(d.abs().max()) <= eps + 1e-7
+    x = src['src_rgbs'] + d
+    with torch.no_grad():
+        featmaps = model.feature_net(x.squeeze(0).permute(0, 3, 1, 2))
+        ret = gnt_render_single_image(ray_sampler=sampler, ray_batch=sampler.get_all(), model=model, projector=Projector(dev),
+                                      chunk_size=c['chunk_size'], det=True, N_samples=c['S'], inv_uniform=True, N_importance=0,
+                                      white_bkgd=False, featmaps=featmaps, ret_alpha=False, single_net=True, src_ray_batch=src)
+    image = ret['outputs_coarse']['rgb'].double().numpy()
+    gt = data['rgb'][0].double().numpy()
+    mine = dict(losses=losses, delta=d.cpu().double().numpy().reshape(-1)[::c['delta_stride']], image=image,
+                psnr=float(-10. * np.log10(np.mean((image - gt) ** 2))))
+    return attack100_compare('g1', 'HIP path (GNT)', mine, g, eps, log)
+
+
 def check_step_graph(dev):
     """PGDAttack.step as ONE hipGraph launch (eval_adv.PGDAttack._graph_step) against the launch-by-launch step: same kernels, same
     arguments, same order -- with the sorted (bitwise reproducible) feature-map scatter the perturbation, both Adam moments and the

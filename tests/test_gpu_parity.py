@@ -160,6 +160,15 @@ def test_gnt_universal_loop_in_training_mode():
     pc.check_gnt_attack_step('cuda', train=True)
 
 
+def test_whole_attack_outcome_gnt():
+    log = []
+    pc.check_attack100_gnt('cuda', log)
+    out = os.environ.get('NERFOOL_PARITY_LOG')
+    if out:
+        with open(out, 'a') as f:
+            f.write('\n'.join(log) + '\n')
+
+
 def test_whole_attack_outcome_bf16_rows():
     """the same whole attack with the IBRNet row network on bf16 matrix-core operands (BASELINE config 5's path): its outcome, too, lies
     no further from the reference's float64 run than twice the reference's own float32 distance (first losses within 2 %)"""

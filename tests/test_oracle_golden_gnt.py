@@ -90,3 +90,44 @@ def test_gnt_training_mode_dropout_matches_reference(tag):
     ratio = float(draws.std(0).numpy().mean() / std.mean())
     print('[gnt train mode] %s: max |z| of the mean over %d elements %.2f; spread ratio %.3f' % (tag, mean.size, zmax, ratio))
     assert zmax <= 4.5 and 0.8 <= ratio <= 1.25
+
+
+def test_oracle_whole_gnt_attack_outcome():
+    """the whole view-specific GNT attack (tests/golden/attack100_g1.npz: the reference's loop of eval/gnt/eval_adv.py:967-1054 in eval
+    mode, 100 iterations, render, PSNR -- in float32, float64 and float32 with another summation order): the oracle's free-running
+    loop ends no further from the reference's float64 run than twice the reference's own run-to-run distance"""
+    import parity_cases as pcases
+    from fixtures import ATTACK100, attack100_gnt_inputs
+    from oracle import attack_ref as atk, feature_net_ref as fnet, ibrnet_ref as ib
+    g = Golden('attack100_g1')
+    c = ATTACK100['g1']
+    data, cnn, p, delta0 = attack100_gnt_inputs(c)
+    cam = data['camera']
+    ro, rd = ib.rays_single_image(c['H'], c['W'], cam[:, 2:18].reshape(-1, 4, 4), cam[:, 18:34].reshape(-1, 4, 4))
+    gt = data['rgb'].reshape(-1, 3)
+    src = {'src_rgbs': data['src_rgbs'], 'src_cameras': data['src_cameras']}
+    rng = atk.new_pixel_rng()
+    eps = c['epsilon'] / 255.0
+    delta = delta0.clone()
+    opt = atk.AdamAscent(delta.shape, c['adam_lr'], c['lr_step_size'], c['lr_gamma'])
+    losses = []
+    for it in range(c['adv_iters']):
+        idx = torch.from_numpy(atk.pick_pixels(rng, c['H'] * c['W'], c['N_rand']))
+        batch = {'ray_o': ro[idx], 'ray_d': rd[idx], 'rgb': gt[idx], 'camera': cam, 'depth_range': data['depth_range']}
+        d = delta.clone().requires_grad_(True)
+        fm = fnet.resunet_forward(cnn, (src['src_rgbs'] + d).squeeze(0).permute(0, 3, 1, 2), coarse_out_ch=32, fine_out_ch=0)[0]
+        ret = gr.render_rays(batch, p, (fm, fm), c['S'], c['depth'], inv_uniform=True, det=True, src_ray_batch=src)
+        loss = gr.criterion(ret['outputs_coarse'], batch)
+        grad, = torch.autograd.grad(loss, d)
+        losses.append(float(loss))
+        delta = atk.project(opt.step(delta, grad), src['src_rgbs'], eps)
+    with torch.no_grad():
+        fm = fnet.resunet_forward(cnn, (src['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2), coarse_out_ch=32, fine_out_ch=0)[0]
+        rows = []
+        for i in range(0, ro.shape[0], c['chunk_size']):
+            b = {'ray_o': ro[i:i + c['chunk_size']], 'ray_d': rd[i:i + c['chunk_size']], 'camera': cam, 'depth_range': data['depth_range']}
+            rows.append(gr.render_rays(b, p, (fm, fm), c['S'], c['depth'], inv_uniform=True, det=True, src_ray_batch=src)['outputs_coarse']['rgb'])
+    image = torch.cat(rows).reshape(c['H'], c['W'], 3).double().numpy()
+    mine = dict(losses=np.array(losses), delta=delta.double().numpy().reshape(-1)[::c['delta_stride']], image=image,
+                psnr=float(-10. * np.log10(np.mean((image - data['rgb'][0].double().numpy()) ** 2))))
+    pcases.attack100_compare('g1', 'GNT oracle (PyTorch-CPU restatement)', mine, g, eps)
