@@ -1442,12 +1442,12 @@ def check_gnt_attack_step(dev, train=False, universal_iters=3):
         x = src['src_rgbs'] + d
         assert float(x.min()) >= -1e-6 and float(x.max()) <= 1 + 1e-6
         losses = []
-        for seed in (111, 111, 222):
+        for seed in (24680, 222):          # the seed of the first evaluation above again, then another one
             model.net_coarse.dropout_seed = seed
             a2 = GEA.PGDAttack(args, model, Projector(dev), src, delta=delta0.clone().requires_grad_(True))
             a2.gradient(data, select_inds=picks)
             losses.append(float(a2.last_loss))
-        assert losses[0] == losses[1] and losses[0] != losses[2], losses
+        assert losses[0] == loss and losses[1] != loss, (loss, losses)
         model.switch_to_eval()
 
 

@@ -238,5 +238,11 @@ def test_gnt_training_mode_dropout():
 
 def test_gnt_universal_loop_in_training_mode():
     """a GNT attack step and the universal loop with the model left in training mode (the reference's eval/gnt/eval_adv.py:739-878)"""
-    with wino_fp32_operands():
+    # (the Dropout sites live in the GNT kernels: the feature CNN runs as the plain nn.Module graph here, which the stand-in does not
+    #  have to emulate -- the fused executor under a GNT step is test_gnt_attack_step's)
+    from nerfool_amd.ibrnet import feature_network
+    saved, feature_network.CNN_PATH = feature_network.CNN_PATH, 'torch'
+    try:
         pc.check_gnt_attack_step('cpu', train=True, universal_iters=1)
+    finally:
+        feature_network.CNN_PATH = saved
