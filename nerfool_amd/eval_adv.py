@@ -70,7 +70,7 @@ def clean_featmaps(model, src_ray_batch):
 
 
 def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, return_loss=True, select_inds=None,
-                         shard=None, criterion=None, lookahead=False, featmaps_clean=None):
+                         shard=None, criterion=None, lookahead=False, featmaps_clean=None, two_phase=False):
     """One loss evaluation of the attack (eval_adv.py:258-310,512-519): draw N_rand rays of the target view `data`,
     features from the PERTURBED source images, colours from the CLEAN ones, masked MSE on coarse + fine.
 
@@ -84,7 +84,9 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
     shard: optional `RayShard` -- this rank renders its slice of the drawn rays and the loss denominators are the
     all-reduced mask counts.
     lookahead: the caller is a PGD loop that will draw again -- the next iteration's pixel pick is prepared on a helper
-    thread (same RandomState stream, see ibrnet/sample_ray.py)."""
+    thread (same RandomState stream, see ibrnet/sample_ray.py).
+    two_phase: (shard with the CNN sharded by view) the caller finishes the backward pass itself with
+    `shard.finish_view_sharded_backward(loss)` instead of `loss.backward()` -- see RayShard.view_sharded_featmaps."""
     _reject_out_of_scope(args)
     device = delta.device
     sampler = RaySamplerSingleImage.cached(data, device)
@@ -95,8 +97,8 @@ def optimize_adv_perturb(args, delta, model, projector, src_ray_batch, data, ret
         if shard is not None:
             select_inds = select_inds[shard.rank::shard.world]
     train_ray_batch = sampler.select(select_inds)
-    if shard is not None and shard.shard_views and shard.world > 1:
-        featmaps = shard.view_sharded_featmaps(model.feature_net, src_ray_batch['src_rgbs'], delta)
+    if shard is not None and shard.exchanges_views:
+        featmaps = shard.view_sharded_featmaps(model.feature_net, src_ray_batch['src_rgbs'], delta, two_phase=two_phase)
     else:
         featmaps = model.feature_net((src_ray_batch['src_rgbs'] + delta).squeeze(0).permute(0, 3, 1, 2))
     gnt = _is_gnt(model)
@@ -180,7 +182,9 @@ class RayShard:
 
     Every rank then applies the identical deterministic update, so delta stays replicated without a broadcast."""
 
-    def __init__(self, group=None, shard_views=True, split_n_rand=False):
+    def __init__(self, group=None, shard_views=True, split_n_rand=False, exchange_when_alone=False):
+        """exchange_when_alone: test hook -- a ONE-rank group still runs the view-sharded flow with its four collectives (the only way
+        to drive those RCCL calls, and the graph segments around them, on a single-GPU box)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -188,9 +192,16 @@ class RayShard:
         self.world = dist.get_world_size(group)
         self.shard_views = bool(shard_views)
         self.split_n_rand = bool(split_n_rand)
+        self._exchange_when_alone = bool(exchange_when_alone)
         self.collectives = 0            # issued so far (bench.py reports collectives per step)
         self.bytes = 0                  # payload bytes of those collectives (size of the reduced / gathered buffer)
         self.gather_render_to = 0       # group rank that receives a sharded render_single_image (None: every rank)
+        self._segmenter = None          # set while PGDAttack captures a step: collectives cut the capture into graph segments
+        self._pending = None            # two-phase backward of the view-sharded CNN (view_sharded_featmaps(two_phase=True))
+
+    @property
+    def exchanges_views(self):
+        return self.shard_views and (self.world > 1 or self._exchange_when_alone)
 
     def global_rank(self, r):
         return self.dist.get_global_rank(self.group, r) if self.group is not None else r
@@ -212,6 +223,19 @@ class RayShard:
         self.collectives += 1
         self.bytes += t.numel() * t.element_size()
 
+    def _run(self, collective, payload):
+        """Issue one collective of the step (`collective()`: a closure over STATIC buffers, nothing allocated inside).  While a step is
+        being captured (PGDAttack._capture) the collective is not issued: it ends the current graph segment, is remembered, and the next
+        segment begins -- a replayed step is then segment, collective, segment, ... with the collectives enqueued eagerly between the
+        graph launches (host-driven backends like gloo cannot be captured; RCCL sees exactly the calls of an eager step)."""
+        def issue():
+            collective()
+            self._count(payload)
+        if self._segmenter is not None:
+            self._segmenter.cut(issue)
+        else:
+            issue()
+
     def gather_views_nhwc(self, local, lo, hi, n_views):
         """local [hi-lo, C, H, W] channels-last (the views this rank owns) -> [V, C, H, W] channels-last on every rank"""
         full = torch.empty((n_views,) + tuple(local.shape[1:]), dtype=local.dtype,
@@ -220,13 +244,12 @@ class RayShard:
         assert flat.is_contiguous()
         if self.even(n_views):
             mine = local.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
-            self.dist.all_gather_into_tensor(flat, mine, group=self.group)
+            self._run(lambda: self.dist.all_gather_into_tensor(flat, mine, group=self.group), flat)
         else:
             flat.zero_()
             if hi > lo:
                 full[lo:hi] = local
-            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
-        self._count(flat)
+            self._run(lambda: self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group), flat)
         return full
 
     def scatter_views_nhwc(self, g, lo, hi):
@@ -234,12 +257,12 @@ class RayShard:
         [hi-lo, C, H, W] channels-last"""
         flat = g.permute(0, 2, 3, 1)
         assert flat.is_contiguous()
-        self._count(flat)
         if self.even(g.shape[0]):
             out = torch.empty((hi - lo,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last)
-            self.dist.reduce_scatter_tensor(out.permute(0, 2, 3, 1), flat, op=self.dist.ReduceOp.SUM, group=self.group)
+            out_flat = out.permute(0, 2, 3, 1)
+            self._run(lambda: self.dist.reduce_scatter_tensor(out_flat, flat, op=self.dist.ReduceOp.SUM, group=self.group), flat)
             return out
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._run(lambda: self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group), flat)
         return g[lo:hi]
 
     def gather_rows(self, buf, dst=0):
@@ -261,8 +284,13 @@ class RayShard:
         self.bytes += self.world * buf.numel() * buf.element_size()
         return full
 
-    def view_sharded_featmaps(self, feature_net, src_rgbs, delta):
-        """feature_net(src + delta) with the views split over the ranks -> the same tuple the network returns."""
+    def view_sharded_featmaps(self, feature_net, src_rgbs, delta, two_phase=False):
+        """feature_net(src + delta) with the views split over the ranks -> the same tuple the network returns.
+
+        two_phase (PGDAttack): the gathered maps are autograd LEAVES and the caller finishes the backward pass with
+        `finish_view_sharded_backward(loss)` -- d maps, the reduce-scatter, then the CNN backward of the own views -- so that every
+        collective is issued from the calling thread (a captured step is cut into graph segments there; autograd's device thread
+        cannot end a stream capture).  Otherwise one autograd.Function carries both exchanges and `loss.backward()` just works."""
         n_views, H, W = src_rgbs.shape[1], src_rgbs.shape[2], src_rgbs.shape[3]
         lo, hi = self.view_range(n_views)
         channels, twice, second_none, Hf, Wf = feature_net.describe_output(H, W)
@@ -270,12 +298,30 @@ class RayShard:
             local = feature_net.forward_full((src_rgbs[:, lo:hi] + delta[:, lo:hi]).squeeze(0).permute(0, 3, 1, 2))
         else:       # nothing to compute here, but this rank still takes part in both exchanges
             local = delta.new_zeros((0, sum(channels), Hf, Wf)) + delta[:, 0:0].sum()
-        maps = _GatherViewFeatures.apply(local, self, lo, hi, n_views, tuple(channels))
+        if two_phase:
+            full = self.gather_views_nhwc(local.detach(), lo, hi, n_views)
+            maps = tuple(m.requires_grad_() for m in (full.split(list(channels), dim=1) if len(channels) > 1 else (full,)))
+            self._pending = (local, maps, lo, hi)
+        else:
+            maps = _GatherViewFeatures.apply(local, self, lo, hi, n_views, tuple(channels))
         if twice:
             return maps[0], maps[0]
         if second_none:
             return maps[0], None
         return maps[0], maps[1]
+
+    def finish_view_sharded_backward(self, loss):
+        """second half of view_sharded_featmaps(two_phase=True): d loss / d maps on this rank's rays -> ONE collective (sum over the ranks,
+        each keeps its own views) -> backward through the feature CNN of the own views into delta.grad"""
+        local, maps, lo, hi = self._pending
+        self._pending = None
+        gs = torch.autograd.grad(loss, maps, allow_unused=True)
+        ref = next(g for g in gs if g is not None)
+        gs = [torch.zeros_like(ref, memory_format=torch.channels_last) if g is None else g for g in gs]
+        g = gs[0].clone(memory_format=torch.channels_last) if len(gs) == 1 else \
+            torch.cat(gs, dim=1).contiguous(memory_format=torch.channels_last)
+        out = self.scatter_views_nhwc(g, lo, hi)
+        local.backward(out)
 
     def global_counts_and_loss(self, ret, train_ray_batch):
         """ONE small all-reduce per step: [valid rays coarse, valid rays fine, sum of masked squared errors coarse, fine]
@@ -289,8 +335,7 @@ class RayShard:
         c, nc = stats(ret['outputs_coarse'])
         f, nf = stats(ret['outputs_fine']) if ret['outputs_fine'] is not None else (c, torch.zeros_like(nc))
         buf = torch.cat([c, f, nc, nf])
-        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group)
-        self._count(buf)
+        self._run(lambda: self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group), buf)
         loss = buf[2] / (buf[0] * 3 + 1e-6)
         if ret['outputs_fine'] is not None:
             loss = loss + buf[3] / (buf[1] * 3 + 1e-6)
@@ -301,13 +346,48 @@ class RayShard:
         so the sum over the ranks IS the concatenation of the owners' slices -- one all-gather, half the bytes of an
         all-reduce (an all-reduce when the views do not divide evenly)."""
         V = grad.shape[1] if grad.dim() == 5 else 0
-        if self.shard_views and self.world > 1 and grad.dim() == 5 and grad.is_contiguous() and self.even(V):
+        if self.exchanges_views and grad.dim() == 5 and grad.is_contiguous() and self.even(V):
             lo, hi = self.view_range(V)
-            self.dist.all_gather_into_tensor(grad[0], grad[0, lo:hi].clone(), group=self.group)
+            whole, mine = grad[0], grad[0, lo:hi].clone()
+            self._run(lambda: self.dist.all_gather_into_tensor(whole, mine, group=self.group), grad)
         else:
-            self.dist.all_reduce(grad, op=self.dist.ReduceOp.SUM, group=self.group)
-        self._count(grad)
+            self._run(lambda: self.dist.all_reduce(grad, op=self.dist.ReduceOp.SUM, group=self.group), grad)
         return grad
+
+
+class _SegmentedCapture:
+    """A PGD step captured as hipGraph SEGMENTS split at its collectives: [graph 0] collective 0 [graph 1] collective 1 ... [graph n].
+    Unsharded steps have no collective and are one graph.  All segments allocate from ONE private pool, so a tensor made in segment k
+    (saved activations, the autograd graph's buffers, the static collective buffers) is still there when segment k + 1 reads it -- the
+    arrangement of torch.cuda.make_graphed_callables (separate forward / backward graphs over one pool).  Nothing executes while
+    capturing, so the collectives are NOT issued at capture time (every rank captures at the same step): `replay()` runs the step."""
+
+    def __init__(self, pool, error_mode):
+        self.pool, self.error_mode = pool, error_mode
+        self.graphs, self.collectives = [], []
+        self._ctx = None
+
+    def begin(self):
+        g = torch.cuda.CUDAGraph()
+        self._ctx = torch.cuda.graph(g, pool=self.pool, capture_error_mode=self.error_mode)
+        self._ctx.__enter__()
+        self.graphs.append(g)
+
+    def cut(self, collective):
+        self._ctx.__exit__(None, None, None)
+        self.collectives.append(collective)
+        self.begin()
+
+    def end(self, failed=False):
+        ctx, self._ctx = self._ctx, None
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+
+    def replay(self):
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.collectives):
+                self.collectives[i]()
 
 
 class PGDAttack:
@@ -317,8 +397,9 @@ class PGDAttack:
     delta, optional gradient all-reduce, fused update + eps-ball + [0,1]-box projection."""
 
     def __init__(self, args, model, projector, src_ray_batch, shard=None, delta=None, graph=None):
-        """graph: None (default) -- on a GPU, single process, the steps of one target view are captured into a hipGraph after two
-        eager steps and replayed (`_graph_step`); False -- every step is enqueued launch by launch."""
+        """graph: None (default) -- on a GPU the steps of one target view are captured after two eager steps and replayed
+        (`_graph_step`): ONE hipGraph without a shard, graph segments split at the collectives with one (`_SegmentedCapture`);
+        False -- every step is enqueued launch by launch."""
         _reject_out_of_scope(args)
         self.args, self.model, self.projector, self.src = args, model, projector, src_ray_batch
         self.shard = shard
@@ -335,7 +416,7 @@ class PGDAttack:
         self.iters = 0
         self.last_loss = None
         self._featmaps_clean = None
-        self.use_graph = (graph is None or bool(graph)) and shard is None and self.delta.is_cuda
+        self.use_graph = (graph is None or bool(graph)) and self.delta.is_cuda
         self._graphs = {}           # (target view, draw) -> (CUDAGraph, static picks, static {neg_step_size, bc2_sqrt}, loss, gradient, sampler)
         self._g_warm = {}           # key -> eager steps taken on it so far
         self._g_pool = None         # one activation pool for all captured views (replays never overlap; the loss is copied out)
@@ -350,10 +431,16 @@ class PGDAttack:
         self.delta.grad = None
         if self._featmaps_clean is None and getattr(self.args, 'use_pseudo_gt', False):
             self._featmaps_clean = clean_featmaps(self.model, self.src)
+        # (view-sharded CNN: the backward pass is finished in two phases around its reduce-scatter -- every collective of a step is
+        #  issued from this thread, which is what lets `_capture` cut the step into graph segments there)
+        two_phase = self.shard is not None and self.shard.exchanges_views
         loss, total = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data,
                                            return_loss=True, select_inds=select_inds, shard=self.shard, lookahead=lookahead,
-                                           featmaps_clean=self._featmaps_clean)
-        loss.backward()
+                                           featmaps_clean=self._featmaps_clean, two_phase=two_phase)
+        if two_phase:
+            self.shard.finish_view_sharded_backward(loss)
+        else:
+            loss.backward()
         grad = self.delta.grad
         if self.shard is not None:
             self.shard.all_reduce_grad(grad)
@@ -378,7 +465,7 @@ class PGDAttack:
         self.apply(self.gradient(data, select_inds, lookahead))
         return self.last_loss
 
-    # ---- the step as ONE hipGraph launch ------------------------------------------------------------------------------------
+    # ---- the step as ONE hipGraph launch (sharded: as graph segments between its collectives) ---------------------------------
     # A PGD step is ~250 kernel launches of fixed shapes on fixed buffers; enqueued one by one from Python they cost the host
     # 4.5 ms against 8 ms of GPU time (BENCH_r04 host_issue_ms_per_step).  The iteration-dependent inputs are exactly two: the pixel
     # picks (host RNG stream -> a static int64 device buffer, refreshed by a stream-ordered copy before each replay) and Adam's
@@ -388,6 +475,11 @@ class PGDAttack:
     # at most MAX_GRAPHS views, further ones run eagerly) after two eager steps on that view have warmed every lazy initialisation,
     # and replayed: the same kernels on the same arguments in the same order, so an eager step and a replayed one are
     # interchangeable (bench.py interleaves them: HIP-event brackets need eager launches).
+    # Sharded (RayShard): the same capture, cut at every collective of the step (RayShard._run -> _SegmentedCapture.cut): the north-star
+    # form is [CNN fwd, render fwd, local loss sums] 16-byte all-reduce [loss, render bwd, CNN bwd] all-reduce of d delta [update]; the
+    # view-sharded form has five segments around its four collectives.  Each rank draws the step's picks (the same stream on every
+    # rank), keeps its rank::world slice and copies it into its static index buffer.  All ranks take the same eager / capture / replay
+    # decisions (they depend on step counts only), so the collectives stay matched.
     MAX_GRAPHS = 64
 
     def _graph_eligible(self, select_inds):
@@ -403,7 +495,8 @@ class PGDAttack:
         import numpy as np
         device = self.delta.device
         sampler = RaySamplerSingleImage.cached(data, device)
-        n_rand = self.args.N_rand
+        shard = self.shard
+        n_rand = self.args.N_rand if shard is None else shard.pixels_to_draw(self.args.N_rand)
         mode, ratio = getattr(self.args, 'sample_mode', 'uniform'), getattr(self.args, 'center_ratio', 0.8)
         # everything a replay would freeze: the target view (its sampler: rays, colours, cameras), the draw, the render settings, the
         # projection radii, the buffers the captured kernels address (delta, moments, sources) and the state of the model's weights
@@ -411,15 +504,18 @@ class PGDAttack:
         a = self.args
         key = (id(sampler), n_rand, mode, ratio, self.use_adam, a.N_samples, a.N_importance, bool(a.inv_uniform), bool(getattr(a, 'det', True)),
                bool(a.white_bkgd), bool(getattr(a, 'ret_alpha', False)), self.epsilon, self.alpha, self.delta.data_ptr(),
-               self.src['src_rgbs'].data_ptr(), self.exp_avg.data_ptr() if self.use_adam else 0, self._weights_version())
+               self.src['src_rgbs'].data_ptr(), self.exp_avg.data_ptr() if self.use_adam else 0, self._weights_version(),
+               None if shard is None else (shard.rank, shard.world, shard.exchanges_views, shard.split_n_rand))
         picks = sampler.sample_random_pixel(n_rand, mode, ratio, lookahead=lookahead)
+        if shard is not None:
+            picks = picks[shard.rank::shard.world]
         if key not in self._graphs:
             if self._g_warm.get(key, 0) < 2 or len(self._graphs) >= self.MAX_GRAPHS:
                 # eager: warms allocator, record packing, per-device kernel attributes
                 self._g_warm[key] = self._g_warm.get(key, 0) + 1
                 self.apply(self.gradient(data, picks, False))
                 return self.last_loss
-            self._capture(key, data, sampler, n_rand)
+            self._capture(key, data, sampler, len(picks))
         graph, g_idx, g_hyper, g_loss = self._graphs[key][:4]
         g_idx.copy_(torch.from_numpy(np.ascontiguousarray(picks, dtype=np.int64)).pin_memory(), non_blocking=True)
         if self.use_adam:
@@ -445,21 +541,27 @@ class PGDAttack:
         device = self.delta.device
         g_idx = torch.zeros(n_rand, dtype=torch.int64, device=device)
         g_hyper = torch.ones(2, dtype=torch.float32, device=device)
-        graph = torch.cuda.CUDAGraph()
         self.delta.grad = None
         torch.cuda.synchronize(device)
         if self._g_pool is None:
             self._g_pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(graph, pool=self._g_pool):
-            loss, total = optimize_adv_perturb(self.args, self.delta, self.model, self.projector, self.src, data, return_loss=True,
-                                               select_inds=g_idx, lookahead=False)
-            loss.backward()
-            grad = self.delta.grad
+        # (a process group's watchdog thread may poll its events while this thread captures: with a shard, capture errors are scoped
+        #  to the capturing thread)
+        graph = _SegmentedCapture(self._g_pool, 'global' if self.shard is None else 'thread_local')
+        if self.shard is not None:
+            self.shard._segmenter = graph
+        try:
+            graph.begin()
+            grad = self.gradient(data, select_inds=g_idx, lookahead=False)        # (sharded: its collectives cut the capture)
             if self.use_adam:
                 ops.pgd_adam_step_dev_(self.delta.data, grad, self.exp_avg, self.exp_avg_sq, self.src['src_rgbs'], g_hyper, self.epsilon)
             else:
                 ops.pgd_sign_step_(self.delta.data, grad, self.src['src_rgbs'], self.alpha, self.epsilon)
-            g_loss = total['rgb'].detach()
+            g_loss = self.last_loss
+        finally:
+            if self.shard is not None:
+                self.shard._segmenter = None
+            graph.end()
         self.delta.grad = None
         # (the sampler is held so that its ray tensors -- and its id(), part of the key -- outlive the graph that reads them)
         self._graphs[key] = (graph, g_idx, g_hyper, g_loss, grad, sampler)

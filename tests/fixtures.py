@@ -127,6 +127,12 @@ ATTACK100 = {
                lr_gamma=0.5, seed=12, chunk_size=2048, delta_stride=1, mode='adam', flavour='gnt'),
     'c2': dict(H=378, W=504, V=4, S=64, N_imp=64, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
                lr_gamma=0.5, seed=9, chunk_size=4096, delta_stride=10, image_dtype='float16'),
+    # round 6: BASELINE config 2 at its REAL frame size (756 x 1008, 64 + 64 samples, N_rand 512), 100 of its 1000 iterations, run FIVE times by
+    # the reference (tests/golden/make_golden_r06.py: float32, float64, and three other summation orders of float32 -- oneDNN off, 3 threads,
+    # 5 threads with oneDNN off): the floor is a maximum over ten pairwise distances.  The attacked image is rendered through the
+    # reference's own render_stride argument (every 4th pixel: 189 x 252 rays; a full-frame CPU render is ~40 min per run).
+    'c2full': dict(H=756, W=1008, V=4, S=64, N_imp=64, N_rand=512, adv_iters=100, epsilon=8, adam_lr=1e-3, lr_step_size=100,
+                   lr_gamma=0.5, seed=10, chunk_size=4096, delta_stride=40, image_dtype='float16', render_stride=4, skip_clean_render=True),
 }
 
 

@@ -34,15 +34,24 @@ from make_golden import EA, Projector, ResUNet, npy, ref_net, ref_sample_ray, re
 from fixtures import ATTACK100, attack100_inputs, attack_outcome_stats, second_target_view  # noqa: E402  (also runs on the GPU box)
 
 
-def reference_attack(dtype, c, inputs, use_ea, mkldnn=True, log=None):
+def reference_attack(dtype, c, inputs, use_ea, mkldnn=True, log=None, threads=None, checkpoints=()):
     """One whole attack of the reference in `dtype`.  use_ea: iterate through the reference's own optimize_adv_perturb (float32
     only: it builds its sampler and draws its pixels itself); otherwise the same body (eval_adv.py:264-310) on explicit picks
-    from an identical RandomState(234) stream, with the fp32 rays cast to `dtype`."""
+    from an identical RandomState(234) stream, with the fp32 rays cast to `dtype`.
+    Round 6 (make_golden_r06.py): `threads` = torch's intra-op thread count for this run (another partition of the reductions);
+    c['render_stride'] renders every n-th pixel of the attacked image through the reference's own render_stride argument;
+    `checkpoints` = iterations t at which the state around the step is kept (delta_t, Adam moments before and after, the
+    reference's gradient, the picks, delta_t+1)."""
     from ibrnet.render_image import render_single_image
     from ibrnet.render_ray import render_rays
     data, cnn_sd, pc, pf, delta0 = inputs
     S, N_imp, R = c['S'], c['N_imp'], c['N_rand']
     old = torch.get_default_dtype()
+    old_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(threads)
+    stride = c.get('render_stride', 1)
+    ckpt = {}
     cast = lambda t: t.to(dtype) if torch.is_tensor(t) and t.is_floating_point() else t
     try:
         sampler = ref_sample_ray.RaySamplerSingleImage(data, 'cpu')       # fp32 rays: INPUTS of every run
@@ -83,6 +92,10 @@ def reference_attack(dtype, c, inputs, use_ea, mkldnn=True, log=None):
                 rays_o, rays_d, rgb_all = smp.rays_o.to(dtype), smp.rays_d.to(dtype), cast(smp.rgb)
                 picks = rs.choice(smp.H * smp.W, size=(R,), replace=False)
                 pick_sum += int(picks.astype(np.int64).sum()) * (it + 1)
+                if it in checkpoints:
+                    st = opt.state[delta]
+                    ckpt[it] = dict(picks=picks.astype(np.int64), delta=delta.data.clone().numpy(), exp_avg=st['exp_avg'].clone().numpy(),
+                                    exp_avg_sq=st['exp_avg_sq'].clone().numpy(), step=int(st['step']), lr=float(opt.param_groups[0]['lr']))
                 if use_ea:
                     loss, _ = EA.optimize_adv_perturb(args, delta, model, projector, src_ray_batch, views[vi], return_loss=True)
                 else:
@@ -104,31 +117,42 @@ def reference_attack(dtype, c, inputs, use_ea, mkldnn=True, log=None):
                 else:
                     opt.zero_grad()
                     loss.backward()
+                    if it in checkpoints:
+                        ckpt[it]['grad'] = delta.grad.detach().clone().numpy()      # d loss / d delta (before the sign flip)
                     delta.grad.data *= -1
                     opt.step()
                     sched.step()
                 delta.data = EA.clamp(delta.data, -eps, eps)
                 delta.data = EA.clamp(delta.data, 0 - src, 1 - src)
                 losses.append(float(loss))
+                if it in checkpoints:
+                    st = opt.state[delta]
+                    ckpt[it].update(loss=float(loss), delta_next=delta.data.clone().numpy(), exp_avg_next=st['exp_avg'].clone().numpy(),
+                                    exp_avg_sq_next=st['exp_avg_sq'].clone().numpy())
                 if log and (it % 10 == 0 or it + 1 == n_steps):
                     print('  %s iter %3d loss %.7f  (%.1f s)' % (log, it, losses[-1], time.time() - t0), flush=True)
             # the attacked render + the clean one (eval_adv.py:863-886; PSNR as :888-905 / utils.py:35 on the fine image)
             images = {}
             with torch.no_grad():
-                ray_batch = {k: cast(v) for k, v in sampler.get_all().items()}
+                render_sampler = sampler if stride == 1 else ref_sample_ray.RaySamplerSingleImage(data, 'cpu', render_stride=stride)
+                ray_batch = {k: cast(v) for k, v in render_sampler.get_all().items()}
                 for tag, d in (('adv', delta.data), ('clean', torch.zeros_like(delta.data))):
                     featmaps = feature_net((src + d).squeeze(0).permute(0, 3, 1, 2))
-                    ret = render_single_image(ray_sampler=sampler, ray_batch=ray_batch, model=model, projector=projector,
+                    if tag == 'clean' and c.get('skip_clean_render') and dtype != torch.float64:
+                        continue
+                    ret = render_single_image(ray_sampler=render_sampler, ray_batch=ray_batch, model=model, projector=projector,
                                               chunk_size=c['chunk_size'], det=True, N_samples=S, inv_uniform=True,
-                                              N_importance=N_imp, white_bkgd=False, featmaps=featmaps, args=args,
+                                              N_importance=N_imp, white_bkgd=False, render_stride=stride, featmaps=featmaps, args=args,
                                               src_ray_batch=src_ray_batch)
                     images[tag] = ret['outputs_fine']['rgb'].double().numpy()
-        gt = data['rgb'][0].double().numpy()
+        gt = data['rgb'][0].double().numpy()[::stride, ::stride]
         psnr = {k: float(-10. * np.log10(np.mean((v - gt) ** 2))) for k, v in images.items()}
         return dict(losses=np.array(losses), delta=delta.data.double().numpy().copy(), image=images['adv'],
-                    image_clean=images['clean'], psnr=psnr['adv'], psnr_clean=psnr['clean'], pick_sum=pick_sum)
+                    image_clean=images.get('clean'), psnr=psnr['adv'], psnr_clean=psnr.get('clean', float('nan')), pick_sum=pick_sum,
+                    checkpoints=ckpt)
     finally:
         torch.set_default_dtype(old)
+        torch.set_num_threads(old_threads)
 
 
 def run_case(tag):

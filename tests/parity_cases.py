@@ -696,16 +696,10 @@ def attack100_compare(tag, name, mine, g, eps, log=None, early_rtol=2e-3):
     return st64
 
 
-def check_attack100(dev, tag='c1', log=None, precision='fp32'):
-    """A WHOLE view-specific attack, free-running, against the reference's own runs of it (tests/golden/attack100_<tag>.npz):
-    eval_adv.py:781-843 (100 Adam-ascent iterations on the RandomState(234) pixel stream) -> :863-886 (render of the attacked
-    sources) -> PSNR.  Compared: loss trajectory, final perturbation (mean distance in units of eps, sign agreement, share of
-    entries at +-eps), attacked image, PSNR -- each bounded by twice the reference's own float32-vs-float64 distance."""
-    from fixtures import ATTACK100, attack100_inputs
-    g = Golden('attack100_' + tag)
-    c = ATTACK100[tag]
+def attack100_setup(c, dev, precision='fp32'):
+    """(data, model, args, delta0) of a whole-attack case of tests/fixtures.ATTACK100, every input regenerated from its seeds"""
+    from fixtures import attack100_inputs
     data, cnn_sd, p_coarse, p_fine, delta0 = attack100_inputs(c)
-    eps = c['epsilon'] / 255.0
     feature_net = ResUNet(coarse_out_ch=32, fine_out_ch=32)
     feature_net.load_state_dict(cnn_sd, strict=True)
     for p in feature_net.parameters():
@@ -720,6 +714,66 @@ def check_attack100(dev, tag='c1', log=None, precision='fp32'):
                            inv_uniform=True, det=True, white_bkgd=False, epsilon=c['epsilon'], adv_lr=c.get('adv_lr', 2), use_adam=mode != 'sign',
                            adam_lr=c['adam_lr'], lr_step_size=c['lr_step_size'], lr_gamma=c['lr_gamma'], adv_iters=c['adv_iters'],
                            chunk_size=c['chunk_size'])
+    return data, model, args, delta0
+
+
+def check_attack_steps_late(dev, iters=None):
+    """Teacher-forced PGD steps LATE in the trajectory (tests/golden/attack100_c1_late.npz: the reference's own float32 run of case c1,
+    state around iterations 50 and 99 -- ~6 % of the perturbation on +-eps, the [0,1] box clamp active, Adam's second moment ~1e-8,
+    bias corrections far from their start values): from the reference's delta_t the HIP path must reproduce the loss and the gradient
+    (float64 oracle on the evaluation's ReLU pattern, 1e-3); from the reference's gradient and moments the fused update must reproduce
+    delta_t+1 (2e-7) and both moments (1e-5) -- the same bars as check_attack_steps at iterations 0-2."""
+    from fixtures import ATTACK100
+    g = Golden('attack100_c1_late')
+    c = ATTACK100['c1']
+    data, model, args, _ = attack100_setup(c, dev)
+    eps = c['epsilon'] / 255.0
+    sampler = RaySamplerSingleImage(data, dev)
+    src = sampler.get_all()
+    cfg64 = dict(N_samples=args.N_samples, N_importance=args.N_importance, inv_uniform=True, white_bkgd=False)
+    for t in ([int(x) for x in g.np('iters')] if iters is None else iters):
+        k = lambda name: g.t('t%d/%s' % (t, name), dev)
+        delta_t, picks = k('delta'), g.np('t%d/picks' % t)
+        on_eps = float((delta_t.abs() >= eps * (1 - 1e-6)).float().mean())
+        assert on_eps > 0.03, 'the checkpoint is supposed to sit late in the trajectory (%.4f of delta on +-eps)' % on_eps
+        a = EA.PGDAttack(args, model, Projector(dev), src, delta=delta_t.clone().requires_grad_(True), graph=False)
+        a.exp_avg.copy_(k('exp_avg'))
+        a.exp_avg_sq.copy_(k('exp_avg_sq'))
+        a.iters = int(g.np('t%d/adam_step_before' % t))
+        assert a.iters == t and abs(a.lr() - float(g.np('t%d/lr' % t))) < 1e-12
+        grad = a.gradient(data, select_inds=picks, lookahead=False)
+        ref_grad = g.np('t%d/grad' % t)
+        assert_close(a.last_loss, g.np('t%d/loss' % t), 1e-3, 1e-6, 'attack loss, iter %d' % t)
+        gerr = float(np.linalg.norm(grad.cpu().numpy() - ref_grad) / np.linalg.norm(ref_grad))
+        print('[grad parity] attack100 c1 iter %d: rel-L2 vs the reference fp32 gradient %.3e' % (t, gerr))
+        if _fused_cnn():
+            delta_gradient_float64_check(model, data, delta_t, picks, cfg64,
+                                         lambda: a.gradient(data, select_inds=picks, lookahead=False), 'attack100 c1 iter %d' % t)
+        else:
+            assert gerr < 2e-3, 'd loss / d delta, iter %d: relative L2 error %.3e' % (t, gerr)
+        a.apply(g.t('t%d/grad' % t, dev))                 # the reference's gradient
+        want = k('delta_next')
+        assert_close(a.delta.data, want, 0, 2e-7, 'delta after the fused Adam step %d' % (t + 1))
+        # the clamps did something at this point of the trajectory, and the kernel did the same thing
+        at_eps = (want.abs() >= eps * (1 - 1e-6))
+        assert float(at_eps.float().mean()) > 0.03 and torch.equal(a.delta.data.abs() >= eps * (1 - 1e-6), at_eps)
+        m_ref, v_ref = g.np('t%d/exp_avg_next' % t), g.np('t%d/exp_avg_sq_next' % t)
+        assert_close(a.exp_avg.reshape(-1)[::4], m_ref, 1e-5, 1e-6 * float(np.abs(m_ref).max()), 'exp_avg')
+        assert_close(a.exp_avg_sq.reshape(-1)[::4], v_ref, 1e-5, 1e-6 * float(np.abs(v_ref).max()), 'exp_avg_sq')
+
+
+def check_attack100(dev, tag='c1', log=None, precision='fp32'):
+    """A WHOLE view-specific attack, free-running, against the reference's own runs of it (tests/golden/attack100_<tag>.npz):
+    eval_adv.py:781-843 (100 Adam-ascent iterations on the RandomState(234) pixel stream) -> :863-886 (render of the attacked
+    sources) -> PSNR.  Compared: loss trajectory, final perturbation (mean distance in units of eps, sign agreement, share of
+    entries at +-eps), attacked image, PSNR -- each bounded by twice the reference's own float32-vs-float64 distance."""
+    from fixtures import ATTACK100
+    g = Golden('attack100_' + tag)
+    c = ATTACK100[tag]
+    data, model, args, delta0 = attack100_setup(c, dev, precision)
+    eps = c['epsilon'] / 255.0
+    mode = c.get('mode', 'adam')
+    stride = c.get('render_stride', 1)
     sampler = RaySamplerSingleImage(data, dev)
     src = sampler.get_all()
     product_sample_ray.rng.seed(234)
@@ -748,11 +802,13 @@ def check_attack100(dev, tag='c1', log=None, precision='fp32'):
     assert float(x.min()) >= -1e-6 and float(x.max()) <= 1 + 1e-6
     with torch.no_grad():
         featmaps = model.feature_net(x.squeeze(0).permute(0, 3, 1, 2))
-        ret = render_single_image(ray_sampler=sampler, ray_batch=sampler.get_all(), model=model, projector=Projector(dev),
+        # (c2full: every 4th pixel through render_stride, like the reference's capture)
+        render_sampler = sampler if stride == 1 else RaySamplerSingleImage(data, dev, render_stride=stride)
+        ret = render_single_image(ray_sampler=render_sampler, ray_batch=render_sampler.get_all(), model=model, projector=Projector(dev),
                                   chunk_size=c['chunk_size'], det=True, N_samples=c['S'], inv_uniform=True, N_importance=c['N_imp'],
-                                  white_bkgd=False, featmaps=featmaps, args=None, src_ray_batch=src)
+                                  white_bkgd=False, render_stride=stride, featmaps=featmaps, args=None, src_ray_batch=src)
     image = ret['outputs_fine']['rgb'].double().numpy()
-    gt = data['rgb'][0].double().numpy()
+    gt = data['rgb'][0].double().numpy()[::stride, ::stride]
     mine = dict(losses=losses, delta=d.cpu().double().numpy().reshape(-1)[::c['delta_stride']], image=image,
                 psnr=float(-10. * np.log10(np.mean((image - gt) ** 2))))
     return attack100_compare(tag, 'HIP path' + (' (bf16 row network)' if precision == 'bf16' else ''), mine, g, eps, log,

@@ -115,6 +115,12 @@ def test_attack_steps():
         pc.check_attack_steps('cpu', free_steps=2)
 
 
+def test_attack_step_late_in_the_trajectory():
+    """the reference's state at iteration 99 of a 100-iteration attack (clamps active): loss, gradient, fused update"""
+    with fast_paths():
+        pc.check_attack_steps_late('cpu', iters=[99])
+
+
 def test_attack_step_on_the_product_dispatch():
     """one teacher-forced PGD step through exactly what runs on the GPU -- fused CNN executor, matrix-core IBRNet kernels with
     the scatter fused into the backward -- with the float64 check on the ReLU pattern of this evaluation"""

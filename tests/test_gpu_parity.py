@@ -135,6 +135,10 @@ def test_attack_steps():
     pc.check_attack_steps('cuda')
 
 
+def test_attack_steps_late_in_the_trajectory():
+    pc.check_attack_steps_late('cuda')
+
+
 @pytest.mark.parametrize('case', ['tiny', 'medium'])
 def test_delta_gradient_vs_float64(case):
     pc.check_delta_gradient_vs_float64(case, 'cuda')
@@ -555,3 +559,92 @@ def test_rccl_collectives_on_a_one_rank_group(tmp_path):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29617', RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'RCCL world-1 collectives OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+SHARDED_GRAPH_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import torch
+import torch.distributed as dist
+from types import SimpleNamespace
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+rank, world, backend = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), os.environ['BACKEND']
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+if backend == 'nccl':
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)          # 'nccl' IS RCCL on ROCm
+else:
+    dist.init_process_group('gloo', rank=rank, world_size=world)                          # several ranks on ONE GPU: functional only
+import parity_cases as pc
+from nerfool_amd import eval_adv as EA, ops
+from nerfool_amd.ibrnet import sample_ray
+from nerfool_amd.ibrnet.projection import Projector
+ops.GATHER_BWD = 'deterministic'            # sorted scatter: a step is bitwise reproducible
+g, args, model, data, sampler, dims = pc._attack_setup('cuda')
+src = sampler.get_all()
+d0 = g.t('in/delta0', 'cuda')
+for views, split, use_adam in ((False, False, True), (True, False, True), (True, True, False), (False, True, False)):
+    a = SimpleNamespace(**dict(vars(args), use_adam=use_adam))
+    runs = []
+    for graph in (None, False):
+        sample_ray.rng.seed(234)
+        sh = EA.RayShard(shard_views=views, split_n_rand=split, exchange_when_alone=True)
+        atk = EA.PGDAttack(a, model, Projector('cuda'), src, shard=sh, delta=d0.clone().requires_grad_(True), graph=graph)
+        losses = [float(atk.step(data)) for _ in range(6)]
+        runs.append((atk, sh, losses, sample_ray.rng.get_state()[2]))
+    (ga, gs, gl, gpos), (ea, es, el, epos) = runs
+    per_step = 4 if views else 2
+    assert ga.graph_replays == 4 and ea.graph_replays == 0, (ga.graph_replays, ea.graph_replays)
+    seg = list(ga._graphs.values())[0][0]
+    assert len(seg.graphs) == per_step + 1 and len(seg.collectives) == per_step, (len(seg.graphs), len(seg.collectives))
+    assert gs.collectives == es.collectives == 6 * per_step, (gs.collectives, es.collectives)
+    assert gs.bytes == es.bytes
+    assert ga.iters == ea.iters == 6 and gpos == epos
+    assert gl == el, ('losses', views, split, gl, el)
+    assert torch.equal(ga.delta.data, ea.delta.data), 'delta: segmented graph replay vs eager launches (views=%%s)' %% views
+    if use_adam:
+        assert torch.equal(ga.exp_avg, ea.exp_avg) and torch.equal(ga.exp_avg_sq, ea.exp_avg_sq)
+    # every rank holds the same perturbation (identical deterministic update of the all-reduced gradient)
+    ref = ga.delta.data.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(ref, ga.delta.data), 'delta differs between the ranks'
+    print('rank %%d: views=%%s split=%%s adam=%%s: %%d segments, losses %%s' %% (rank, views, split, use_adam, len(seg.graphs), gl[-2:]), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+print('SHARDED GRAPH OK rank %%d' %% rank)
+"""
+
+
+def _run_sharded_graph_worker(tmp_path, world, backend, port):
+    import subprocess
+    import sys
+    script = tmp_path / 'sharded_graph_worker.py'
+    script.write_text(SHARDED_GRAPH_WORKER % dict(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), BACKEND=backend,
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900))
+    finally:
+        for p in procs:         # exact PIDs
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and 'SHARDED GRAPH OK rank %d' % r in out, 'rank %d:\n%s\n%s' % (r, out[-2000:], err[-4000:])
+
+
+def test_sharded_step_as_graph_segments_rccl_one_rank(tmp_path):
+    """A SHARDED PGD step replayed as hipGraph segments split at its collectives (eval_adv._SegmentedCapture) against the same step
+    enqueued launch by launch, on the RCCL backend (one-rank group: all a single-GPU box allows; `exchange_when_alone` makes the
+    view-sharded flow issue its four collectives anyway): perturbation, Adam moments and losses bit-identical after six steps (two
+    eager warm-ups, the capture, four replays), 3 segments around 2 collectives (replicated CNN) / 5 around 4 (CNN sharded by view)."""
+    _run_sharded_graph_worker(tmp_path, 1, 'nccl', 29631)
+
+
+def test_sharded_step_as_graph_segments_two_ranks_on_one_gpu(tmp_path):
+    """The same with TWO ranks exchanging real data (gloo: RCCL refuses two ranks on one device) on the one GPU of the box: segmented
+    replay == eager step on both ranks, and both ranks end with the same perturbation."""
+    _run_sharded_graph_worker(tmp_path, 2, 'gloo', 29633)
