@@ -120,6 +120,8 @@ def parse():
                     help="operand form of the 3x3 convolutions' Winograd products: 'bf16x3' (default of the package: every fp32 operand as "
                          "three bf16 parts on the bf16 matrix cores, six cross terms, error at fp32 rounding level) or 'fp32' "
                          "(v_mfma_f32_32x32x2_f32, the form of rounds 1-3)")
+    ap.add_argument('--universal-views', type=int, default=8,
+                    help='target views of the universal-loop leg (extra.universal: BASELINE config 3 on this many GPUs; 0 = skip)')
     ap.add_argument('--device', choices=('gpu', 'cpu-standin'), default='gpu',
                     help="'cpu-standin': FUNCTIONAL check of the launcher / sharding on a box without a GPU -- the kernels' CPU stand-in "
                          "build (tests/host_harness), gloo, shape-generic kernels; tiny sizes only, never a measurement")
@@ -246,9 +248,10 @@ def prime(attack, data):
     """untimed preparation in front of the W warm-up steps of a timed region: a fresh PGDAttack captures its step into a hipGraph on its
     third step on a target view (two eager steps, capture, replay) -- without this the capture would fall inside a timed region
     whose warm-up is shorter than three steps"""
-    if getattr(attack, 'use_graph', False):
+    if getattr(attack, 'use_graph', False) and not getattr(attack, '_bench_primed', False):
         for _ in range(3):
             attack.step(data)
+        attack._bench_primed = True
 
 
 def time_steps(attack, data, steps, warmup, barrier, timer=None, every=1):
@@ -271,6 +274,37 @@ def time_steps(attack, data, steps, warmup, barrier, timer=None, every=1):
             attack.step(data)
     barrier()
     return time.perf_counter() - t0
+
+
+def universal_leg(a, EA, make_attack, data, dev, barrier, max_over_ranks, world):
+    """BASELINE config 3's loop on this many GPUs: PGDAttack.run_universal (eval_adv.py:634-740) cycling over `universal_views`
+    synthetic TARGET views of the scene, one shared perturbation on the source views.  Each target view gets its own cached sampler
+    and its own captured step (graph segments when sharded); reported: the time of the first cycles (two eager steps + the capture per
+    view), ms/step once every view replays, and the allocator's peak."""
+    from nerfool_amd.synthetic import target_views
+    views = target_views(data, a.universal_views)
+    uni = make_attack(a.cnn_shard, a.scaling)
+    torch.cuda.reset_peak_memory_stats(dev)
+    barrier()
+    t0 = time.perf_counter()
+    uni.run_universal(views, n_iters=3 * len(views) - 1)          # three cycles: eager, eager, capture + replay
+    barrier()
+    t_capture = max_over_ranks(time.perf_counter() - t0)
+    replays0 = uni.graph_replays
+    n = 4 * len(views)
+    barrier()
+    t0 = time.perf_counter()
+    uni.run_universal(views, n_iters=n - 1)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    rays = a.n_rand * (world if a.scaling == 'weak' else 1)
+    out = {'target_views': len(views), 'ms_per_step': round(1e3 * dt / n, 4), 'rays_per_s': rays * n / dt, 'steps_timed': n,
+           'graphs_captured': len(uni._graphs), 'replayed_steps_in_timed_region': uni.graph_replays - replays0,
+           'first_three_cycles_s': round(t_capture, 3), 'hbm_peak_allocated_gb': round(torch.cuda.max_memory_allocated(dev) / 1e9, 3),
+           'final_loss': float(uni.last_loss), 'n_gpus': world,
+           'note': 'one cached sampler (rays + target image) and one captured step per target view, all in one activation pool'}
+    del uni
+    return out
 
 
 def render_leg(model, projector, sampler, src_ray_batch, featmaps, n_chunks, samples, importance, gnt, prof, par=None):
@@ -487,7 +521,21 @@ def main():
             return float(t)
         return seconds
 
+    def host_issue(atk):
+        """host time to ENQUEUE a step (no synchronisation inside the bracket; 3 steps stay below the queue depth): the step is
+        launch-bound when this approaches ms_per_step.  Sharded steps: segments + collectives as the step issues them."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            atk.step(data)
+        ms = 1e3 * (time.perf_counter() - t0) / 3
+        barrier()
+        return ms
+
     attack = make_attack(a.cnn_shard, a.scaling)
+    if attack.shard is not None:
+        prime(attack, data)                 # (so that the collective counters below cover warm-up + timed steps only)
+        c0, b0 = attack.shard.collectives, attack.shard.bytes
     # HIP events only around the kernels the roofline table prices (~10 of the ~250 launches of a step): bracketing every
     # launch costs ~1.5 ms of host time per step, which is visible now that the step is close to launch-bound
     timer = None if standin else prof.KernelTimer(only=ROOFLINE_KERNELS)
@@ -498,21 +546,14 @@ def main():
     rays_per_step = a.n_rand * (world if a.scaling == 'weak' else 1)
     collectives_per_step = payload_per_step = None
     if attack.shard is not None:
-        collectives_per_step = attack.shard.collectives / float(a.steps + a.warmup)
-        payload_per_step = attack.shard.bytes / float(a.steps + a.warmup)
+        collectives_per_step = (attack.shard.collectives - c0) / float(a.steps + a.warmup)
+        payload_per_step = (attack.shard.bytes - b0) / float(a.steps + a.warmup)
 
     hand_written_ms = None
     multi = None
     host_issue_ms = None
     if not standin:
-        # host time to ENQUEUE a step (no synchronisation inside the bracket; 3 steps = ~550 launches stay below the queue depth):
-        # the step is launch-bound when this approaches ms_per_step
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            attack.step(data)
-        host_issue_ms = 1e3 * (time.perf_counter() - t0) / 3
-        barrier()
+        host_issue_ms = host_issue(attack)
     if a.extras:
         # every hand-written launch, timed over two extra steps OUTSIDE the timed region (extra.hand_written_kernel_ms_per_step)
         all_timer = prof.KernelTimer()
@@ -530,16 +571,22 @@ def main():
             if (cnn_shard, scaling) == (a.cnn_shard, a.scaling):
                 ms, rays = 1e3 * elapsed / a.steps, rays_per_step
                 coll, payload = collectives_per_step, payload_per_step
+                issue, segs = host_issue_ms, [len(v[0].graphs) for v in attack._graphs.values()]
             else:
                 other = make_attack(cnn_shard, scaling)
+                prime(other, data)
+                c1, b1 = other.shard.collectives, other.shard.bytes
                 n = max(5, a.steps // 2)
                 ms = 1e3 * max_over_ranks(time_steps(other, data, n, 2, barrier)) / n
                 rays = a.n_rand * (world if scaling == 'weak' else 1)
-                coll, payload = other.shard.collectives / float(n + 2), other.shard.bytes / float(n + 2)
+                coll, payload = (other.shard.collectives - c1) / float(n + 2), (other.shard.bytes - b1) / float(n + 2)
+                issue, segs = host_issue(other), [len(v[0].graphs) for v in other._graphs.values()]
                 del other
             multi['forms']['%s/%s' % (cnn_shard, scaling)] = {
                 'ms_per_step': round(ms, 4), 'rays_per_step_all_ranks': rays, 'rays_per_s': rays / (ms * 1e-3),
-                'collectives_per_step': coll, 'collective_payload_bytes_per_step': payload}
+                'collectives_per_step': coll, 'collective_payload_bytes_per_step': payload,
+                # the step is replayed as hipGraph segments split at its collectives (eval_adv._SegmentedCapture)
+                'host_issue_ms_per_step': round(issue, 4), 'graph_segments_per_step': segs[0] if segs else None}
         for cnn_shard in ('view', 'replicated'):
             multi['exchange_ms_per_step_isolated_' + cnn_shard] = round(max_over_ranks(
                 exchange_microbench(attack.shard, a.views, C, Hf, Wf, a.height, a.width, dev, cnn_shard == 'view') * 1e-3) * 1e3, 4)
@@ -578,6 +625,19 @@ def main():
         ms = 1e3 * time_steps(big, data, n, 2, barrier) / n
         extra_legs['attack_n_rand_4096'] = {'ms_per_step': round(ms, 4), 'rays_per_s': 4096 / (ms * 1e-3)}
         del big
+    if a.extras and world == 1 and a.model == 'ibrnet' and a.config == 'c2' and a.conv_operands == 'bf16x3':
+        # the same step with the backward-data convolutions on THREE operand parts like the forward (the timed headline runs them on two:
+        # config.conv_operands_bwd)
+        saved_bwd, feature_network.WINO_BWD_OPERANDS = feature_network.WINO_BWD_OPERANDS, 'bf16x3'
+        try:
+            x3 = make_attack(a.cnn_shard, a.scaling)
+            n = max(5, a.steps // 2)
+            extra_legs['step_ms_all_bf16x3'] = round(1e3 * time_steps(x3, data, n, 2, barrier) / n, 4)
+            del x3
+        finally:
+            feature_network.WINO_BWD_OPERANDS = saved_bwd
+    if a.extras and a.universal_views > 0 and a.model == 'ibrnet' and a.config == 'c2':
+        extra_legs['universal'] = universal_leg(a, EA, make_attack, data, dev, barrier, max_over_ranks, world)
     if a.extras and a.model == 'ibrnet' and a.config == 'c2':
         # the whole 756x1008 image through render_single_image: 187 chunks of 4096 rays, outputs moved to the host (D2H) and
         # reshaped as the reference does (render_image.py:52-102).  N > 1: the chunks are dealt to the ranks as contiguous blocks
@@ -616,7 +676,13 @@ def main():
             # enqueue a chunk's first launches while the GPU idles) -- 8 chunks read 12 % low
             r = render_leg(model8, projector8, sampler8, src8, fm8, 32, 64, imp, False, prof, par)
             fl = ibrnet_flops(1, 64, a.views) + (ibrnet_flops(1, 64 + imp, a.views) if imp else 0)
-            r['mfma_frac_of_peak'] = round(r['rays_per_s_per_gpu'] * fl / 1e12 / PEAK_F32_TFLOPS, 4)
+            # priced like extra.kernels: the row network of this leg (k_ibr_sol_fwd) issues its products on the bf16 matrix pipe with
+            # every fp32 operand in three parts -- executed bf16 FLOPs <= 6 x the algorithmic FLOPs (upper bound: the view-invariant
+            # part of base_fc.0 is multiplied once per sample, the per-ray attention runs in fp32), against the dense bf16 peak
+            tf = r['rays_per_s_per_gpu'] * fl / 1e12
+            r['mfma_frac_of_peak'] = round(6.0 * tf / PEAK_BF16_TFLOPS, 4)
+            r['mfma_peak'] = 'dense bf16 matrix peak %.0f TFLOP/s; achieved = 6 x algorithmic FLOPs (upper bound on the executed bf16 products), whole leg incl. per-ray kernels' % PEAK_BF16_TFLOPS
+            r['product_frac_of_fp32_peak'] = round(tf / PEAK_F32_TFLOPS, 4)
             extra_legs[tag] = r
         del model8, fm8, sampler8, src8, data8
 
@@ -756,6 +822,9 @@ def main():
         'dtype': 'bf16' if (a.precision == 'bf16') else 'f32', 'data': 'synthetic',
         'device': 'MI355X (gfx950)' if not standin else 'cpu-standin: FUNCTIONAL check of the launcher / sharding, not a measurement',
         'config': {'workload': workload, 'conv_operands': a.conv_operands,
+                   # operand form of the 27 backward-data Winograd launches of a step (round 5: two bf16 parts per operand, three products;
+                   # the all-bf16x3 step is timed beside it: extra.step_ms_all_bf16x3)
+                   'conv_operands_bwd': (feature_network.WINO_BWD_OPERANDS if a.conv_operands == 'bf16x3' else a.conv_operands),
                    'rays_per_step_all_ranks': rays_per_step, 'parallelism': par,
                    'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step},
         'roofline': roofline,

@@ -91,3 +91,23 @@ def smooth_featmaps(V, C, Hf, Wf, seed=0, amp=1.0):
     base = torch.randn(V, C, h0, w0, generator=gen)
     fm = torch.nn.functional.interpolate(base, size=(Hf, Wf), mode='bilinear', align_corners=True)
     return (amp * (fm + 0.1 * torch.randn(V, C, Hf, Wf, generator=gen))).contiguous()
+
+
+def target_views(data, n, seed=100, radius=0.15):
+    """n TARGET views of one scene for the universal loop (eval_adv.py:634-740 cycles over a scene's training views while the
+    perturbation lives on the shared source views): `data` itself, then copies whose target camera is moved on a small circle around it
+    (camera-to-world translation, scene units) with their own smooth target images."""
+    views = [data]
+    for i in range(1, n):
+        ang = 2.0 * math.pi * i / max(n - 1, 1)
+        cam = data['camera'].clone()
+        c2w = cam[0, 18:34].reshape(4, 4).clone()
+        c2w[:3, 3] += torch.tensor([radius * math.cos(ang), radius * math.sin(ang), 0.02 * i], dtype=cam.dtype)
+        cam[0, 18:34] = c2w.reshape(-1)
+        H, W = int(cam[0, 0]), int(cam[0, 1])
+        v = dict(data)
+        v['camera'] = cam
+        v['rgb'] = _smooth_image(torch.Generator().manual_seed(seed + i), H, W)[None]
+        v['rgb_path'] = ['synthetic_target_%d' % i]
+        views.append(v)
+    return views

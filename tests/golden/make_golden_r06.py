@@ -11,7 +11,11 @@ make_golden_r05.reference_attack (eval/ibrnet/eval_adv.py:781-843 -> :863-886 ->
           is active, Adam's second moment is tiny): delta_t, both moments before the step, the picks, the reference's gradient and loss,
           delta_t+1 and both moments after -> attack100_c1_late.npz
 
-    python tests/golden/make_golden_r06.py late c2full
+  center  `sample_mode='center'` pixel picks of the reference's sampler (ibrnet/sample_ray.py:132-152) on the attack_tiny scene
+          (48 x 64) and on a non-square 30 x 52 frame, centre ratios 0.8 / 0.5, three consecutive draws from the RandomState(234)
+          stream each, and the rays random_sample returns for the first draw -> sampler_center.npz
+
+    python tests/golden/make_golden_r06.py center late c2full
 
 Runs only in the build container (late: ~2 min; c2full: several hours on 6 of 8 cores)."""
 import itertools
@@ -60,6 +64,33 @@ def run_late():
     path = os.path.join(HERE, 'attack100_c1_late.npz')
     np.savez_compressed(path, **out)
     print('%s %.1f KB  (%.0f s)' % (path, os.path.getsize(path) / 1024., time.time() - t0), flush=True)
+
+
+def run_center():
+    import make_golden as mg
+    from nerfool_amd.synthetic import make_scene
+    tiny = np.load(os.path.join(HERE, 'attack_tiny.npz'))
+    data_tiny = {k: torch.from_numpy(tiny['in/' + k]) for k in ('rgb', 'camera', 'src_rgbs', 'src_cameras', 'depth_range')}
+    data_tiny['rgb_path'] = ['golden']
+    out = {}
+    for tag, data, n_rand in (('tiny', data_tiny, 64), ('odd', make_scene(30, 52, 2, seed=3), 40)):
+        smp = mg.ref_sample_ray.RaySamplerSingleImage(data, 'cpu')
+        for ratio in (0.8, 0.5):
+            mg.reset_pixel_rng()
+            picks = np.stack([smp.sample_random_pixel(n_rand, 'center', ratio) for _ in range(3)])
+            out['%s/r%02d/picks' % (tag, int(ratio * 10))] = picks.astype(np.int64)
+            # the stream position after the draws: the next UNIFORM pick
+            out['%s/r%02d/next_uniform' % (tag, int(ratio * 10))] = smp.sample_random_pixel(n_rand, 'uniform').astype(np.int64)
+            mg.reset_pixel_rng()
+            batch = smp.random_sample(n_rand, 'center', ratio)
+            assert np.array_equal(np.asarray(batch['selected_inds']), picks[0])
+            out['%s/r%02d/ray_d' % (tag, int(ratio * 10))] = batch['ray_d'].numpy()
+            out['%s/r%02d/rgb' % (tag, int(ratio * 10))] = batch['rgb'].numpy()
+            print('center %s ratio %.1f: picks in [%d, %d], H x W = %d x %d' % (tag, ratio, picks.min(), picks.max(), smp.H, smp.W))
+        out[tag + '/n_rand'] = np.array(n_rand)
+    path = os.path.join(HERE, 'sampler_center.npz')
+    np.savez_compressed(path, **out)
+    print('%s %.1f KB' % (path, os.path.getsize(path) / 1024.))
 
 
 RUNS = (('ref32', dict(dtype=torch.float32, use_ea=True)),
@@ -126,5 +157,7 @@ if __name__ == '__main__':
     for what in (sys.argv[1:] or ['late']):
         if what == 'late':
             run_late()
+        elif what == 'center':
+            run_center()
         else:
             run_full(what)

@@ -373,6 +373,23 @@ def check_ray_sampler(dev):
     product_sample_ray.rng.seed(234)
     picks = np.stack([sampler.sample_random_pixel(dims[3], 'uniform') for _ in range(3)])
     assert np.array_equal(picks, g.np('adam/selected_inds')[:3])
+    # sample_mode='center' (ibrnet/sample_ray.py:132-152): the reference's picks on this scene and on a non-square 30 x 52 frame, centre
+    # ratios 0.8 / 0.5, three consecutive draws (with and without the look-ahead thread), the stream position afterwards, the rays
+    from nerfool_amd.synthetic import make_scene
+    gc = Golden('sampler_center')
+    for tag, smp in (('tiny', sampler), ('odd', RaySamplerSingleImage(make_scene(30, 52, 2, seed=3), dev))):
+        n = int(gc.np(tag + '/n_rand'))
+        for ratio in (0.8, 0.5):
+            key = '%s/r%02d/' % (tag, int(ratio * 10))
+            for lookahead in (False, True):
+                product_sample_ray.rng.seed(234)
+                picks = np.stack([smp.sample_random_pixel(n, 'center', ratio, lookahead=lookahead) for _ in range(3)])
+                assert np.array_equal(picks, gc.np(key + 'picks')), (tag, ratio, lookahead)
+                assert np.array_equal(smp.sample_random_pixel(n, 'uniform'), gc.np(key + 'next_uniform'))
+            product_sample_ray.rng.seed(234)
+            batch = smp.random_sample(n, 'center', ratio)
+            assert_close(batch['ray_d'], gc.np(key + 'ray_d'), 1e-5, 1e-5, 'centre-mode ray_d')
+            assert_close(batch['rgb'], gc.np(key + 'rgb'), 0, 1e-7, 'centre-mode rgb')
 
 
 def check_feature_net(dev):
