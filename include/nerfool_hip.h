@@ -387,6 +387,19 @@ int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* 
 int nf_gnt_bwd_mfma(const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples, int n_views,
                     int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream);
 
+/* The matrix-core pair in TRAINING mode (round 6): the Dropout-active network of the reference's universal GNT loop
+ * (eval/gnt/eval_adv.py:739-878, before switch_to_eval at :959; sites gnt/transformer_network.py:45-48, :85-88, :162-166) with the
+ * masks of nf_gnt_fwd_train (same generator, same indices: the two pairs evaluate identical masks for one seed).
+ * seed_dev: optional DEVICE pointer to the seed word -- when non-null the kernels read the seed from it instead of `seed`, so a
+ * hipGraph-captured PGD step takes a fresh seed per replay (the host refreshes the word in stream order before each replay).  The
+ * backward must be given the seed / word of its forward.  Workspace and blob as nf_gnt_fwd_mfma / nf_gnt_bwd_mfma. */
+int nf_gnt_fwd_train_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
+                          const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save, float* rgb,
+                          float* alpha, float* workspace, uint32_t seed, double p, const uint32_t* seed_dev, nf_stream_t stream);
+int nf_gnt_bwd_train_mfma(const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples, int n_views,
+                          int depth, float* d_rgb_feat, float* workspace, uint32_t seed, double p, const uint32_t* seed_dev,
+                          nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * a14 (glue only)  ResUNet: InstanceNorm + affine + residual + ReLU/ELU + reflect padding fused into one pass over a
  * convolution output, producing the pre-padded input of the next convolution.   ref: ibrnet/feature_network.py:38-78,

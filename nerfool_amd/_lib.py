@@ -74,6 +74,8 @@ _PROTOTYPES = {
     'nf_gnt_mfma_supported': (c_int, [c_int, c_int]),
     'nf_gnt_fwd_mfma': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     'nf_gnt_bwd_mfma': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P]),
+    'nf_gnt_fwd_train_mfma': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, _P, _P, _P, c_uint32, c_double, _P, _P]),
+    'nf_gnt_bwd_train_mfma': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P, c_uint32, c_double, _P, _P]),
     'nf_conv1x1_pack_floats': (c_int64, [c_int, c_int]),
     'nf_conv1x1_pack': (c_int, [_P, c_int, c_int, c_int, _P]),
     'nf_conv1x1': (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int, c_int,

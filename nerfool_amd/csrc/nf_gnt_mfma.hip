@@ -526,10 +526,34 @@ __device__ __forceinline__ float gm_sign_word(const g16& f) {
 }
 __host__ __device__ constexpr int gm_sign_slot(int j) { return (j & 3) + 8 * (j >> 2); }
 
+// ---- TRAINING mode (round 6): the eight Dropout sites of a layer on the matrix-core kernels, masks from the counter-based generator
+//      of nf_gnt.h (gnt_keep: the same masks as k_gnt_fwd / k_gnt_bwd, the oracle and the fixture's reference run).  TRAIN is a template
+//      flag: the eval-mode kernels carry none of it.  Element (t, r) of a fragment-ordered V64 of the lane's sample is channel
+//      32 t + n(r, h) of the [.., 64] tensor the reference hands to nn.Dropout.
+template <bool TRAIN>
+__device__ __forceinline__ float gm_keep(const GntDrop& dr, unsigned site, unsigned long long idx) {
+    return TRAIN ? gnt_keep(dr, site, idx) : 1.f;
+}
+// x .* keep(site, base + channel) over the 64 channels of the lane's sample
+template <bool TRAIN>
+__device__ __forceinline__ V64 gm_drop64(const GntDrop& dr, unsigned site, unsigned long long base, int h, const V64& x) {
+    if (!TRAIN) return x;
+    V64 y;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y.t[t][r] = x.t[t][r] * gnt_keep(dr, site, base + (unsigned)(32 * t + gm_nidx(r, h)));
+    return y;
+}
+
 // feed-forward 64 -> 256 (ReLU) -> 64, hidden tile j chained straight into fc2; returns FF(y) (bias included).
 // jump (nullable): where the stream continues behind this block when that is not the next record in memory.
+// TRAIN: the hidden units pass Dropout site `site` (index smp_idx * 256 + unit); the sign word then marks the units that survived BOTH
+// the ReLU and the Dropout -- what the backward scales by 1 / (1 - p).  (The output's site + 1 is the caller's: gm_drop64.)
+template <bool TRAIN>
 __device__ __forceinline__ V64 gm_ff(const GmCtx& c, GmW& w, const float* __restrict__ b1, const float* __restrict__ b2, int lane,
-                                     const V64& y, bool save, int f_slot, const float* jump) {
+                                     const V64& y, bool save, int f_slot, const float* jump, const GntDrop& dr, unsigned site,
+                                     unsigned long long smp_idx) {
     V64 o;
     o.t[0] = gm_tile(b2, c.h);
     o.t[1] = gm_tile(b2 + 32, c.h);
@@ -538,7 +562,10 @@ __device__ __forceinline__ V64 gm_ff(const GmCtx& c, GmW& w, const float* __rest
         g16 f = gm_tile_s(w, lane, y, gm_tile(b1 + j * 32, c.h));
         if (j == 7 && jump) w.p = jump;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) f[r] = fmaxf(f[r], 0.f);
+        for (int r = 0; r < 16; ++r) {
+            f[r] = fmaxf(f[r], 0.f);
+            if (TRAIN) f[r] *= gnt_keep(dr, site, smp_idx * 256 + (unsigned)(32 * j + gm_nidx(r, c.h)));
+        }
         if (save) GM_SAVE(gm_smp_at(c, f_slot + gm_sign_slot(j)) + c.smp_lane, gm_sign_word(f));      // the backward needs relu' only
         o.t[0] = gm_take_a(w, lane, f, o.t[0]);
         o.t[1] = gm_take_b(w, lane, f, o.t[1]);
@@ -565,13 +592,15 @@ template <int NW> struct GmLds {
 // SAVE (write what the backward reads) is a template flag, not an argument: inside the view loop the count of stores that follow the
 // next view's loads then is a compile-time fact, and the wait in front of the loop's back edge is vmcnt(32) instead of a vmcnt(0) that
 // sits out the acknowledgements of the stores
-template <int NW, bool SAVE>
+template <int NW, bool SAVE, bool TRAIN>
 __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restrict__ wb, const float* __restrict__ rgb_feat_all,
                                                           const float* __restrict__ ray_diff_all, const float* __restrict__ mask_all,
                                                           const float* __restrict__ pts, const float* __restrict__ ray_d, int V,
                                                           int depth, float* __restrict__ rgb_out, float* __restrict__ ws,
-                                                          int64_t row_floats, int64_t smp_floats, float* __restrict__ alpha_out) {
+                                                          int64_t row_floats, int64_t smp_floats, float* __restrict__ alpha_out,
+                                                          GntDrop dr, const unsigned* __restrict__ seed_dev, int64_t ray0) {
     HIP_DYNAMIC_SHARED(float, lds)
+    if (TRAIN && seed_dev) dr.seed = *seed_dev;         // (a captured step reads its seed from a device word: a replay must not freeze it)
     constexpr int S = 32 * NW;
     float* tab = lds;
     float* Kl = lds + GM_TAB_FLOATS;
@@ -594,6 +623,8 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
     const float* ray_diff = ray_diff_all + ray * S * V * 4;
     const float* mask = mask_all + ray * S * V;
     constexpr bool sv = SAVE;
+    const unsigned long long gray = (unsigned long long)(ray0 + ray);          // the ray's index in the call's tensors (Dropout indices)
+    const unsigned long long smp_idx = gray * S + (unsigned)c.s;
 
     // ---- stem: X_v = W2 relu(W1 rgb_feat_v + b1) + b2 (kept in the workspace), q = max over the views (first maximum wins)
     V64 cur, amax;
@@ -758,8 +789,9 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                             if (sv) GM_SAVE(gm_row_at(c, lr + RWL_PROB + 32 * t + gm_nidx(r, 0), v) + c.row_lane, lg);
                             const float mn = fmaxf(mx.t[t][r], lg);
                             const float sc = __expf(mx.t[t][r] - mn), p = __expf(lg - mn);
-                            sum.t[t][r] = sum.t[t][r] * sc + p;
-                            acc.t[t][r] = acc.t[t][r] * sc + p * vpq[e];
+                            sum.t[t][r] = sum.t[t][r] * sc + p;         // (the softmax normalises BEFORE Dropout site 0, :85)
+                            const float pk = p * gm_keep<TRAIN>(dr, 8 * i + 0, (smp_idx * V + v) * 64 + (unsigned)(32 * t + gm_nidx(r, h)));
+                            acc.t[t][r] = acc.t[t][r] * sc + pk * vpq[e];
                             mx.t[t][r] = mn;
                         }
                     }
@@ -780,12 +812,14 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                 gm_save_smp(c, ls + SL_RS, sum);
             }
             if (sv) gm_save_smp(c, ls + SL_U, u);
-            const V64 o = gm_lin64_s(w, tb + MB_VOUT, lane, h, u);
+            const V64 o = gm_drop64<TRAIN>(dr, 8 * i + 1, smp_idx * 64, h, gm_lin64_s(w, tb + MB_VOUT, lane, h, u));      // :88
             cur = gm_load_smp(c, SW_CUR);
 #pragma unroll
             for (int t = 0; t < 2; ++t) cur.t[t] += o.t[t];
             y = gm_layernorm(c, cur, tb + MB_LN + 128, tb + MB_LN + 192, 1e-6f, sv, ls + SL_XH2, ls + SL_RSTD2);
-            const V64 f = gm_ff(c, w, tb + MB_VFF1, tb + MB_VFF2, lane, y, sv, ls + SL_F, (i & 1) ? Lst + ST_RQ * 64 : nullptr);
+            const V64 f = gm_drop64<TRAIN>(dr, 8 * i + 3, smp_idx * 64, h,
+                                           gm_ff<TRAIN>(c, w, tb + MB_VFF1, tb + MB_VFF2, lane, y, sv, ls + SL_F,
+                                                        (i & 1) ? Lst + ST_RQ * 64 : nullptr, dr, 8 * i + 2, smp_idx));
 #pragma unroll
             for (int t = 0; t < 2; ++t) cur.t[t] += f.t[t];
         }
@@ -865,7 +899,14 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
                         l += sc[kt][r];
                     }
                 l = gm_half_sum(l);
-                // ret_alpha: attention row of sample 0 in the LAST ray transformer, averaged over the heads; the lanes of
+                if (TRAIN) {        // Dropout site 4 on the normalised probabilities [R, 4, S, S] (:162): query = own sample, key = row
+                    const unsigned long long arow = ((gray * 4 + (unsigned)hd) * S + (unsigned)c.s) * S;
+#pragma unroll
+                    for (int kt = 0; kt < NW; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[kt][r] *= gnt_keep(dr, 8 * i + 4, arow + (unsigned)(32 * kt + gm_nidx(r, h)));
+                }
+                // ret_alpha (the DROPPED attention in training mode, :162-169): attention row of sample 0 in the LAST ray transformer, averaged over the heads; the lanes of
                 // query 0 (wave 0, m == 0) hold it -- keys 32 kt + n(r, h) -- and accumulate straight into the output
                 if (alpha_out && i == depth - 1 && wave == 0 && m == 0) {
 #pragma unroll
@@ -894,11 +935,13 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_fwd_mfma(const float* __restric
             }
             __syncthreads();        // K / V of this layer are dead: the next layer may overwrite the LDS image
             if (sv) gm_save_smp(c, ls + SL_OUTA, att);
-            const V64 o = gm_lin64_s(w, tb + MB_ROUT, lane, h, att);
+            const V64 o = gm_drop64<TRAIN>(dr, 8 * i + 5, smp_idx * 64, h, gm_lin64_s(w, tb + MB_ROUT, lane, h, att));     // :166
 #pragma unroll
             for (int t = 0; t < 2; ++t) cur.t[t] += o.t[t];
             y = gm_layernorm(c, cur, tb + MB_LN + 384, tb + MB_LN + 448, 1e-6f, sv, ls + SL_RXH2, ls + SL_RRSTD2);
-            const V64 f = gm_ff(c, w, tb + MB_RFF1, tb + MB_RFF2, lane, y, sv, ls + SL_F2, next_stream);
+            const V64 f = gm_drop64<TRAIN>(dr, 8 * i + 7, smp_idx * 64, h,
+                                           gm_ff<TRAIN>(c, w, tb + MB_RFF1, tb + MB_RFF2, lane, y, sv, ls + SL_F2, next_stream, dr,
+                                                        8 * i + 6, smp_idx));
 #pragma unroll
             for (int t = 0; t < 2; ++t) cur.t[t] += f.t[t];
         }
@@ -973,7 +1016,8 @@ __device__ __forceinline__ V64 gm_ln_bwd(const GmCtx& c, const V64& dy, const fl
 }
 
 // feed-forward backward: d(FF input y) = W1^T (relu'(F) . W2^T d out); F read from f_slot; stream: 8 x [fc2^T tile j | fc1^T k-tile j]
-__device__ __forceinline__ V64 gm_ff_bwd(const GmCtx& c, GmW& w, int lane, const V64& dout, int f_slot) {
+// scale: 1 (eval) or 1 / (1 - p) (training mode: the sign words mark the units that survived ReLU AND Dropout)
+__device__ __forceinline__ V64 gm_ff_bwd(const GmCtx& c, GmW& w, int lane, const V64& dout, int f_slot, float scale) {
     V64 dy;
     dy.t[0] = dy.t[1] = gm_zero();
     float sg[8];            // relu' of the 8 hidden tiles: one sign word each (gm_sign_word)
@@ -985,7 +1029,7 @@ __device__ __forceinline__ V64 gm_ff_bwd(const GmCtx& c, GmW& w, int lane, const
         g16 df = gm_tile_s(w, lane, dout, gm_zero());
         const unsigned bits = __float_as_uint(sg[j]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) df[r] = (bits >> r) & 1u ? df[r] : 0.f;
+        for (int r = 0; r < 16; ++r) df[r] = (bits >> r) & 1u ? df[r] * scale : 0.f;
         dy.t[0] = gm_take_a(w, lane, df, dy.t[0]);
         dy.t[1] = gm_take_b(w, lane, df, dy.t[1]);
     }
@@ -1000,12 +1044,15 @@ template <int NW> struct GmBwdLds {
     static constexpr int FLOATS = TAB + 4 * REC + 3 * TREC + 3 * SCAL;
 };
 
-template <int NW>
+template <int NW, bool TRAIN>
 __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restrict__ wb, const float* __restrict__ mask_all,
                                                           const float* __restrict__ d_rgb, int V, int depth,
                                                           float* __restrict__ d_rgb_feat, float* __restrict__ ws,
-                                                          int64_t row_floats, int64_t smp_floats) {
+                                                          int64_t row_floats, int64_t smp_floats, GntDrop dr,
+                                                          const unsigned* __restrict__ seed_dev) {
     HIP_DYNAMIC_SHARED(float, lds)
+    if (TRAIN && seed_dev) dr.seed = *seed_dev;         // the seed its forward read (PGDAttack stages one seed per captured forward)
+    const float ff_scale = TRAIN ? dr.scale : 1.f;
     constexpr int S = 32 * NW;
     float* tab = lds;
     float* Kr = lds + GmBwdLds<NW>::TAB;
@@ -1030,6 +1077,7 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
     c.ws_row = ws + ray * per_ray;
     c.ws_smp = c.ws_row + (size_t)S * V * row_floats;
     const float* mask = mask_all + ray * S * V;
+    const unsigned long long gray = (unsigned long long)ray, smp_idx = gray * S + (unsigned)c.s;
 
     // ---- rgb_fc, mean over the samples, final LayerNorm
     V64 dcur;
@@ -1070,14 +1118,14 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
         const int lr = RW_BASE + i * RW_LAYER;
         // ================= ray transformer backward =================
         {
-            const V64 dy = gm_ff_bwd(c, w, lane, dcur, ls + SL_F2);
+            const V64 dy = gm_ff_bwd(c, w, lane, gm_drop64<TRAIN>(dr, 8 * i + 7, smp_idx * 64, h, dcur), ls + SL_F2, ff_scale);
             const V64 dl = gm_ln_bwd(c, dy, ln + 384, ls + SL_RXH2, ls + SL_RRSTD2);
 #pragma unroll
             for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
         }
         V64 dq, dk, dv;
         {
-            const V64 go = gm_lin64_sj(w, lane, dcur, nullptr, nullptr);            // d (attention output)
+            const V64 go = gm_lin64_sj(w, lane, gm_drop64<TRAIN>(dr, 8 * i + 5, smp_idx * 64, h, dcur), nullptr, nullptr);            // d (attention output)
             const int rk = ((m & 3) | ((m >> 3) << 2)), hk = (m >> 2) & 1;          // inverse of n(r, hh) for sample m
 #pragma unroll
             for (int hd = 0; hd < 4; ++hd) {
@@ -1125,7 +1173,9 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float pT = __expf(sT[r] - mxq) * rlq;
-                        sT[r] = pT * (dPT[r] - D);                              // d S^T
+                        // (training mode: O = sum_k keep_qk P_qk v_k, so d P_qk = keep_qk (d O_q . v_k); D = d O_q . O_q as before)
+                        const float kp = gm_keep<TRAIN>(dr, 8 * i + 4, ((gray * 4 + (unsigned)hd) * S + (unsigned)c.s) * S + (unsigned)(32 * kt + gm_nidx(r, h)));
+                        sT[r] = pT * (dPT[r] * kp - D);                         // d S^T
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -1147,8 +1197,9 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
                     for (int r = 0; r < 16; ++r) {
                         const int qi = qt * 32 + gm_nidx(r, h);
                         const float pr = __expf(sc[r] - Ms[qi]) * Ls[qi];
-                        dP[r] = pr * (dP[r] - Ds[qi]);                          // d S
-                        sc[r] = pr;
+                        const float kp = gm_keep<TRAIN>(dr, 8 * i + 4, ((gray * 4 + (unsigned)hd) * S + (unsigned)qi) * S + (unsigned)c.s);
+                        dP[r] = pr * (dP[r] * kp - Ds[qi]);                     // d S
+                        sc[r] = pr * kp;                                        // what multiplied v_k in the forward
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -1187,14 +1238,14 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
         }
         // ================= view transformer backward =================
         {
-            const V64 dy = gm_ff_bwd(c, w, lane, dcur, ls + SL_F);
+            const V64 dy = gm_ff_bwd(c, w, lane, gm_drop64<TRAIN>(dr, 8 * i + 3, smp_idx * 64, h, dcur), ls + SL_F, ff_scale);
             const V64 dl = gm_ln_bwd(c, dy, ln + 128, ls + SL_XH2, ls + SL_RSTD2);
 #pragma unroll
             for (int t = 0; t < 2; ++t) dcur.t[t] += dl.t[t];
         }
         {
-            const V64 du = gm_lin64_sj(w, lane, dcur, nullptr, nullptr);
-            // the view softmax: p_v = exp(logit_v - mx) rs with the forward's running maximum and reciprocal sum; rs is folded
+            const V64 du = gm_lin64_sj(w, lane, gm_drop64<TRAIN>(dr, 8 * i + 1, smp_idx * 64, h, dcur), nullptr, nullptr);
+            // the view softmax (training mode: u = sum_v keep_v p_v (v + pos)_v -- the saved u is that sum, and keep_v multiplies (v + pos)_v below): p_v = exp(logit_v - mx) rs with the forward's running maximum and reciprocal sum; rs is folded
             // into du (dur = rs du), and sum_v p_v (v + pos)_v du = u du with the forward's u = sum_v p_v (v + pos)_v
             V64 dur, sp, dqs;
             // the view's saved activations are fetched one view ahead: issued in front of the LAST GEMM of the previous view (a
@@ -1226,8 +1277,9 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float e = __expf(pr.t[t][r] - mx.t[t][r]);          // (pr holds the logits)
-                        dlg.t[t][r] = mk == 0.f ? 0.f : e * (vp.t[t][r] * dur.t[t][r] - sp.t[t][r]);
-                        dvv.t[t][r] = e * dur.t[t][r];
+                        const float kp = gm_keep<TRAIN>(dr, 8 * i + 0, (smp_idx * V + v) * 64 + (unsigned)(32 * t + gm_nidx(r, h)));
+                        dlg.t[t][r] = mk == 0.f ? 0.f : e * (kp * vp.t[t][r] * dur.t[t][r] - sp.t[t][r]);
+                        dvv.t[t][r] = e * kp * dur.t[t][r];
                     }
                 float hsv[4];
 #pragma unroll
@@ -1309,17 +1361,17 @@ __global__ void __launch_bounds__(64 * NW) k_gnt_bwd_mfma(const float* __restric
 // ---------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, bool TRAIN>
 static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray_diff, const float* mask, const float* pts,
                      const float* ray_d, int64_t n_rays, int V, int depth, int save, float* rgb, float* alpha, float* workspace,
-                     hipStream_t st) {
+                     GntDrop dr, const unsigned* seed_dev, hipStream_t st) {
     constexpr int S = 32 * NW;
     static bool configured_on[NF_MAX_DEVICES] = {};
     bool& configured = configured_on[nf_current_device()];
     const size_t smem = GmLds<NW>::FLOATS * sizeof(float);
     if (!configured && smem > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW, true, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_gnt_fwd_mfma<NW, false, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
             nf_set_error("nf_gnt_fwd_mfma: cannot reserve %zu bytes of LDS", smem);
             return 1;
         }
@@ -1331,16 +1383,32 @@ static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray
     for (int64_t r0 = 0; r0 < n_rays; r0 += step) {
         const int64_t nr = n_rays - r0 < step ? n_rays - r0 : step;
         if (save)
-            hipLaunchKernelGGL((k_gnt_fwd_mfma<NW, true>), dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
+            hipLaunchKernelGGL((k_gnt_fwd_mfma<NW, true, TRAIN>), dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
                                ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, V, depth, rgb + r0 * 3,
-                               workspace + r0 * per_ray, rf, sf, alpha ? alpha + r0 * S : nullptr);
+                               workspace + r0 * per_ray, rf, sf, alpha ? alpha + r0 * S : nullptr, dr, seed_dev, r0);
         else
-            hipLaunchKernelGGL((k_gnt_fwd_mfma<NW, false>), dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
+            hipLaunchKernelGGL((k_gnt_fwd_mfma<NW, false, TRAIN>), dim3((unsigned)nr), dim3(64 * NW), smem, st, mblob, rgb_feat + r0 * S * V * 35,
                                ray_diff + r0 * S * V * 4, mask + r0 * S * V, pts + r0 * S * 3, ray_d + r0 * 3, V, depth, rgb + r0 * 3,
-                               workspace, rf, sf, alpha ? alpha + r0 * S : nullptr);
+                               workspace, rf, sf, alpha ? alpha + r0 * S : nullptr, dr, seed_dev, r0);
         NF_LAUNCH_CHECK("nf_gnt_fwd_mfma");
     }
     return 0;
+}
+
+template <bool TRAIN>
+static int gm_fwd_entry(const char* name, const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
+                        const float* pts, const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save,
+                        float* rgb, float* alpha, float* workspace, GntDrop dr, const unsigned* seed_dev, nf_stream_t stream) {
+    NF_REQUIRE(nf_gnt_mfma_supported(n_samples, n_views) && depth >= 1 && depth <= 16 && n_rays >= 0,
+               "%s: S must be 32, 64, 96 or 128 and 1 <= V <= 64 (got S %d V %d depth %d)", name, n_samples, n_views, depth);
+    if (n_rays == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_samples / 32) {
+        case 1: return gm_launch<1, TRAIN>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, dr, seed_dev, st);
+        case 2: return gm_launch<2, TRAIN>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, dr, seed_dev, st);
+        case 3: return gm_launch<3, TRAIN>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, dr, seed_dev, st);
+        default: return gm_launch<4, TRAIN>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, dr, seed_dev, st);
+    }
 }
 
 /* Same arguments as nf_gnt_fwd (workspace of nf_gnt_workspace_floats, consumed by nf_gnt_bwd_mfma when save != 0); weights in
@@ -1348,48 +1416,68 @@ static int gm_launch(const float* mblob, const float* rgb_feat, const float* ray
 extern "C" int nf_gnt_fwd_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
                                const float* pts, const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save,
                                float* rgb, float* alpha, float* workspace, nf_stream_t stream) {
-    NF_REQUIRE(nf_gnt_mfma_supported(n_samples, n_views) && depth >= 1 && depth <= 16 && n_rays >= 0,
-               "nf_gnt_fwd_mfma: S must be 32, 64, 96 or 128 and 1 <= V <= 64 (got S %d V %d depth %d)", n_samples, n_views, depth);
-    if (n_rays == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    switch (n_samples / 32) {
-        case 1: return gm_launch<1>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, st);
-        case 2: return gm_launch<2>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, st);
-        case 3: return gm_launch<3>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, st);
-        default: return gm_launch<4>(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_views, depth, save, rgb, alpha, workspace, st);
-    }
+    return gm_fwd_entry<false>("nf_gnt_fwd_mfma", mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_samples, n_views, depth, save, rgb,
+                               alpha, workspace, gnt_drop_make(0, 0, 0.0), nullptr, stream);
 }
 
-template <int NW>
+/* nf_gnt_fwd_mfma in TRAINING mode (round 6): the eight Dropout(p) sites of every layer live, the masks of nf_gnt_fwd_train (nf_gnt.h:
+ * gnt_keep).  seed_dev (device pointer, nullable): the seed is read from that word instead of `seed` -- a captured PGD step reads the
+ * seed of each replay from a buffer its host refreshes.  nf_gnt_bwd_train_mfma must be given the same seed / word and p. */
+extern "C" int nf_gnt_fwd_train_mfma(const float* mfma_blob, const float* rgb_feat, const float* ray_diff, const float* mask,
+                                     const float* pts, const float* ray_d, int64_t n_rays, int n_samples, int n_views, int depth, int save,
+                                     float* rgb, float* alpha, float* workspace, uint32_t seed, double p, const uint32_t* seed_dev,
+                                     nf_stream_t stream) {
+    NF_REQUIRE(p >= 0.0 && p < 1.0, "nf_gnt_fwd_train_mfma: dropout rate %g outside [0, 1)", p);
+    return gm_fwd_entry<true>("nf_gnt_fwd_train_mfma", mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, n_rays, n_samples, n_views, depth, save,
+                              rgb, alpha, workspace, gnt_drop_make(1, seed, p), seed_dev, stream);
+}
+
+template <int NW, bool TRAIN>
 static int gm_launch_bwd(const float* mblob, const float* mask, const float* d_rgb, int64_t n_rays, int V, int depth,
-                         float* d_rgb_feat, float* workspace, hipStream_t st) {
+                         float* d_rgb_feat, float* workspace, GntDrop dr, const unsigned* seed_dev, hipStream_t st) {
     static bool configured_on[NF_MAX_DEVICES] = {};
     bool& configured = configured_on[nf_current_device()];
     const size_t smem = GmBwdLds<NW>::FLOATS * sizeof(float);
     if (!configured && smem > 64 * 1024) {
-        if (hipFuncSetAttribute((const void*)k_gnt_bwd_mfma<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_gnt_bwd_mfma<NW, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
             nf_set_error("nf_gnt_bwd_mfma: cannot reserve %zu bytes of LDS", smem);
             return 1;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(k_gnt_bwd_mfma<NW>, dim3((unsigned)n_rays), dim3(64 * NW), smem, st, mblob, mask, d_rgb, V, depth, d_rgb_feat,
-                       workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1));
+    hipLaunchKernelGGL((k_gnt_bwd_mfma<NW, TRAIN>), dim3((unsigned)n_rays), dim3(64 * NW), smem, st, mblob, mask, d_rgb, V, depth, d_rgb_feat,
+                       workspace, gnt_row_floats(depth, 1), gnt_smp_floats(depth, 1), dr, seed_dev);
     NF_LAUNCH_CHECK("nf_gnt_bwd_mfma");
     return 0;
+}
+
+template <bool TRAIN>
+static int gm_bwd_entry(const char* name, const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
+                        int n_views, int depth, float* d_rgb_feat, float* workspace, GntDrop dr, const unsigned* seed_dev, nf_stream_t stream) {
+    NF_REQUIRE(nf_gnt_mfma_supported(n_samples, n_views) && depth >= 1 && depth <= 16 && n_rays >= 0,
+               "%s: S must be 32, 64, 96 or 128 and 1 <= V <= 64 (got S %d V %d depth %d)", name, n_samples, n_views, depth);
+    if (n_rays == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_samples / 32) {
+        case 1: return gm_launch_bwd<1, TRAIN>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, dr, seed_dev, st);
+        case 2: return gm_launch_bwd<2, TRAIN>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, dr, seed_dev, st);
+        case 3: return gm_launch_bwd<3, TRAIN>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, dr, seed_dev, st);
+        default: return gm_launch_bwd<4, TRAIN>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, dr, seed_dev, st);
+    }
 }
 
 /* Same arguments as nf_gnt_bwd; `workspace` is the buffer nf_gnt_fwd_mfma with save != 0 filled (not nf_gnt_fwd's). */
 extern "C" int nf_gnt_bwd_mfma(const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
                                int n_views, int depth, float* d_rgb_feat, float* workspace, nf_stream_t stream) {
-    NF_REQUIRE(nf_gnt_mfma_supported(n_samples, n_views) && depth >= 1 && depth <= 16 && n_rays >= 0,
-               "nf_gnt_bwd_mfma: S must be 32, 64, 96 or 128 and 1 <= V <= 64 (got S %d V %d depth %d)", n_samples, n_views, depth);
-    if (n_rays == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    switch (n_samples / 32) {
-        case 1: return gm_launch_bwd<1>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, st);
-        case 2: return gm_launch_bwd<2>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, st);
-        case 3: return gm_launch_bwd<3>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, st);
-        default: return gm_launch_bwd<4>(mfma_blob, mask, d_rgb, n_rays, n_views, depth, d_rgb_feat, workspace, st);
-    }
+    return gm_bwd_entry<false>("nf_gnt_bwd_mfma", mfma_blob, mask, d_rgb, n_rays, n_samples, n_views, depth, d_rgb_feat, workspace,
+                               gnt_drop_make(0, 0, 0.0), nullptr, stream);
+}
+
+/* backward of nf_gnt_fwd_train_mfma(save = 1, seed / seed_dev, p): regenerates the forward's masks */
+extern "C" int nf_gnt_bwd_train_mfma(const float* mfma_blob, const float* mask, const float* d_rgb, int64_t n_rays, int n_samples,
+                                     int n_views, int depth, float* d_rgb_feat, float* workspace, uint32_t seed, double p,
+                                     const uint32_t* seed_dev, nf_stream_t stream) {
+    NF_REQUIRE(p >= 0.0 && p < 1.0, "nf_gnt_bwd_train_mfma: dropout rate %g outside [0, 1)", p);
+    return gm_bwd_entry<true>("nf_gnt_bwd_train_mfma", mfma_blob, mask, d_rgb, n_rays, n_samples, n_views, depth, d_rgb_feat, workspace,
+                              gnt_drop_make(1, seed, p), seed_dev, stream);
 }

@@ -487,9 +487,25 @@ class PGDAttack:
             return False
         from . import prof
         from .ibrnet import feature_network
-        if getattr(getattr(self.model, 'net_coarse', None), 'training', False) and _is_gnt(self.model):
-            return False        # GNT in training mode: every forward takes a new Dropout seed -- a kernel argument a replay would freeze
+        if self._training_gnt_nets():
+            # GNT in training mode (the reference's universal GNT loop): every forward takes a new Dropout seed.  The matrix-core kernels
+            # read it from a device word the attack refreshes before each replay; the shape-generic pair takes it by value -- a kernel
+            # argument a replay would freeze -- so other shapes step eagerly
+            from .gnt import transformer_network as tn
+            a, V = self.args, self.src['src_rgbs'].shape[1]
+            shapes = [a.N_samples] + ([a.N_samples + a.N_importance] if a.N_importance > 0 else [])
+            if tn.KERNEL_PATH != 'mfma' or not all(ops.gnt_mfma_supported(S, V) for S in shapes):
+                return False
         return prof._active is None and feature_network.TRACE_RELU is None and torch.is_grad_enabled()
+
+    def _training_gnt_nets(self):
+        if not _is_gnt(self.model):
+            return []
+        nets = []
+        for net in (getattr(self.model, 'net_coarse', None), getattr(self.model, 'net_fine', None)):
+            if net is not None and getattr(net, 'training', False) and all(net is not n for n in nets):
+                nets.append(net)
+        return nets
 
     def _graph_step(self, data, lookahead):
         import numpy as np
@@ -517,6 +533,8 @@ class PGDAttack:
                 return self.last_loss
             self._capture(key, data, sampler, len(picks))
         graph, g_idx, g_hyper, g_loss = self._graphs[key][:4]
+        for net, n_seeds in self._graphs[key][6]:          # training-mode GNT: this replay's Dropout seeds
+            net.stage_replay_seeds(n_seeds)
         g_idx.copy_(torch.from_numpy(np.ascontiguousarray(picks, dtype=np.int64)).pin_memory(), non_blocking=True)
         if self.use_adam:
             lr = self.lr()
@@ -550,6 +568,9 @@ class PGDAttack:
         graph = _SegmentedCapture(self._g_pool, 'global' if self.shard is None else 'thread_local')
         if self.shard is not None:
             self.shard._segmenter = graph
+        train_nets = self._training_gnt_nets()
+        for net in train_nets:
+            net.begin_seed_capture(device)
         try:
             graph.begin()
             grad = self.gradient(data, select_inds=g_idx, lookahead=False)        # (sharded: its collectives cut the capture)
@@ -563,8 +584,9 @@ class PGDAttack:
                 self.shard._segmenter = None
             graph.end()
         self.delta.grad = None
+        seeds = [(net, net.end_seed_capture()) for net in train_nets]
         # (the sampler is held so that its ray tensors -- and its id(), part of the key -- outlive the graph that reads them)
-        self._graphs[key] = (graph, g_idx, g_hyper, g_loss, grad, sampler)
+        self._graphs[key] = (graph, g_idx, g_hyper, g_loss, grad, sampler, seeds)
 
     def run_view_specific(self, data, n_iters=None):
         """eval_adv.py:796-843: adv_iters steps on one target view."""

@@ -7,7 +7,8 @@ Eval mode (`.eval()` / `model.switch_to_eval()`): Dropout = identity, matrix-cor
 attack, rendering.  TRAINING mode (round 5): the reference's universal GNT loop runs before `model.switch_to_eval()`
 (eval/gnt/eval_adv.py:739-878 vs :959), i.e. with the `Dropout(0.1)` of every attention / feed-forward block live
 (gnt/transformer_network.py:45-48, :85-88, :162-166) -- a stochastic forward.  torch's generator cannot be reproduced on a GPU, so a
-module in training mode runs the shape-generic kernels with masks from a counter-based generator (csrc/nf_gnt.h: gnt_keep; pinned
+module in training mode runs its kernels (round 6: the matrix-core pair too -- nf_gnt_fwd_train_mfma / nf_gnt_bwd_train_mfma -- so config 4's
+universal loop runs on the same kernels as its view-specific one and can be captured into a hipGraph) with masks from a counter-based generator (csrc/nf_gnt.h: gnt_keep; pinned
 against the reference with the same masks injected into its modules, and statistically against the reference's own Dropout --
 tests/golden/make_golden_gnt_train.py): every forward call takes the next seed of `self.dropout_seed` (initialised from
 `torch.initial_seed()`, so `torch.manual_seed` makes an attack reproducible), its backward regenerates the same masks."""
@@ -62,11 +63,13 @@ class _GNTFunction(torch.autograd.Function):
     def forward(ctx, rgb_feat, ray_diff, mask, pts, ray_d, blob, mfma_blob, depth, ret_alpha, dropout=None):
         need_grad = rgb_feat.requires_grad
         ctx.dropout = dropout
-        use_mfma = dropout is None and mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])
+        use_mfma = mfma_blob is not None and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2])
         if use_mfma:
             # (each backward reads what ITS forward saved: ctx.use_mfma picks the matching one below)
-            out = ops.gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha)
-        else:       # shape-generic kernels; training mode (dropout = (seed, p)) exists in this pair only
+            out = ops.gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha, dropout=dropout)
+        else:       # shape-generic kernels (training mode: dropout = (seed, p) by value only -- no seed word, not capturable)
+            if dropout is not None and len(dropout) > 2:
+                raise RuntimeError('a captured training-mode GNT forward needs the matrix-core kernels (S in {32, 64, 96, 128})')
             out = ops.gnt_fwd(blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save=need_grad, want_alpha=ret_alpha, dropout=dropout)
         rgb, ws = out[0], out[1]
         alpha = out[2] if ret_alpha else rgb.new_zeros(0)
@@ -88,7 +91,7 @@ class _GNTFunction(torch.autograd.Function):
             raise RuntimeError('GNT forward ran without saved activations (input did not require grad)')
         ray_diff, mask, blob, ws, mfma_blob = ctx.saved_tensors
         if ctx.use_mfma:
-            d_rgb_feat = ops.gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, ctx.shape, ctx.depth)
+            d_rgb_feat = ops.gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, ctx.shape, ctx.depth, dropout=ctx.dropout)
         else:
             d_rgb_feat = ops.gnt_bwd(blob, ray_diff, mask, d_rgb, ws, ctx.shape, ctx.depth, dropout=ctx.dropout)
         return d_rgb_feat, None, None, None, None, None, None, None, None, None
@@ -119,6 +122,10 @@ class GNT(nn.Module):
         # and the seed of the NEXT training-mode forward (None: taken from torch.initial_seed() at first use)
         self.dropout_p = 0.1
         self.dropout_seed = None
+        # a hipGraph-captured PGD step (eval_adv.PGDAttack) must not freeze the seeds: while a capture is open, the k-th training-mode
+        # forward reads its seed from word k of this device buffer, which the attack refreshes before every replay (stage_replay_seeds)
+        self._seed_words = None
+        self._capture_calls = None
 
     def next_dropout_seed(self):
         """the seed of this training-mode forward; the following call gets the next one"""
@@ -127,6 +134,27 @@ class GNT(nn.Module):
         seed = self.dropout_seed
         self.dropout_seed = (seed + 1) & 0xffffffff
         return seed
+
+    MAX_CAPTURED_FORWARDS = 16
+
+    def begin_seed_capture(self, device):
+        """called (outside the capture) before a step that runs this module in training mode is captured"""
+        if self._seed_words is None or self._seed_words.device != torch.device(device):
+            self._seed_words = torch.zeros(self.MAX_CAPTURED_FORWARDS, dtype=torch.int32, device=device)
+        self._capture_calls = 0
+
+    def end_seed_capture(self):
+        """-> number of training-mode forwards the captured step contains (the seeds one replay consumes)"""
+        n, self._capture_calls = self._capture_calls, None
+        return n
+
+    def stage_replay_seeds(self, n):
+        """before a replay: the next n seeds of the module's sequence -> the words the captured forwards read (stream-ordered copy), so
+        that replayed steps consume the same seed sequence as steps enqueued launch by launch"""
+        import numpy as np
+        if n:
+            seeds = np.array([self.next_dropout_seed() for _ in range(n)], dtype=np.uint32).view(np.int32)
+            self._seed_words[:n].copy_(torch.from_numpy(seeds).pin_memory(), non_blocking=True)
 
     def _packed(self, device):
         key = (str(device), KERNEL_PATH) + tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -140,7 +168,16 @@ class GNT(nn.Module):
         """rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V,1], pts [R,S,3], ray_d [R,3] -> rgb [R,3] (or [R,3+S])"""
         blob, mfma_blob = self._packed(rgb_feat.device)
         # training mode = the reference's Dropout-active forward (its universal loop, eval/gnt/eval_adv.py:739-878)
-        dropout = (self.next_dropout_seed(), self.dropout_p) if self.training else None
+        dropout = None
+        if self.training:
+            if self._capture_calls is not None and rgb_feat.is_cuda and torch.cuda.is_current_stream_capturing():
+                k = self._capture_calls
+                if k >= self.MAX_CAPTURED_FORWARDS:
+                    raise RuntimeError('more than %d training-mode GNT forwards in one captured step' % self.MAX_CAPTURED_FORWARDS)
+                self._capture_calls = k + 1
+                dropout = (0, self.dropout_p, self._seed_words[k:k + 1])      # the seed of each replay arrives in that word
+            else:
+                dropout = (self.next_dropout_seed(), self.dropout_p)
         rgb, alpha = _GNTFunction.apply(rgb_feat, ray_diff, mask[..., 0], pts.detach(), ray_d.detach(), blob, mfma_blob,
                                         self.trans_depth, bool(self.ret_alpha), dropout)
         # ret_alpha: [R, 3 + S] = colour | attention of the first sample in the last ray transformer, mean over heads (:303-309)

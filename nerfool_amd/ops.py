@@ -917,7 +917,9 @@ def gnt_mfma_supported(n_samples, n_views):
     return bool(_lib.lib().nf_gnt_mfma_supported(int(n_samples), int(n_views)))
 
 
-def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=False):
+def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, want_alpha=False, dropout=None):
+    """dropout = (seed, p[, seed word]): TRAINING mode on the matrix-core kernels (nf_gnt_fwd_train_mfma); seed word: a 1-element int32
+    device tensor the kernel reads the seed from instead (captured steps); the backward must be given the same triple"""
     rgb_feat, ray_diff, mask = _c(rgb_feat, 'rgb_feat'), _c(ray_diff, 'ray_diff'), _c(mask, 'mask')
     pts, ray_d = _c(pts, 'pts'), _c(ray_d, 'ray_d')
     R, S, V, F = rgb_feat.shape
@@ -928,19 +930,30 @@ def gnt_fwd_mfma(mfma_blob, rgb_feat, ray_diff, mask, pts, ray_d, depth, save, w
     rgb = torch.empty(R, 3, dtype=torch.float32, device=rgb_feat.device)
     alpha = torch.empty(R, S, dtype=torch.float32, device=rgb_feat.device) if want_alpha else None
     with prof.launch('nf_gnt_fwd_mfma', rgb, R=R, S=S, V=V, depth=depth):
-        _launch(L.nf_gnt_fwd_mfma, 'nf_gnt_fwd_mfma', rgb, _ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
-                                     depth, int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws))
+        if dropout is not None:
+            word = dropout[2] if len(dropout) > 2 else None
+            _launch(L.nf_gnt_fwd_train_mfma, 'nf_gnt_fwd_train_mfma', rgb, _ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts),
+                    _ptr(ray_d), R, S, V, depth, int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws), int(dropout[0]) & 0xffffffff,
+                    float(dropout[1]), _ptr(word))
+        else:
+            _launch(L.nf_gnt_fwd_mfma, 'nf_gnt_fwd_mfma', rgb, _ptr(mfma_blob), _ptr(rgb_feat), _ptr(ray_diff), _ptr(mask), _ptr(pts), _ptr(ray_d), R, S, V,
+                    depth, int(bool(save)), _ptr(rgb), _ptr(alpha), _ptr(ws))
     if want_alpha:
         return rgb, (ws if save else None), alpha
     return rgb, (ws if save else None)
 
 
-def gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, shape, depth):
+def gnt_bwd_mfma(mfma_blob, mask, d_rgb, ws, shape, depth, dropout=None):
     R, S, V = shape
     mask, d_rgb = _c(mask, 'mask'), _c(d_rgb, 'd_rgb')
     d_rgb_feat = torch.empty(R, S, V, 35, dtype=torch.float32, device=d_rgb.device)
     with prof.launch('nf_gnt_bwd_mfma', d_rgb, R=R, S=S, V=V, depth=depth):
-        _launch(_lib.lib().nf_gnt_bwd_mfma, 'nf_gnt_bwd_mfma', d_rgb, _ptr(mfma_blob), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat), _ptr(ws))
+        if dropout is not None:
+            word = dropout[2] if len(dropout) > 2 else None
+            _launch(_lib.lib().nf_gnt_bwd_train_mfma, 'nf_gnt_bwd_train_mfma', d_rgb, _ptr(mfma_blob), _ptr(mask), _ptr(d_rgb), R, S, V, depth,
+                    _ptr(d_rgb_feat), _ptr(ws), int(dropout[0]) & 0xffffffff, float(dropout[1]), _ptr(word))
+        else:
+            _launch(_lib.lib().nf_gnt_bwd_mfma, 'nf_gnt_bwd_mfma', d_rgb, _ptr(mfma_blob), _ptr(mask), _ptr(d_rgb), R, S, V, depth, _ptr(d_rgb_feat), _ptr(ws))
     return d_rgb_feat
 
 

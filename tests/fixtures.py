@@ -184,3 +184,29 @@ def attack100_gnt_inputs(c):
     delta0 = torch.zeros_like(data['src_rgbs']).uniform_(-eps, eps, generator=gen)
     delta0 = torch.max(torch.min(delta0, 1 - data['src_rgbs']), 0 - data['src_rgbs'])
     return data, cnn_sd, params, delta0
+
+
+# training-mode GNT on the MATRIX-CORE kernels (tests/golden/gnt_train_mfma_d2.npz, make_golden_gnt_train.py mfma): a network-level input at
+# the smallest shape those kernels take (32 samples per ray), regenerated from seeds on both sides
+GNT_TRAIN_MFMA = dict(R=6, S=32, V=3, depth=2, seed=31)
+
+
+def gnt_train_mfma_inputs(c=GNT_TRAIN_MFMA):
+    """(parameters, rgb_feat [R,S,V,35], ray_diff [R,S,V,4], mask [R,S,V,1], pts [R,S,3], ray_d [R,3]) -- the same call is made by
+    tests/golden/make_golden_gnt_train.py in front of the reference"""
+    from oracle.gnt_ref import random_gnt_params
+    R, S, V = c['R'], c['S'], c['V']
+    g = torch.Generator().manual_seed(c['seed'])
+    params = random_gnt_params(c['depth'], seed=70 + c['seed'])
+    rgb_feat = torch.randn(R, S, V, 35, generator=g) * 0.6
+    rgb_feat[..., :3] = torch.rand(R, S, V, 3, generator=g)
+    d = torch.randn(R, S, V, 3, generator=g)
+    ray_diff = torch.cat([d / d.norm(dim=-1, keepdim=True), torch.rand(R, S, V, 1, generator=g) * 2 - 1], dim=-1)
+    mask = (torch.rand(R, S, V, 1, generator=g) > 0.15).float()
+    mask[0, :4] = 0.0                       # samples no view sees
+    mask[1, :, 0] = 0.0                     # a view that sees nothing of a ray
+    ray_d = torch.randn(R, 3, generator=g)
+    ray_o = torch.randn(R, 3, generator=g) * 0.2
+    z = torch.linspace(2.0, 6.0, S)
+    pts = ray_o[:, None, :] + z[None, :, None] * (ray_d / ray_d.norm(dim=-1, keepdim=True))[:, None, :]
+    return params, rgb_feat, ray_diff, mask, pts, ray_d

@@ -11,6 +11,7 @@ GNT loop runs before `model.switch_to_eval()` (eval/gnt/eval_adv.py:739-878 vs :
             over 400 draws -- what the distribution of the counter-based masks must reproduce.
 
     python tests/golden/make_golden_gnt_train.py        # writes tests/golden/gnt_train_d2.npz
+    python tests/golden/make_golden_gnt_train.py mfma   # writes tests/golden/gnt_train_mfma_d2.npz (32 samples per ray: the matrix-core kernels)
 Data only; build container only."""
 import os
 import sys
@@ -65,22 +66,28 @@ def npy(t):
 
 
 def run(tag, base, ret_alpha, out):
-    z = np.load(os.path.join(HERE, base + '.npz'))
-    depth = int(z['cfg'][5])
-    t = lambda k: torch.from_numpy(z[k])
-    params = {k[4:]: t(k) for k in z.files if k.startswith('net/')}
-    if ret_alpha:         # the alpha fixture has no network-level capture: take the geometry of the tiny one, its own weights
-        zin = np.load(os.path.join(HERE, 'gnt_tiny_d2_v4.npz'))
+    if base == 'seeded':  # round 6: the matrix-core kernels' smallest shape (32 samples per ray), every input regenerated from seeds
+        sys.path.insert(0, os.path.dirname(HERE))
+        from fixtures import GNT_TRAIN_MFMA, gnt_train_mfma_inputs
+        params, rgb_feat, ray_diff, mask, pts, ray_d = gnt_train_mfma_inputs()
+        depth = GNT_TRAIN_MFMA['depth']
     else:
-        zin = z
-    tin = lambda k: torch.from_numpy(zin[k])
-    rgb_feat, ray_diff, mask, pts = tin('net_in/rgb_feat'), tin('net_in/ray_diff'), tin('net_in/mask'), tin('net_in/pts')
-    ray_d = tin('in/ray_d')
+        z = np.load(os.path.join(HERE, base + '.npz'))
+        depth = int(z['cfg'][5])
+        t = lambda k: torch.from_numpy(z[k])
+        params = {k[4:]: t(k) for k in z.files if k.startswith('net/')}
+        if ret_alpha:         # the alpha fixture has no network-level capture: take the geometry of the tiny one, its own weights
+            zin = np.load(os.path.join(HERE, 'gnt_tiny_d2_v4.npz'))
+        else:
+            zin = z
+        tin = lambda k: torch.from_numpy(zin[k])
+        rgb_feat, ray_diff, mask, pts = tin('net_in/rgb_feat'), tin('net_in/ray_diff'), tin('net_in/mask'), tin('net_in/pts')
+        ray_d = tin('in/ray_d')
     R, S = rgb_feat.shape[:2]
     net = GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=ret_alpha)
     net.load_state_dict(params, strict=True)
     out[tag + '/base'] = np.array(base)
-    out[tag + '/geometry'] = np.array('gnt_tiny_d2_v4' if ret_alpha else base)
+    out[tag + '/geometry'] = np.array('seeded' if base == 'seeded' else ('gnt_tiny_d2_v4' if ret_alpha else base))
     gen = torch.Generator().manual_seed(17)
     w = torch.randn(R, 3 + (S if ret_alpha else 0), generator=gen)
     out[tag + '/w'] = npy(w)
@@ -116,10 +123,15 @@ def run(tag, base, ret_alpha, out):
 
 
 if __name__ == '__main__':
-    torch.set_num_threads(8)
+    torch.set_num_threads(4)
     out = {'p': np.array(P_DROP)}
-    run('plain', 'gnt_tiny_d2_v4', False, out)
-    run('alpha', 'gnt_alpha_d2_v3', True, out)
-    path = os.path.join(HERE, 'gnt_train_d2.npz')
+    if sys.argv[1:] == ['mfma']:          # python tests/golden/make_golden_gnt_train.py mfma -> gnt_train_mfma_d2.npz
+        run('plain', 'seeded', False, out)
+        run('alpha', 'seeded', True, out)
+        path = os.path.join(HERE, 'gnt_train_mfma_d2.npz')
+    else:
+        run('plain', 'gnt_tiny_d2_v4', False, out)
+        run('alpha', 'gnt_alpha_d2_v3', True, out)
+        path = os.path.join(HERE, 'gnt_train_d2.npz')
     np.savez_compressed(path, **out)
     print('%s %.1f KB' % (path, os.path.getsize(path) / 1024.))

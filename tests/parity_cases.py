@@ -1280,30 +1280,35 @@ def check_gnt(case, dev, expect_mfma=False):
     assert err <= 1e-3, 'GNT d loss / d featmap rel-L2 %.3e vs float64' % err
 
 
-def check_gnt_train_mode(dev):
+def check_gnt_train_mode(dev, fixture='gnt_train_d2', expect_mfma=False):
     """GNT in TRAINING mode -- the reference's universal GNT loop runs with Dropout(0.1) live (eval/gnt/eval_adv.py:739-878 before
-    switch_to_eval at :959).  tests/golden/gnt_train_d2.npz: the reference network in train() mode with the counter-based masks injected
-    into its nn.Dropout instances.  The module in .train() with the same seed must reproduce output and d out / d rgb_feat (1e-3);
-    consecutive calls take consecutive seeds, .eval() is untouched, and over 200 seeds the outputs have the mean / spread of the
-    reference's OWN torch-generator Dropout (4.5 standard errors; spread within 25 %)."""
+    switch_to_eval at :959).  tests/golden/gnt_train_d2.npz (8 samples per ray: the shape-generic kernels) / gnt_train_mfma_d2.npz (32
+    samples per ray: the MATRIX-CORE kernels, `expect_mfma` asserts that they ran): the reference network in train() mode with the
+    counter-based masks injected into its nn.Dropout instances.  The module in .train() with the same seed must reproduce output and
+    d out / d rgb_feat (1e-3); consecutive calls take consecutive seeds, .eval() is untouched, and over 200 seeds the outputs have the
+    mean / spread of the reference's OWN torch-generator Dropout (4.5 standard errors; spread within 25 %)."""
     from nerfool_amd.gnt import transformer_network as tn
-    g = Golden('gnt_train_d2')
+    from test_oracle_golden_gnt import gnt_train_inputs
+    g = Golden(fixture)
     pd = float(g.np('p'))
     for tag in ('plain', 'alpha'):
-        base, geo = Golden(str(g.np(tag + '/base'))), Golden(str(g.np(tag + '/geometry')))
-        depth = int(base.np('cfg')[5])
+        params, rgb_feat, ray_diff, mask, pts, ray_d, depth, _w = gnt_train_inputs(g, tag)
         net = tn.GNT(SimpleNamespace(netwidth=64, trans_depth=depth), in_feat_ch=32, posenc_dim=63, viewenc_dim=63, ret_alpha=tag == 'alpha')
-        net.load_state_dict(base.params('net'), strict=True)
+        net.load_state_dict(params, strict=True)
         for p_ in net.parameters():
             p_.requires_grad_(False)
         net = net.to(dev)
         assert abs(net.dropout_p - pd) < 1e-12
-        ins = [geo.t(k, dev) for k in ('net_in/ray_diff', 'net_in/mask', 'net_in/pts', 'in/ray_d')]
+        ins = [t.to(dev) for t in (ray_diff, mask, pts, ray_d)]
+        geo_rgb_feat = lambda d='cpu': rgb_feat.to(d)
+        if expect_mfma:
+            assert tn.KERNEL_PATH == 'mfma' and ops.gnt_mfma_supported(rgb_feat.shape[1], rgb_feat.shape[2]), \
+                'this capture pins the matrix-core GNT kernels in training mode: they must be the ones that run'
         w = g.t(tag + '/w', dev)
         net.train()
         for seed in [int(x) for x in g.np(tag + '/seeds')]:
             net.dropout_seed = seed
-            x = geo.t('net_in/rgb_feat', dev).requires_grad_(True)
+            x = geo_rgb_feat(dev).requires_grad_(True)
             y = net(x, *ins)
             assert net.dropout_seed == seed + 1, 'every training-mode forward takes the next seed'
             ref = g.np('%s/exact/%d/out' % (tag, seed))
@@ -1314,19 +1319,18 @@ def check_gnt_train_mode(dev):
                 # gnt/render_ray.py:256): the expected gradient is the COLOUR columns' -- from the oracle with the same masks, which
                 # tests/test_oracle_golden_gnt.py pins to the reference's capture on all columns
                 from oracle import gnt_ref as gr
-                x64 = geo.t('net_in/rgb_feat').requires_grad_(True)
-                y64 = gr.gnt_forward(base.params('net'), x64, geo.t('net_in/ray_diff'), geo.t('net_in/mask'), geo.t('net_in/pts'),
-                                     geo.t('in/ray_d'), depth, ret_alpha=True, dropout=(seed, pd))
+                x64 = geo_rgb_feat().requires_grad_(True)
+                y64 = gr.gnt_forward(params, x64, ray_diff, mask, pts, ray_d, depth, ret_alpha=True, dropout=(seed, pd))
                 gref = torch.autograd.grad((y64[:, :3] * w.cpu()[:, :3]).sum(), x64)[0].numpy()
             else:
                 gref = g.np('%s/exact/%d/d_rgb_feat' % (tag, seed))
             assert_close(grad, gref, 2e-3, 1e-3 * float(np.abs(gref).max()), 'train-mode d out / d rgb_feat (%s, seed %d)' % (tag, seed), frac_ok=1e-3)
         with torch.no_grad():
             net.dropout_seed = 4000
-            draws = torch.stack([net(geo.t('net_in/rgb_feat', dev), *ins) for _ in range(200)]).cpu()
+            draws = torch.stack([net(geo_rgb_feat(dev), *ins) for _ in range(200)]).cpu()
             assert net.dropout_seed == 4200
             net.eval()
-            ev = net(geo.t('net_in/rgb_feat', dev), *ins)
+            ev = net(geo_rgb_feat(dev), *ins)
         assert_close(ev, g.np(tag + '/eval'), 1e-3, 1e-3 * float(np.abs(g.np(tag + '/eval')).max()), 'eval-mode output after training-mode calls')
         mean, std, n = g.np(tag + '/stat/mean'), g.np(tag + '/stat/std'), int(g.np(tag + '/stat/n'))
         se = np.sqrt(std ** 2 / n + draws.std(0).numpy() ** 2 / draws.shape[0]) + 1e-6
@@ -1521,6 +1525,49 @@ def check_gnt_attack_step(dev, train=False, universal_iters=3):
             a2.gradient(data, select_inds=picks)
             losses.append(float(a2.last_loss))
         assert losses[0] == loss and losses[1] != loss, (loss, losses)
+        model.switch_to_eval()
+
+
+def check_gnt_train_step_graph(dev):
+    """A TRAINING-mode GNT PGD step (Dropout live: the reference's universal GNT loop) on the matrix-core kernels, replayed as a hipGraph
+    against the same steps enqueued launch by launch: the captured forwards read their Dropout seeds from device words the attack
+    refreshes before every replay (GNT.stage_replay_seeds), so both runs consume the same seed sequence -- perturbation, Adam moments and
+    losses bit-identical after six steps (sorted scatter), the module's seed counter at the same place; another seed gives other losses."""
+    from nerfool_amd.gnt import eval_adv as GEA
+    from nerfool_amd.gnt import transformer_network as tn
+    from nerfool_amd.gnt.model import GNTModel
+    from nerfool_amd.synthetic import make_scene
+    torch.manual_seed(0)
+    H, W, V, R, S, depth = 48, 64, 3, 24, 32, 2
+    args = SimpleNamespace(netwidth=64, trans_depth=depth, single_net=True, ret_alpha=False, coarse_feat_dim=32, fine_feat_dim=32,
+                           N_rand=R, N_samples=S, N_importance=0, inv_uniform=True, det=True, white_bkgd=False, epsilon=8, adv_lr=2,
+                           use_adam=True, adam_lr=1e-3, lr_step_size=100, lr_gamma=0.5, adv_iters=1, sample_mode='uniform',
+                           center_ratio=0.8, ckpt_path=None)
+    model = GNTModel(args, device=dev)
+    model.switch_to_train()
+    assert model.net_coarse.training and tn.KERNEL_PATH == 'mfma' and ops.gnt_mfma_supported(S, V)
+    data = make_scene(H, W, V, seed=21, tilt=0.3)
+    sampler = RaySamplerSingleImage(data, dev)
+    src = sampler.get_all()
+    delta0 = GEA.PGDAttack(args, model, Projector(dev), src).delta.detach().clone()
+    saved, ops.GATHER_BWD = ops.GATHER_BWD, 'deterministic'
+    try:
+        runs = []
+        for graph, seed in ((None, 1357), (False, 1357), (None, 99)):
+            model.net_coarse.dropout_seed = seed
+            product_sample_ray.rng.seed(234)
+            a = GEA.PGDAttack(args, model, Projector(dev), src, delta=delta0.clone().requires_grad_(True), graph=graph)
+            losses = [float(a.step(data)) for _ in range(6)]
+            assert model.net_coarse.dropout_seed == seed + 6, 'one seed per training-mode forward, replayed or not'
+            runs.append((a, losses))
+        (ga, gl), (ea, el), (oa, ol) = runs
+        assert ga.graph_replays == 4 and ea.graph_replays == 0 and oa.graph_replays == 4
+        assert gl == el, ('losses', gl, el)
+        assert torch.equal(ga.delta.data, ea.delta.data) and torch.equal(ga.exp_avg, ea.exp_avg) and torch.equal(ga.exp_avg_sq, ea.exp_avg_sq)
+        assert all(x != y for x, y in zip(gl, ol)), 'another seed sequence must give other masks (also inside replays)'
+        assert len(set(gl[2:])) == 4, 'every replay takes a fresh seed'
+    finally:
+        ops.GATHER_BWD = saved
         model.switch_to_eval()
 
 

@@ -160,6 +160,14 @@ def test_gnt_training_mode_dropout():
     pc.check_gnt_train_mode('cuda')
 
 
+def test_gnt_training_mode_dropout_on_the_matrix_core_kernels():
+    pc.check_gnt_train_mode('cuda', 'gnt_train_mfma_d2', expect_mfma=True)
+
+
+def test_gnt_training_mode_step_graph_equals_eager_step():
+    pc.check_gnt_train_step_graph('cuda')
+
+
 def test_gnt_universal_loop_in_training_mode():
     pc.check_gnt_attack_step('cuda', train=True)
 

@@ -56,20 +56,28 @@ def test_gnt_ret_alpha_and_hierarchical_sampling_match_reference():
 def gnt_train_inputs(g, tag, device='cpu'):
     """(params, rgb_feat, ray_diff, mask, pts, ray_d, depth, upstream weights) of one case of gnt_train_d2.npz: the network weights of
     its base fixture on the network-level capture of its geometry fixture"""
+    if str(g.np(tag + '/base')) == 'seeded':        # gnt_train_mfma_d2.npz: every input regenerated from seeds (tests/fixtures.py)
+        from fixtures import GNT_TRAIN_MFMA, gnt_train_mfma_inputs
+        p, rgb_feat, ray_diff, mask, pts, ray_d = gnt_train_mfma_inputs()
+        to = lambda t: t.to(device)
+        from collections import OrderedDict
+        return (OrderedDict((k, to(v)) for k, v in p.items()), to(rgb_feat), to(ray_diff), to(mask), to(pts), to(ray_d), GNT_TRAIN_MFMA['depth'],
+                g.t(tag + '/w', device))
     base, geo = Golden(str(g.np(tag + '/base'))), Golden(str(g.np(tag + '/geometry')))
     depth = int(base.np('cfg')[5])
     return (base.params('net', device), geo.t('net_in/rgb_feat', device), geo.t('net_in/ray_diff', device), geo.t('net_in/mask', device),
             geo.t('net_in/pts', device), geo.t('in/ray_d', device), depth, g.t(tag + '/w', device))
 
 
+@pytest.mark.parametrize('fixture', ['gnt_train_d2', 'gnt_train_mfma_d2'])
 @pytest.mark.parametrize('tag', ['plain', 'alpha'])
-def test_gnt_training_mode_dropout_matches_reference(tag):
+def test_gnt_training_mode_dropout_matches_reference(tag, fixture):
     """The reference's universal GNT loop runs with Dropout(0.1) live (eval/gnt/eval_adv.py:739-878 before switch_to_eval at :959;
     gnt/transformer_network.py:45-48, 72/85-88, 136/162-166).  (1) EXACT: the reference network in train() mode with its nn.Dropout
     instances replaced by the counter-based masks (tests/golden/make_golden_gnt_train.py) against the oracle with the same (seed, site,
     index) masks -- output and d out / d rgb_feat.  (2) STATISTICAL: over 400 seeds the oracle's outputs have the mean and the spread of
     400 draws of the reference with its OWN torch-generator Dropout (4.5 standard errors per element; spread within 25 %)."""
-    g = Golden('gnt_train_d2')
+    g = Golden(fixture)          # (gnt_train_mfma_d2: 32 samples per ray, the shape the matrix-core kernels are pinned on)
     p, rgb_feat, ray_diff, mask, pts, ray_d, depth, w = gnt_train_inputs(g, tag)
     alpha = tag == 'alpha'
     pd = float(g.np('p'))
@@ -82,10 +90,11 @@ def test_gnt_training_mode_dropout_matches_reference(tag):
         assert_close(grad, ref, 1e-3, 1e-4 * float(np.abs(ref).max()), 'train-mode d out / d rgb_feat, seed %d' % seed)
     with torch.no_grad():
         assert_close(gr.gnt_forward(p, rgb_feat, ray_diff, mask, pts, ray_d, depth, ret_alpha=alpha), g.np(tag + '/eval'), 1e-4, 2e-5, 'eval output')
+        n_draws = 400 if fixture == "gnt_train_d2" else 60          # (the 32-sample case costs 16x the attention work per draw)
         draws = torch.stack([gr.gnt_forward(p, rgb_feat, ray_diff, mask, pts, ray_d, depth, ret_alpha=alpha, dropout=(1000 + s, pd))
-                             for s in range(400)])
+                             for s in range(n_draws)])
     mean, std, n = g.np(tag + '/stat/mean'), g.np(tag + '/stat/std'), int(g.np(tag + '/stat/n'))
-    se = np.sqrt(std ** 2 / n + draws.std(0).numpy() ** 2 / 400) + 1e-6
+    se = np.sqrt(std ** 2 / n + draws.std(0).numpy() ** 2 / n_draws) + 1e-6
     zmax = float(np.abs((draws.mean(0).numpy() - mean) / se).max())
     ratio = float(draws.std(0).numpy().mean() / std.mean())
     print('[gnt train mode] %s: max |z| of the mean over %d elements %.2f; spread ratio %.3f' % (tag, mean.size, zmax, ratio))
