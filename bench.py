@@ -636,6 +636,25 @@ def main():
             del x3
         finally:
             feature_network.WINO_BWD_OPERANDS = saved_bwd
+    if a.extras and a.model == 'gnt':
+        # BASELINE config 4's UNIVERSAL loop runs the network in training mode (Dropout(0.1) live: eval/gnt/eval_adv.py:739-878 before
+        # switch_to_eval at :959): the same step with the training-mode matrix-core kernels, replayed as a hipGraph with a fresh seed per step
+        model.switch_to_train()
+        try:
+            tr = make_attack(a.cnn_shard, a.scaling)
+            n = max(5, a.steps // 2)
+            ms_tr = 1e3 * max_over_ranks(time_steps(tr, data, n, 2, barrier)) / n
+            t_timer = prof.KernelTimer(only=('nf_gnt_fwd_mfma', 'nf_gnt_bwd_mfma', 'nf_gnt_fwd', 'nf_gnt_bwd'))
+            with prof.timing(t_timer):
+                tr.step(data)
+            extra_legs['training_mode_step'] = {
+                'ms_per_step': round(ms_tr, 4), 'vs_eval_mode_step': round(ms_tr / (1e3 * elapsed / a.steps), 4),
+                'graph_replays': tr.graph_replays, 'kernels_ms': {k: round(v['mean_ms'], 4) for k, v in t_timer.summary().items()},
+                'note': 'Dropout(0.1) at the eight sites of every layer, masks from the counter-based generator (nf_gnt.h), seeds read from '
+                        'device words refreshed before each replay'}
+            del tr
+        finally:
+            model.switch_to_eval()
     if a.extras and a.universal_views > 0 and a.model == 'ibrnet' and a.config == 'c2':
         extra_legs['universal'] = universal_leg(a, EA, make_attack, data, dev, barrier, max_over_ranks, world)
     if a.extras and a.model == 'ibrnet' and a.config == 'c2':
