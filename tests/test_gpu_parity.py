@@ -388,6 +388,37 @@ def test_c5_full_size_properties():
         assert rel <= 2.5e-2, (k, rel)
 
 
+def test_c5_full_size_row_backward_against_the_shape_generic_kernels():
+    """The matrix-core row kernels on their MULTI-TILE path (config 5: V = 8, 512 rays x 128 / 256 samples -- several tiles per workgroup
+    through the grid-stride loop) against the shape-generic kernels, which share none of the tiling, on the same inputs: colours and
+    d loss / d feature maps equal to fp32 rounding; and, with the sorted scatter, two runs of the matrix-core path bit-identical.
+    (Round 5's two-part-operand probe of the row backward broke linearity by 3 % exactly on this path; it was removed before its cause
+    was found -- this test is what a tile-indexing bug in the KEPT kernels could not pass.)"""
+    from nerfool_amd import ops
+    from nerfool_amd.ibrnet import mlp_network
+    shape = dict(H=512, W=512, V=8, R=512, S=128, N=128, depth_range=(3.2, 4.8), white_bkgd=True)
+    saved = (mlp_network.KERNEL_PATH, ops.GATHER_BWD)
+    ops.GATHER_BWD = 'deterministic'
+    try:
+        a = _full_size_render_properties(precision='fp32', **shape)
+        b = _full_size_render_properties(precision='fp32', **shape)
+        for k in ('rgb_c', 'rgb_f', 'z_f', 'g_c', 'g_f'):
+            assert torch.equal(a[k], b[k]), 'matrix-core path, sorted scatter: run-to-run difference in %s' % k
+        mlp_network.KERNEL_PATH = 'generic'
+        g = _full_size_render_properties(precision='fp32', **shape)
+    finally:
+        mlp_network.KERNEL_PATH, ops.GATHER_BWD = saved
+    for k in ('rgb_c', 'rgb_f'):
+        err = float((a[k] - g[k]).abs().max())
+        print('[config 5 full size] %s: matrix-core rows vs shape-generic rows max abs %.2e' % (k, err))
+        assert err <= 1e-4, (k, err)
+    same_z = float((a['z_f'] == g['z_f']).float().mean())
+    for k in ('g_c', 'g_f'):
+        rel = float((a[k] - g[k]).norm() / g[k].norm())
+        print('[config 5 full size] %s: matrix-core rows vs shape-generic rows rel-L2 %.2e (fine depths identical: %.4f)' % (k, rel, same_z))
+        assert rel <= (1e-4 if same_z == 1.0 else 5e-3), (k, rel, same_z)
+
+
 def test_full_size_properties():
     """BASELINE config 2 sizes (756x1008 sources, V=4, 64+64 samples, 512 rays): size-independent invariants."""
     from nerfool_amd import ops
