@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3      # MI355X fp32 MFMA / vector peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0        # HBM3E spec peak
-PMC_PROFILE = 'profiles/r05_pmc_traffic.json'
+PMC_PROFILE = 'profiles/r06_pmc_traffic.json'
 # kernels whose matrix products run on the bf16 pipe with every fp32 operand split in three (round 4): priced against the bf16 peak
 X3_KERNELS = {
     'nf_conv3x3_wino': 'achieved = executed bf16 products: 6 per Winograd-domain product (three operand parts); each product counted once in '
@@ -71,7 +71,7 @@ def pmc_traffic(kernel, a):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     in their own runs of this command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the
     profile does not cover this workload: counters cannot be read from inside the benchmark process."""
-    for rel in (PMC_PROFILE, 'profiles/r04_pmc_traffic.json', 'profiles/r03_pmc_traffic.json'):
+    for rel in (PMC_PROFILE, 'profiles/r05_pmc_traffic.json', 'profiles/r04_pmc_traffic.json'):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 prof = json.load(f)
