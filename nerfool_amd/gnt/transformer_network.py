@@ -139,8 +139,15 @@ class GNT(nn.Module):
 
     def begin_seed_capture(self, device):
         """called (outside the capture) before a step that runs this module in training mode is captured"""
-        if self._seed_words is None or self._seed_words.device != torch.device(device):
-            self._seed_words = torch.zeros(self.MAX_CAPTURED_FORWARDS, dtype=torch.int32, device=device)
+        # ONE buffer per module for its lifetime on a device: every captured graph holds its address
+        dev = torch.device(device)
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        if self._seed_words is None:
+            self._seed_words = torch.zeros(self.MAX_CAPTURED_FORWARDS, dtype=torch.int32, device=dev)
+        elif self._seed_words.device != dev:
+            raise RuntimeError('training-mode GNT steps were captured on %s; capturing on %s too needs another module instance'
+                               % (self._seed_words.device, dev))
         self._capture_calls = 0
 
     def end_seed_capture(self):
