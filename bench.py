@@ -501,13 +501,17 @@ def main():
     from nerfool_amd.ibrnet import feature_network
     feature_network.WINO_OPERANDS = a.conv_operands
 
+    graph_ok = [True]       # N > 1: cleared when the segmented capture of a sharded step fails on this node (all ranks agree, below)
+    graph_note = [None]
+
     def make_attack(cnn_shard, scaling, n_rand=None):
         """a fresh PGDAttack (own delta / moments) in the given multi-GPU form; n_rand as on the command line: rays per rank
         (weak) or per step in total (strong)"""
         shard = None
         if world > 1:
             shard = EA.RayShard(shard_views=cnn_shard == 'view', split_n_rand=scaling == 'strong')
-        return EA.PGDAttack(make_args(a, a.n_rand if n_rand is None else n_rand), model, projector, src_ray_batch, shard=shard)
+        return EA.PGDAttack(make_args(a, a.n_rand if n_rand is None else n_rand), model, projector, src_ray_batch, shard=shard,
+                            graph=None if graph_ok[0] else False)
 
     def barrier():
         if world > 1:
@@ -534,7 +538,22 @@ def main():
 
     attack = make_attack(a.cnn_shard, a.scaling)
     if attack.shard is not None:
-        prime(attack, data)                 # (so that the collective counters below cover warm-up + timed steps only)
+        # (prime here so that the collective counters below cover warm-up + timed steps only.)  Sharded steps replay as hipGraph
+        # segments between their collectives; that path has run on a one-rank RCCL group and with two gloo ranks on one GPU, never on
+        # several GPUs -- if the capture raises here (on every rank alike: same code, same hardware), all ranks agree to run the bench
+        # with eager steps instead of losing the scaling measurement, and the line says so
+        ok = 1
+        try:
+            prime(attack, data)
+        except Exception as e:          # noqa: BLE001
+            ok, graph_note[0] = 0, 'segmented graph capture failed, steps enqueued launch by launch: %r' % (e,)
+            print('[bench rank %d] %s' % (rank, graph_note[0]), file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag) == 0:
+            graph_ok[0] = False
+            graph_note[0] = graph_note[0] or 'segmented graph capture failed on another rank, steps enqueued launch by launch'
+            attack = make_attack(a.cnn_shard, a.scaling)
         c0, b0 = attack.shard.collectives, attack.shard.bytes
     # HIP events only around the kernels the roofline table prices (~10 of the ~250 launches of a step): bracketing every
     # launch costs ~1.5 ms of host time per step, which is visible now that the step is close to launch-bound
@@ -845,7 +864,9 @@ def main():
                    # the all-bf16x3 step is timed beside it: extra.step_ms_all_bf16x3)
                    'conv_operands_bwd': (feature_network.WINO_BWD_OPERANDS if a.conv_operands == 'bf16x3' else a.conv_operands),
                    'rays_per_step_all_ranks': rays_per_step, 'parallelism': par,
-                   'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step},
+                   'collectives_per_step': collectives_per_step, 'collective_payload_bytes_per_step': payload_per_step,
+                   'step_launch': ('one hipGraph replay per step' if world == 1 else 'hipGraph segments between the collectives')
+                                  if (graph_ok[0] and not standin) else (graph_note[0] or 'launch by launch')},
         'roofline': roofline,
         'host_issue_ms_per_step': None if host_issue_ms is None else round(host_issue_ms, 4),
         'roofline_sampling': {'steps_with_hip_events': timed_steps, 'of_timed_steps': a.steps, 'every': a.event_every,
