@@ -1280,7 +1280,7 @@ def check_gnt(case, dev, expect_mfma=False):
     assert err <= 1e-3, 'GNT d loss / d featmap rel-L2 %.3e vs float64' % err
 
 
-def check_gnt_train_mode(dev, fixture='gnt_train_d2', expect_mfma=False):
+def check_gnt_train_mode(dev, fixture='gnt_train_d2', expect_mfma=False, stat_draws=200):
     """GNT in TRAINING mode -- the reference's universal GNT loop runs with Dropout(0.1) live (eval/gnt/eval_adv.py:739-878 before
     switch_to_eval at :959).  tests/golden/gnt_train_d2.npz (8 samples per ray: the shape-generic kernels) / gnt_train_mfma_d2.npz (32
     samples per ray: the MATRIX-CORE kernels, `expect_mfma` asserts that they ran): the reference network in train() mode with the
@@ -1327,11 +1327,13 @@ def check_gnt_train_mode(dev, fixture='gnt_train_d2', expect_mfma=False):
             assert_close(grad, gref, 2e-3, 1e-3 * float(np.abs(gref).max()), 'train-mode d out / d rgb_feat (%s, seed %d)' % (tag, seed), frac_ok=1e-3)
         with torch.no_grad():
             net.dropout_seed = 4000
-            draws = torch.stack([net(geo_rgb_feat(dev), *ins) for _ in range(200)]).cpu()
-            assert net.dropout_seed == 4200
+            draws = torch.stack([net(geo_rgb_feat(dev), *ins) for _ in range(max(stat_draws, 2))]).cpu()
+            assert net.dropout_seed == 4000 + max(stat_draws, 2)
             net.eval()
             ev = net(geo_rgb_feat(dev), *ins)
         assert_close(ev, g.np(tag + '/eval'), 1e-3, 1e-3 * float(np.abs(g.np(tag + '/eval')).max()), 'eval-mode output after training-mode calls')
+        if stat_draws < 100:        # (emulated kernels: the exact comparison only; the statistics are the GPU run's)
+            continue
         mean, std, n = g.np(tag + '/stat/mean'), g.np(tag + '/stat/std'), int(g.np(tag + '/stat/n'))
         se = np.sqrt(std ** 2 / n + draws.std(0).numpy() ** 2 / draws.shape[0]) + 1e-6
         zmax = float(np.abs((draws.mean(0).numpy() - mean) / se).max())

@@ -242,6 +242,13 @@ def test_gnt_training_mode_dropout():
     pc.check_gnt_train_mode('cpu')
 
 
+def test_gnt_training_mode_dropout_on_the_matrix_core_kernels():
+    """the Dropout-active network on the matrix-core kernels (emulated MFMA) against the reference capture with the same masks, 32
+    samples per ray -- exact part only (the statistics over hundreds of seeds are the GPU test's)"""
+    with wino_fp32_operands():
+        pc.check_gnt_train_mode('cpu', 'gnt_train_mfma_d2', expect_mfma=True, stat_draws=2)
+
+
 def test_gnt_universal_loop_in_training_mode():
     """a GNT attack step and the universal loop with the model left in training mode (the reference's eval/gnt/eval_adv.py:739-878)"""
     # (the Dropout sites live in the GNT kernels: the feature CNN runs as the plain nn.Module graph here, which the stand-in does not
