@@ -397,7 +397,12 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                 }
                 // [E] this step's products: the cross terms of order <= 2^-16
                 const wu4* a = opa[s & 1];
+#ifdef WB_EXP_NO_MFMA
+                // TIMING EXPERIMENT (wrong results): one vector instruction in place of each matrix instruction, operands kept alive
+#define WB_PROD(pa, pb) acc[nu][kb][(pa) + 3 * (pb)] += __builtin_bit_cast(float, a[pa][0]) * __builtin_bit_cast(float, bv[pb][0])
+#else
 #define WB_PROD(pa, pb) acc[nu][kb] = WB_MFMA(__builtin_bit_cast(wb8, a[pa]), __builtin_bit_cast(wb8, bv[pb]), acc[nu][kb])
+#endif
                 WB_PROD(0, 0);
                 if (NS >= 2) {
                     WB_PROD(0, 1);
