@@ -29,7 +29,7 @@ def table(kernels):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+    rnd = sys.argv[1] if len(sys.argv) > 1 else 'r06'
     b, g = load(rnd + '_bench_ibrnet.json'), load(rnd + '_bench_gnt.json')
     c5, c5f = load(rnd + '_bench_c5_bf16.json'), load(rnd + '_bench_c5_fp32.json')
     k1000 = load(rnd + '_bench_1000iters_ibrnet.json')
@@ -108,6 +108,21 @@ def main():
     opt('CNN glue micro-benchmark (`tools/bench_cnn_glue.py`)', '_cnn_glue_microbench.txt')
     opt('Plain bf16 operands in the 3x3 convolutions: measured and rejected (`tools/diag_bf16_cnn.py`)', '_plain_bf16_cnn_rejected.txt')
     opt('MFMA / VALU overlap probe (`tools/experimental/probe_overlap.hip`)', '_probe_mfma_valu_overlap.txt')
+    opt('Winograd kernel: what a launch is made of (timing builds, phase timers)', '_wino_ablation.txt')
+    opt('A sharded PGD step on the RCCL backend, one-rank group, every collective issued: eager vs hipGraph segments (`tools/shard_host_issue.py`)',
+        '_sharded_step_one_rank_rccl.json')
+    opt('Whole attacks against the reference\'s own float32 / float64 / other-order runs (`NERFOOL_PARITY_LOG` of the GPU tests)',
+        '_attack100_outcome.txt')
+    if 'universal' in ex:
+        u = ex['universal']
+        md.append('## Universal loop on one GPU (BASELINE config 3\'s loop, `extra.universal`)\n\n%d target views: %.2f ms per step once every view replays '
+                  '(%d captured graphs, first three cycles %.2f s, allocator peak %.2f GB); all-bf16x3 step (`extra.step_ms_all_bf16x3`): %.2f ms; '
+                  'host issue %.2f ms per step.\n' % (u['target_views'], u['ms_per_step'], u['graphs_captured'], u['first_three_cycles_s'],
+                                                   u['hbm_peak_allocated_gb'], ex.get('step_ms_all_bf16x3', float('nan')), b['host_issue_ms_per_step']))
+    if 'training_mode_step' in g['extra']:
+        t = g['extra']['training_mode_step']
+        md.append('## GNT in training mode (Dropout live, config 4\'s universal loop; `extra.training_mode_step` of the GNT bench line)\n\n'
+                  '%.2f ms per step = %.3f x the eval-mode step; kernels %s.\n' % (t['ms_per_step'], t['vs_eval_mode_step'], t['kernels_ms']))
     md.append('## Parity figures printed by the GPU tests (`%s_parity_numbers.txt`)\n\n```\n%s\n```\n' % (rnd, text(rnd + '_parity_numbers.txt')))
     with open(os.path.join(P, rnd + '_rocprofv3_summary.md'), 'w') as f:
         f.write('\n'.join(md))
