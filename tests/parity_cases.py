@@ -671,10 +671,15 @@ ATTACK100_BARS = {'loss_rel_max': (2.0, 0.0), 'loss_rel_mean': (2.0, 0.0), 'loss
                   'image_rms': (2.0, 0.0), 'psnr_diff': (2.0, 0.1)}
 
 
+def attack100_pairs(g):
+    """names of the reference's own run pairs a fixture holds distances for: three (float32, float64, one other order) in the round-5
+    fixtures, ten (five runs) in attack100_c2full"""
+    return [str(p) for p in g.np('floor_pairs')] if 'floor_pairs' in g else ['ref32_vs_ref64', 'alt32_vs_ref64', 'ref32_vs_alt32']
+
+
 def attack100_floor(g):
-    """the reference's own floor per statistic: the largest of its three run-to-run distances"""
-    pairs = ('ref32_vs_ref64', 'alt32_vs_ref64', 'ref32_vs_alt32')
-    return {k: max(float(g.np('floor/%s/%s' % (p, k))) for p in pairs) for k in ATTACK100_BARS}
+    """the reference's own floor per statistic: the largest of its run-to-run distances"""
+    return {k: max(float(g.np('floor/%s/%s' % (p, k))) for p in attack100_pairs(g)) for k in ATTACK100_BARS}
 
 
 def attack100_compare(tag, name, mine, g, eps, log=None, early_rtol=2e-3):
@@ -699,7 +704,12 @@ def attack100_compare(tag, name, mine, g, eps, log=None, early_rtol=2e-3):
         print(ln)
         if log is not None:
             log.append(ln)
+    # a floor that is a maximum over >= 6 pairs needs no absolute allowance on top (the allowances cover the three-pair fixtures, whose
+    # floor is a small sample of a noisy quantity); the PSNR keeps 0.1 dB: it is a difference of logarithms of nearly equal numbers
+    many = len(attack100_pairs(g)) >= 6
     for k, (mult, allow) in ATTACK100_BARS.items():
+        if many and k != 'psnr_diff':
+            allow = 0.0
         assert st64[k] <= mult * floor[k] + allow, '%s %s: %s = %.3e against %.1f x the reference floor %.3e (+ %.1e)' % (
             tag, name, k, st64[k], mult, floor[k], allow)
     # the first iterations, before the trajectories part: the reference's losses to rounding (sign-PGD moves every entry by a full

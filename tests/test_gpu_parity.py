@@ -196,11 +196,12 @@ def test_step_graph_equals_eager_step():
     pc.check_step_graph('cuda')
 
 
-@pytest.mark.parametrize('tag', ['c1', 'c2', 's1', 'u1'])
+@pytest.mark.parametrize('tag', ['c1', 'c2', 's1', 'u1', 'c2full'])
 def test_whole_attack_outcome(tag):
     """a whole free-running attack (100 iterations, attacked render, PSNR) against the reference's own float32 / float64 runs of it:
     tests/golden/attack100_<tag>.npz, bars = twice the reference's own run-to-run distance.  c1 / c2: view-specific Adam-ascent at
-    BASELINE config 1's shape / config 2's sampling; s1: sign-PGD; u1: the universal loop over two target views (config 3's loop)"""
+    BASELINE config 1's shape / config 2's sampling; s1: sign-PGD; u1: the universal loop over two target views (config 3's loop); c2full
+    (round 6): BASELINE config 2 at its real 756 x 1008 frame, five reference runs = ten pairwise distances, no absolute allowances"""
     log = []
     pc.check_attack100('cuda', tag, log)
     out = os.environ.get('NERFOOL_PARITY_LOG')
