@@ -467,11 +467,15 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int k = kbase + 32 * kb + wn_nidx(rsel + q, hh);
+#ifdef WB_EXP_NO_STORE
+                if (o[0][q] == 123.456f && k < K && row < Ho) yn[k * yo.cs + row * yo.rs + col] = o[1][q];      // TIMING EXPERIMENT: (almost) no stores
+#else
                 if (k < K && row < Ho) {
                     float* yp = yn + k * yo.cs + row * yo.rs + col;
                     if (col + 1 < Wo) *reinterpret_cast<w2f*>(yp) = w2f{o[0][q], o[1][q]};
                     else if (col < Wo) yp[0] = o[0][q];
                 }
+#endif
             }
         }
     }
