@@ -90,6 +90,9 @@ extern "C" int nf_wino_bf_pack(const float* weight, int c_out, int c_in, int bac
 // two fp32 values -> their bf16 roundings (packed) and the exact remainders
 __device__ __forceinline__ unsigned wb_split_pair(float& x0, float& x1) { return nf_split_pair_bf16(x0, x1); }
 
+#ifndef WB_A_GLOBAL
+#define WB_A_GLOBAL 0     // 1: A parts from global memory into registers one step ahead (no LDS ring) -- tuning form, see load_a
+#endif
 #ifndef WB_PIPE_E
 #define WB_PIPE_E 1       // the next chunk's window values are read under the last steps of the current chunk
 #endif
@@ -246,12 +249,28 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
 #pragma unroll
         for (int p = 0; p < NS; ++p) wa[p] = *reinterpret_cast<const wu4*>(rs + p * 256);
     };
+    // WB_A_GLOBAL (tuning form): the A parts of the NEXT step straight from global memory (L2) into the registers the LDS reads filled -- no
+    // ring, no LDS-DMA, no LDS read; the compiler counts the loads (vmcnt) itself
+    auto load_a = [&](wu4 (&wa)[NS]) {
+        const float* src = wnext + 4 * lane;
 #pragma unroll
-    for (int q = 0; q < DIST; ++q) issue_step(q);     // (at least NSTEP >= 4 > DIST steps in the stream)
-    fetch(0);
-    commit(0);          // the compiler drains the VM counter for the fetched registers here: the first DIST steps have landed too
-    __syncthreads();
-    read_a(opa[0], 0);
+        for (int p = 0; p < NS; ++p) wa[p] = *reinterpret_cast<const wu4*>(src + p * 256);
+        wnext += STEP;
+    };
+    constexpr bool AG = WB_A_GLOBAL != 0;
+    if (AG) {
+        load_a(opa[0]);     // step 0 (older than the window fetch below: a wait for it does not wait for the window)
+        fetch(0);
+        commit(0);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int q = 0; q < DIST; ++q) issue_step(q);     // (at least NSTEP >= 4 > DIST steps in the stream)
+        fetch(0);
+        commit(0);          // the compiler drains the VM counter for the fetched registers here: the first DIST steps have landed too
+        __syncthreads();
+        read_a(opa[0], 0);
+    }
     WB_T(t_pro);
     WB_ACC(7, t_pro - t_begin);
 
@@ -312,6 +331,7 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
         WB_T(t_e);
         WB_ACC(2, t_e - t_c0);
         // the next chunk's window travels global -> registers under this chunk's products, -> LDS in front of step HAND
+        if (AG && NSTEP > 1) load_a(opa[1]);          // step 1's parts: issued in front of the window fetch (older than it)
 #ifndef WB_EXP_NO_FETCH
         if (!last) fetch(chunk + 1);
 #endif
@@ -350,9 +370,13 @@ __global__ void __launch_bounds__(256, 2) k_wino3x3_bf(const float* __restrict__
                     WB_T(t_h1);
                     WB_ACC(4, t_h1 - t_h0);
                 }
+                if (AG) {
+                    // the parts of step s + 1 (the first step of the next chunk behind the last one), one step ahead of their use
+                    if (s >= 1 && (!last || s < NSTEP - 1)) load_a(opa[(s + 1) & 1]);
+                }
                 // [A] records of step s + DIST; never past the end of the stream
-                if (!last || s + DIST < NSTEP) issue_step(s + DIST);
-                if (!last || s < NSTEP - 1) {
+                if (!AG && (!last || s + DIST < NSTEP)) issue_step(s + DIST);
+                if (!AG && (!last || s < NSTEP - 1)) {
                     WB_T(t_w0);
                     // [C] the records of step s + 1 were issued DIST - 1 steps ago; behind them in the counter: the steps issued since
                     // (fewer at the end of the stream) and, while the window fetch of this chunk is younger than them, its 6 loads (the
